@@ -1,0 +1,244 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REFERENCE's own PyTorch code on CPU.
+
+Run in the build container only (needs /root/reference, which does not exist on the GPU box):
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/make_golden.py
+
+The reference has no tests or golden vectors for this path, so these files ARE the
+pin: tests/test_oracle_golden.py replays them against oracle/r3d_oracle.c (CPU) and
+tests/test_gpu_parity.py replays them against the HIP path (GPU).
+
+The two RNG draws inside the reference renderer (torch.rand_like at renderer.py:226 and torch.rand at
+renderer.py:281) are replaced, for the duration of the call, by functions returning pre-drawn arrays
+that are stored with the outputs, so every implementation sees identical sampling noise.
+"""
+import contextlib
+import os
+import sys
+
+import numpy as np
+
+REF = os.environ.get("R3D_REFERENCE", "/root/reference")
+REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.dont_write_bytecode = True
+sys.path.insert(0, REF)
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+
+from real3dportrait_amd import synth  # noqa: E402
+
+from modules.eg3ds.models.networks_stylegan2 import SynthesisBlock  # noqa: E402
+from modules.eg3ds.models.superresolution import SuperresolutionHybrid8XDC  # noqa: E402
+from modules.eg3ds.models.triplane import OSGDecoder, TriPlaneGenerator  # noqa: E402
+from modules.eg3ds.volumetric_rendering.ray_sampler import RaySampler  # noqa: E402
+from modules.eg3ds.volumetric_rendering.renderer import ImportanceRenderer  # noqa: E402
+from modules.eg3ds.volumetric_rendering import math_utils  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(8)
+
+
+@contextlib.contextmanager
+def injected_noise(noise_c, u_f):
+    """Make the renderer's two RNG draws return our arrays (shape-checked)."""
+    real_rand_like, real_rand = torch.rand_like, torch.rand
+    state = {"c": 0, "f": 0}
+
+    def fake_rand_like(t, *a, **k):
+        assert tuple(t.shape[:3]) == tuple(noise_c.shape[:3]), (t.shape, noise_c.shape)
+        state["c"] += 1
+        return torch.from_numpy(noise_c).reshape(t.shape).clone()
+
+    def fake_rand(*shape, **k):
+        shape = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else tuple(shape)
+        assert shape == tuple(u_f.shape), (shape, u_f.shape)
+        state["f"] += 1
+        return torch.from_numpy(u_f).clone()
+
+    torch.rand_like, torch.rand = fake_rand_like, fake_rand
+    try:
+        yield state
+    finally:
+        torch.rand_like, torch.rand = real_rand_like, real_rand
+
+
+def make_decoder(dec_np):
+    dec = OSGDecoder(32, {"decoder_lr_mul": 1, "decoder_output_dim": 32}).eval()
+    with torch.no_grad():
+        dec.net[0].weight.copy_(torch.from_numpy(dec_np[0]))
+        dec.net[0].bias.copy_(torch.from_numpy(dec_np[1]))
+        dec.net[2].weight.copy_(torch.from_numpy(dec_np[2]))
+        dec.net[2].bias.copy_(torch.from_numpy(dec_np[3]))
+    return dec
+
+
+def load_block(block, p):
+    with torch.no_grad():
+        for name in ("conv0", "conv1", "torgb"):
+            layer = getattr(block, name)
+            w, b, aw, ab = p[name]
+            layer.weight.copy_(torch.from_numpy(w))
+            layer.bias.copy_(torch.from_numpy(b))
+            layer.affine.weight.copy_(torch.from_numpy(aw))
+            layer.affine.bias.copy_(torch.from_numpy(ab))
+
+
+def opts(Nc, Nf, box_warp=1.0, white_back=False):
+    return {"ray_start": "auto", "ray_end": "auto", "box_warp": box_warp, "depth_resolution": Nc,
+            "depth_resolution_importance": Nf, "disparity_space_sampling": False, "clamp_mode": "softplus",
+            "white_back": white_back}
+
+
+def render_case(name, planes, cams, R, Nc, Nf, dec_seed, noise_seed, box_warp=1.0, white_back=False,
+                sigma_bias=0.0, store_planes=True, planes_spec=None):
+    cams = np.asarray(cams, np.float32).reshape(-1, 25)
+    N, M = cams.shape[0], R * R
+    dec_np = synth.synth_decoder(dec_seed, sigma_bias=sigma_bias)
+    dec = make_decoder(dec_np)
+    noise_c = synth.synth_noise(noise_seed, (N, M, Nc, 1), stream=7)
+    u_f = synth.synth_noise(noise_seed, (N * M, max(Nf, 1)), stream=8)[:, :Nf].copy() if Nf > 0 else np.zeros((N * M, 0), np.float32)
+    cam_t = torch.from_numpy(cams)
+    c2w, K = cam_t[:, :16].view(-1, 4, 4), cam_t[:, 16:].view(-1, 3, 3)
+    with torch.no_grad():
+        o, d = RaySampler()(c2w, K, R)
+        rs, re = math_utils.get_ray_limits_box(o, d, box_side_length=box_warp)
+        ren = ImportanceRenderer(hp={"enable_rescale_plane_regulation": False,
+                                     "triplane_feature_type": "triplane"}).eval()
+        with injected_noise(noise_c, u_f) as st:
+            rgb, depth, wsum, valid = ren(torch.from_numpy(planes), dec, o, d, opts(Nc, Nf, box_warp, white_back))
+        assert st["c"] == 1 and st["f"] == (1 if Nf > 0 else 0)
+    out = dict(cams=cams, R=R, Nc=Nc, Nf=Nf, box_warp=np.float32(box_warp), white_back=int(white_back),
+               dec_w1=dec_np[0], dec_b1=dec_np[1], dec_w2=dec_np[2], dec_b2=dec_np[3],
+               noise_c=noise_c, u_f=u_f,
+               origins=o.numpy(), dirs=d.numpy(), raw_start=rs.numpy(), raw_end=re.numpy(),
+               rgb=rgb.numpy(), depth=depth.numpy(), wsum=wsum.numpy(), valid=valid.numpy())
+    if store_planes:
+        out["planes"] = planes
+    else:
+        out["planes_spec"] = np.asarray(planes_spec, np.float64)   # (seed, N, C, H, W, scale)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "rgb", rgb.shape, "valid frac", float(valid.float().mean()), "wsum mean", float(wsum.mean()))
+
+
+def run_model_case(name):
+    planes = synth.synth_planes(21, N=2, H=32, W=32)
+    dec_np = synth.synth_decoder(22)
+    dec = make_decoder(dec_np)
+    coords = (synth.synth_noise(23, (2, 777, 3)) - 0.5) * 1.3     # includes points outside the +-0.5 box
+    ren = ImportanceRenderer(hp={"enable_rescale_plane_regulation": False, "triplane_feature_type": "triplane"}).eval()
+    with torch.no_grad():
+        out = ren.run_model(torch.from_numpy(planes), dec, torch.from_numpy(coords), None, opts(16, 0))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), planes=planes, coords=coords.astype(np.float32),
+                        dec_w1=dec_np[0], dec_b1=dec_np[1], dec_w2=dec_np[2], dec_b2=dec_np[3],
+                        rgb=out["rgb"].numpy(), sigma=out["sigma"].numpy(), box_warp=np.float32(1.0))
+    print(name, out["rgb"].shape)
+
+
+def sr_small_case(name):
+    """The reference's SynthesisBlock pair (32->256 @ res 32, 256->128 @ res 64): same layers as
+    SuperresolutionHybrid8XDC (superresolution.py:342-345) at 1/8 spatial size."""
+    seed = 31
+    params = synth.synth_sr_params(seed)
+    kw = dict(w_dim=512, img_channels=3, use_fp16=False, conv_clamp=None, channel_base=32768, channel_max=512,
+              fused_modconv_default="inference_only")
+    b0 = SynthesisBlock(32, 256, resolution=32, is_last=False, **kw).eval()
+    b1 = SynthesisBlock(256, 128, resolution=64, is_last=True, **kw).eval()
+    load_block(b0, params[0])
+    load_block(b1, params[1])
+    x = synth.hash_unitvar(seed, (1, 32, 16, 16), stream=1)
+    rgb = synth.hash_unitvar(seed, (1, 3, 16, 16), stream=2) * np.float32(0.5)
+    ws = (np.ones((1, 3, 512), np.float32) + synth.hash_unitvar(seed, (1, 3, 512), stream=3) * np.float32(0.1))
+    with torch.no_grad():
+        x0, r0 = b0(torch.from_numpy(x), torch.from_numpy(rgb), torch.from_numpy(ws), noise_mode="none")
+        x1, r1 = b1(x0, r0, torch.from_numpy(ws), noise_mode="none")
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=seed, x=x, rgb=rgb, ws=ws,
+                        x0=x0.numpy()[:, ::4], rgb0=r0.numpy(), x1=x1.numpy()[:, ::8], rgb1=r1.numpy())
+    print(name, r1.shape, float(r1.abs().mean()))
+
+
+def sr_full_case(name):
+    """SuperresolutionHybrid8XDC 128^2 -> 512^2 with all-ones ws (what Real3D feeds it,
+    secc_img2plane_torso.py:15 / triplane.py:131-132)."""
+    seed = 41
+    params = synth.synth_sr_params(seed)
+    sr = SuperresolutionHybrid8XDC(channels=32, img_resolution=512, sr_num_fp16_res=0, sr_antialias=True,
+                                   channel_base=32768, channel_max=512, fused_modconv_default="inference_only").eval()
+    load_block(sr.block0, params[0])
+    load_block(sr.block1, params[1])
+    x = synth.hash_unitvar(seed, (1, 32, 128, 128), stream=1)
+    rgb = x[:, :3].copy()
+    ws = np.ones((1, 14, 512), np.float32)
+    with torch.no_grad():
+        out = sr(torch.from_numpy(rgb), torch.from_numpy(x), torch.from_numpy(ws), noise_mode="none").numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=seed, strided=out[:, :, ::4, ::4],
+                        corner=out[:, :, :96, :96], tail=out[:, :, -64:, -64:],
+                        mean=np.float64(out.mean()), absmean=np.float64(np.abs(out).mean()))
+    print(name, out.shape, float(np.abs(out).mean()))
+
+
+def synthesis_case(name):
+    """TriPlaneGenerator.synthesis (modules/eg3ds/models/triplane.py:90-138) at the reference default:
+    R=128, 48+48 samples, SR to 512^2, cached planes, ones ws."""
+    from utils.commons.hparams import set_hparams, hparams
+    set_hparams(os.path.join(REF, "egs/egs_bases/eg3d/base.yaml"), print_hparams=False)
+    hparams.update(ray_near="auto", ray_far="auto", ones_ws_for_sr=True, enable_rescale_plane_regulation=False)
+    G = TriPlaneGenerator().eval()
+    seed = 51
+    dec_np = synth.synth_decoder(seed, sigma_bias=4.0)
+    with torch.no_grad():
+        G.decoder.net[0].weight.copy_(torch.from_numpy(dec_np[0]))
+        G.decoder.net[0].bias.copy_(torch.from_numpy(dec_np[1]))
+        G.decoder.net[2].weight.copy_(torch.from_numpy(dec_np[2]))
+        G.decoder.net[2].bias.copy_(torch.from_numpy(dec_np[3]))
+    params = synth.synth_sr_params(seed)
+    load_block(G.superresolution.block0, params[0])
+    load_block(G.superresolution.block1, params[1])
+    planes = synth.synth_planes(seed, N=1)
+    G._last_planes = torch.from_numpy(planes).view(1, 96, 256, 256)
+    cam = synth.look_at_camera(0.25, -0.1)[None]
+    R, Nc, Nf = 128, 48, 48
+    noise_c = synth.synth_noise(seed, (1, R * R, Nc, 1), stream=7)
+    u_f = synth.synth_noise(seed, (R * R, Nf), stream=8)
+    with torch.no_grad(), injected_noise(noise_c, u_f):
+        out = G.synthesis(torch.ones(1, G.backbone.num_ws, 512), torch.from_numpy(cam), use_cached_backbone=True,
+                          noise_mode="none")
+    img = out["image"].numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=seed, cam=cam, R=R, Nc=Nc, Nf=Nf,
+                        image_strided=img[:, :, ::4, ::4], image_corner=img[:, :, :96, :96],
+                        image_raw=out["image_raw"].numpy(), image_depth=out["image_depth"].numpy(),
+                        image_feature_strided=out["image_feature"].numpy()[:, ::4],
+                        absmean=np.float64(np.abs(img).mean()))
+    print(name, img.shape, float(np.abs(img).mean()))
+
+
+def main():
+    which = sys.argv[1:] or ["render", "run_model", "sr_small", "sr_full", "synthesis"]
+    if "render" in which:
+        small = synth.synth_planes(1, N=1, H=32, W=32)
+        render_case("render_a_r16_16p16", small, [synth.look_at_camera(0.0, 0.0)], 16, 16, 16, 2, 3)
+        small2 = synth.synth_planes(4, N=2, H=32, W=32)
+        render_case("render_b_n2_r16_48p48", small2, synth.camera_sweep(2, -0.3, 0.3), 16, 48, 48, 5, 6,
+                    sigma_bias=4.0)
+        # camera pushed sideways: a large share of rays misses the box (exercises the fix-up, Q2/Q3)
+        cam = synth.look_at_camera(0.1, 0.05)
+        cam[3] += 0.45
+        render_case("render_c_invalid_r16_16p0", small, [cam], 16, 16, 0, 7, 8)
+        render_case("render_e_white_r12_32p16_bw", small, [synth.look_at_camera(-0.2, 0.15)], 12, 32, 16, 9, 10,
+                    box_warp=1.2, white_back=True, sigma_bias=2.0)
+        big = synth.synth_planes(11, N=1)
+        render_case("render_d_cfg1_r64_16p16", big, [synth.look_at_camera(0.0, 0.0)], 64, 16, 16, 12, 13,
+                    store_planes=False, planes_spec=(11, 1, 32, 256, 256, 1.0), sigma_bias=3.0)
+    if "run_model" in which:
+        run_model_case("run_model_a")
+    if "sr_small" in which:
+        sr_small_case("sr_small_a")
+    if "sr_full" in which:
+        sr_full_case("sr_full_a")
+    if "synthesis" in which:
+        synthesis_case("synthesis_ref_a")
+
+
+if __name__ == "__main__":
+    main()
