@@ -1,0 +1,137 @@
+/*
+ * r3d_hip.h -- C ABI of libr3d_hip.so: MI355X (gfx950) native tri-plane NeRF render + super-resolution.
+ *
+ * This is the drop-in boundary for the per-frame hot path of Real3D-Portrait.  The reference has no
+ * native renderer (it is ~25 eager ATen ops per pass) and three pybind11/CUDA plugins for the SR
+ * blocks; every entry point below names the reference interface it replaces (file:line relative to the
+ * upstream repo).  All pointers are BORROWED raw device pointers (fp32 unless noted), all tensors are
+ * contiguous, `stream` is a hipStream_t passed as void*.  No function synchronises, allocates or frees
+ * device memory.  Every function returns 0 on success or a negative r3d_status; the message of the last
+ * failure on the calling thread is available from r3d_last_error().
+ *
+ * Reference-side binding: see INTEGRATION.md (ctypes stub a maintainer would add).
+ */
+#ifndef R3D_HIP_H
+#define R3D_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* r3d_stream_t; /* hipStream_t */
+
+enum r3d_status {
+    R3D_OK = 0,
+    R3D_ERR_INVALID_ARG = -1,   /* shape / pointer / option outside what the kernels support */
+    R3D_ERR_WORKSPACE = -2,     /* workspace pointer NULL or too small */
+    R3D_ERR_LAUNCH = -3,        /* HIP launch / runtime error (message has hipGetErrorString) */
+    R3D_ERR_UNSUPPORTED = -4    /* valid in the reference, not implemented here (e.g. trigrid) */
+};
+
+#define R3D_FEATURES 32         /* tri-plane channels C            (img2plane_model.py:72-82)        */
+#define R3D_HIDDEN 64           /* OSGDecoder hidden width         (modules/eg3ds/models/triplane.py:169) */
+#define R3D_DECODER_OUT 33      /* 1 density + 32 colour features  (triplane.py:175)                 */
+
+int r3d_version(void);
+const char* r3d_last_error(void);
+
+/* --- plane layout -------------------------------------------------------------------------------
+ * Re-lays tri-planes from the reference's NCHW [N,3,C,H,W] to channel-last [N,3,H,W,C] so that each
+ * bilinear tap is one contiguous 128-byte read, optionally fusing the per-frame `cano + secc` add.
+ * Replaces: the plane add in OSAvatarSECC_Img2plane.cal_plane_given_cano (modules/real3d/
+ * secc_img2plane.py:73-81) + the reshape at modules/eg3ds/volumetric_rendering/renderer.py:68.
+ * `add` may be NULL. */
+int r3d_planes_to_nhwc(const float* planes_nchw, const float* add_nchw, float* planes_nhwc,
+                       int N, int C, int H, int W, r3d_stream_t stream);
+
+/* --- A1 ray generation --------------------------------------------------------------------------
+ * Replaces RaySampler.forward(cam2world[N,4,4], intrinsics[N,3,3], resolution)
+ * (modules/eg3ds/volumetric_rendering/ray_sampler.py:24-63).  origins/dirs: [N, R*R, 3]. */
+int r3d_raygen(const float* c2w, const float* intrinsics, int N, int R,
+               float* origins, float* dirs, r3d_stream_t stream);
+
+/* --- A2..A10 volume render ----------------------------------------------------------------------
+ * Replaces ImportanceRenderer.forward(planes, decoder, ray_origins, ray_directions, rendering_options)
+ * (modules/eg3ds/volumetric_rendering/renderer.py:118-167) with ray_start == ray_end == 'auto',
+ * disparity_space_sampling False, clamp_mode 'softplus', feature type 'triplane': box limits + fix-up
+ * (math_utils.py:46-98, renderer.py:121-126), stratified depths (:209-232), tri-plane sampling (:65-75),
+ * OSGDecoder (modules/eg3ds/models/triplane.py:177-189), MipRayMarcher2 (ray_marcher.py:25-57),
+ * importance resampling (:234-297), sort-merge (:197-207) and the final composite.
+ *
+ *   planes_nhwc  [N,3,H,W,32]      from r3d_planes_to_nhwc
+ *   w1,b1,w2,b2  RAW decoder parameters decoder.net.0.{weight[64,32],bias[64]}, decoder.net.2.{weight[33,64],
+ *                bias[33]}; the FullyConnectedLayer gains 1/sqrt(fan_in) are applied inside
+ *   origins,dirs [N,M,3]
+ *   Nc, Nf       depth_resolution / depth_resolution_importance (4 <= Nc <= 96, 0 <= Nf <= 96)
+ *   noise_c      [N,M,Nc] U[0,1) stratification jitter (the reference's torch.rand_like, renderer.py:226)
+ *   u_f          [N*M,Nf] U[0,1) importance draws       (the reference's torch.rand,      renderer.py:281)
+ *                either may be NULL: the kernel then draws from a counter-based hash of
+ *                (seed, ray, sample), which makes a frame's noise independent of how frames are sharded
+ *   rgb [N,M,32], depth [N,M], wsum [N,M], valid [N,M] (1 byte, is_ray_valid)
+ *   workspace    r3d_render_workspace_bytes() bytes of device scratch
+ */
+size_t r3d_render_workspace_bytes(int N, int M, int Nc, int Nf);
+int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
+                       const float* w1, const float* b1, const float* w2, const float* b2,
+                       const float* origins, const float* dirs, int M,
+                       int Nc, int Nf, float box_warp, int white_back,
+                       const float* noise_c, const float* u_f, uint64_t seed,
+                       float* rgb, float* depth, float* wsum, uint8_t* valid,
+                       void* workspace, size_t workspace_bytes, r3d_stream_t stream);
+
+/* Replaces ImportanceRenderer.run_model(planes, decoder, sample_coordinates, sample_directions, options)
+ * (renderer.py:169-188; inference branches) -- the point-query used by .sample() (triplane.py:140-148).
+ * coords [N,npts,3] -> rgb [N,npts,32], sigma [N,npts]. */
+int r3d_run_model(const float* planes_nhwc, int N, int H, int W,
+                  const float* w1, const float* b1, const float* w2, const float* b2,
+                  const float* coords, int npts, float box_warp,
+                  float* rgb, float* sigma, r3d_stream_t stream);
+
+/* --- A12..A14 super-resolution ------------------------------------------------------------------
+ * One StyleGAN2 SynthesisBlock (architecture 'skip', up=2, fp32, eval, noise_mode 'none'):
+ * replaces SynthesisBlock.forward (modules/eg3ds/models/networks_stylegan2.py:429-473) including
+ * modulated_conv2d (:37-94), conv2d_resample up=2 path (torch_utils/ops/conv2d_resample.py:116-133),
+ * and the three plugin calls it makes: bias_act_plugin.bias_act (ops/bias_act.cpp:36),
+ * upfirdn2d_plugin.upfirdn2d (ops/upfirdn2d.cpp:20) for the post-T-conv FIR and the RGB-skip upsample2d.
+ *
+ * r3d_sr_block_pack: modulation + demodulation + re-layout of the raw parameters for one batch of
+ * style vectors (runs every forward; ~1.7 M parameters):
+ *   ws3 [N,3,WD] (conv0, conv1, torgb style inputs);  *_w/_b/_aw/_ab = layer.weight / .bias /
+ *   .affine.weight / .affine.bias;   packed: r3d_sr_block_packed_bytes(N,Cin,Cout) bytes.
+ * r3d_sr_block_forward:
+ *   x [N,Cin,Hin,Win] NCHW or channel-blocked (see x_blocked), img [N,3,Hin,Win] NCHW
+ *   -> x_out (channel-blocked [N,Cout/8,2Hin,2Win,8]; NCHW if x_out_nchw != 0), img_out [N,3,2Hin,2Win] NCHW.
+ *   clamp < 0 disables conv_clamp (the fp32 configuration Real3D uses, img2plane_baseline.py:102-104).
+ */
+size_t r3d_sr_block_packed_bytes(int N, int Cin, int Cout);
+size_t r3d_sr_block_workspace_bytes(int N, int Cin, int Cout, int Hin, int Win);
+int r3d_sr_block_pack(const float* ws3, int N, int WD, int Cin, int Cout,
+                      const float* c0_w, const float* c0_b, const float* c0_aw, const float* c0_ab,
+                      const float* c1_w, const float* c1_b, const float* c1_aw, const float* c1_ab,
+                      const float* rgb_w, const float* rgb_b, const float* rgb_aw, const float* rgb_ab,
+                      void* packed, r3d_stream_t stream);
+int r3d_sr_block_forward(const void* packed, int N, int Cin, int Cout, int Hin, int Win,
+                         const float* x, int x_blocked, const float* img, float clamp,
+                         float* x_out, int x_out_nchw, float* img_out,
+                         void* workspace, size_t workspace_bytes, r3d_stream_t stream);
+
+/* --- output side --------------------------------------------------------------------------------
+ * clamp(-1,1) -> (x+1)*127.5 -> uint8 HWC, the conversion real3d_infer.py:495-521 does on the host
+ * after the frame loop; used to build the per-rank frame ring that is gathered over RCCL.
+ * img [N,3,H,W] fp32 -> out [N,H,W,3] uint8. */
+int r3d_frames_to_u8(const float* img, int N, int H, int W, uint8_t* out, r3d_stream_t stream);
+
+/* Time a region with HIP events ON THE GIVEN STREAM (bench.py's roofline leg): returns elapsed ms
+ * between two events; handles are opaque. */
+int r3d_event_create(void** ev);
+int r3d_event_record(void* ev, r3d_stream_t stream);
+int r3d_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
+int r3d_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* R3D_HIP_H */

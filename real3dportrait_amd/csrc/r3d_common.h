@@ -1,0 +1,47 @@
+// Shared helpers for the gfx950 kernels (device + host side of libr3d_hip.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/r3d_hip.h"
+
+namespace r3d {
+
+void set_error(const char* fmt, ...);
+int check_launch(const char* what);
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- ordered-int encoding so float min/max can use integer atomics --------------------------------
+__device__ __forceinline__ int f2ord(float f) {
+    int b = __float_as_int(f);
+    return b >= 0 ? b : b ^ 0x7fffffff;
+}
+__device__ __forceinline__ float ord2f(int k) {
+    return __int_as_float(k >= 0 ? k : k ^ 0x7fffffff);
+}
+
+// ---- fast transcendentals on the hardware exp2/log2 (<= ~1 ulp of the result scale) ---------------
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float flog(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+// torch.nn.Softplus(beta=1, threshold=20)
+__device__ __forceinline__ float softplus20(float x) {
+    const float r = fmaxf(x, 0.0f) + flog(1.0f + fexp(-fabsf(x)));
+    return x > 20.0f ? x : r;
+}
+__device__ __forceinline__ float sigmoidf(float x) { return __builtin_amdgcn_rcpf(1.0f + fexp(-x)); }
+
+// ---- counter-based uniform [0,1) (used when the caller passes no noise tensors) ---------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ float hash_uniform(uint64_t seed, uint32_t stream, uint64_t idx) {
+    uint32_t h = mix32((uint32_t)seed ^ 0x9E3779B9U * (stream + 1));
+    h = mix32(h ^ (uint32_t)(seed >> 32));
+    h = mix32(h ^ (uint32_t)idx);
+    h = mix32(h ^ (uint32_t)(idx >> 32) ^ 0x85ebca6bU);
+    return (float)(h >> 8) * (1.0f / 16777216.0f);
+}
+
+}  // namespace r3d

@@ -1,0 +1,815 @@
+// Fused tri-plane NeRF volume renderer for gfx950 (MI355X).
+//
+// One wavefront renders one ray end-to-end: stratified depths -> tri-plane gather -> decoder MLP on
+// f32 MFMA -> coarse ray-march weights -> importance resampling -> second gather/MLP pass ->
+// sorted merge -> wavefront-level alpha composite.  Nothing per-sample ever goes to HBM: the 48+48
+// decoded colours of a ray stay in the wave's MFMA accumulator registers until the composite weights
+// are known, and the composite  sum_k w_k (c_k+c_{k+1})/2  is evaluated as  sum_i omega_i c_i  with
+// omega_i = (w_{r(i)-1}+w_{r(i)})/2 (r = rank of sample i in depth order), so colours are never sorted
+// or moved -- only the 96 (depth, density) scalars are.
+//
+// Lane mapping (wave64): lane = (q = lane>>4, s = lane&15).  A "tile" is 16 samples; lane (q,s) owns
+// channels 8q..8q+7 of sample s of each tile, so the four lanes of a sample read one 128-byte
+// channel-last tap as 4 x 32 B and the gathered features ARE the B operand of
+// v_mfma_f32_16x16x4_f32 (k-slot q <-> channel 8q+kk).  The MLP is evaluated transposed
+// (H^T = W1 X^T, Y^T = W2 H^T) so layer-1 accumulators feed layer 2 as B operands directly
+// (k-slot q <-> hidden unit 16mt+4q+reg): no LDS round trip between gather, layer 1, softplus, layer 2.
+//
+// Behaviour restated from (upstream repo paths): modules/eg3ds/volumetric_rendering/renderer.py:118-297,
+// ray_marcher.py:25-57, math_utils.py:46-118, ray_sampler.py:24-63, modules/eg3ds/models/triplane.py:177-189.
+#include "r3d_common.h"
+
+namespace r3d {
+
+static constexpr int kC = R3D_FEATURES;      // 32
+static constexpr int kHid = R3D_HIDDEN;      // 64
+static constexpr int kOut = R3D_DECODER_OUT; // 33
+static constexpr int kWavesPerBlock = 4;
+static constexpr int kMaxSamples = 192;      // Nc + Nf
+static constexpr int kRayArr = kMaxSamples + 8;
+
+// -------------------------------------------------------------------------------------------------
+// layout kernel: NCHW [N*3][C][H*W] (+ optional add) -> [N*3][H*W][C]
+// -------------------------------------------------------------------------------------------------
+__global__ void planes_to_nhwc_kernel(const float* __restrict__ src, const float* __restrict__ add,
+                                      float* __restrict__ dst, int C, int HW)
+{
+    __shared__ float tile[32][33];
+    const int p = blockIdx.z;
+    const int hw0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;   // 32 x 8
+    const float* s = src + (size_t)p * C * HW;
+    const float* a = add ? add + (size_t)p * C * HW : nullptr;
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, hw = hw0 + tx;
+        float v = 0.f;
+        if (c < C && hw < HW) { v = s[(size_t)c * HW + hw]; if (a) v += a[(size_t)c * HW + hw]; }
+        tile[j][tx] = v;
+    }
+    __syncthreads();
+    float* d = dst + (size_t)p * HW * C;
+    for (int j = ty; j < 32; j += 8) {
+        const int hw = hw0 + j, c = c0 + tx;
+        if (c < C && hw < HW) d[(size_t)hw * C + c] = tile[tx][j];
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// A1 ray generation (ray_sampler.py:24-63)
+// -------------------------------------------------------------------------------------------------
+__global__ void raygen_kernel(const float* __restrict__ c2w, const float* __restrict__ K, int R,
+                              float* __restrict__ origins, float* __restrict__ dirs)
+{
+    const int n = blockIdx.y;
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    const int M = R * R;
+    if (m >= M) return;
+    const float* Cm = c2w + 16 * n;
+    const float* Kn = K + 9 * n;
+    const float fx = Kn[0], sk = Kn[1], cx = Kn[2], fy = Kn[4], cy = Kn[5];
+    const float inv_r = 1.0f / (float)R, half_r = 0.5f / (float)R;
+    const int i = m / R, j = m - i * R;
+    const float xc = (float)j * inv_r + half_r;
+    const float yc = (float)i * inv_r + half_r;
+    const float xl = (xc - cx + cy * sk / fy - sk * yc / fy) / fx;
+    const float yl = (yc - cy) / fy;
+    const float camx = Cm[3], camy = Cm[7], camz = Cm[11];
+    float dx = Cm[0] * xl + Cm[1] * yl + Cm[2] + Cm[3] - camx;
+    float dy = Cm[4] * xl + Cm[5] * yl + Cm[6] + Cm[7] - camy;
+    float dz = Cm[8] * xl + Cm[9] * yl + Cm[10] + Cm[11] - camz;
+    const float nrm = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
+    const size_t o = 3 * ((size_t)n * M + m);
+    origins[o] = camx; origins[o + 1] = camy; origins[o + 2] = camz;
+    dirs[o] = dx / nrm; dirs[o + 1] = dy / nrm; dirs[o + 2] = dz / nrm;
+}
+
+// -------------------------------------------------------------------------------------------------
+// A2 ray/box limits (math_utils.py:46-98) + global min/max of valid ray starts (renderer.py:123-126)
+// gstate: [0] ord(min tmin over valid), [1] ord(max tmin over valid), [2] any valid,
+//         [3] ord(min depth), [4] ord(max depth)   (depth range for ray_marcher.py:50)
+// -------------------------------------------------------------------------------------------------
+__global__ void init_state_kernel(int* gstate)
+{
+    gstate[0] = 0x7fffffff; gstate[1] = (int)0x80000000; gstate[2] = 0;
+    gstate[3] = 0x7fffffff; gstate[4] = (int)0x80000000;
+}
+
+__global__ void ray_limits_kernel(const float* __restrict__ origins, const float* __restrict__ dirs,
+                                  int nrays, float half, float* __restrict__ ray_start,
+                                  float* __restrict__ ray_end, uint8_t* __restrict__ valid, int* gstate)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    float tmin = 0.f, tmax = 0.f;
+    bool v = false;
+    if (r < nrays) {
+        float lo[3], hi[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const float o = origins[3 * (size_t)r + a];
+            const float inv = 1.0f / dirs[3 * (size_t)r + a];
+            const bool neg = inv < 0.0f;
+            lo[a] = ((neg ? half : -half) - o) * inv;
+            hi[a] = ((neg ? -half : half) - o) * inv;
+        }
+        bool ok = true;
+        tmin = lo[0]; tmax = hi[0];
+        if (tmin > hi[1] || lo[1] > tmax) ok = false;
+        tmin = fmaxf(tmin, lo[1]); tmax = fminf(tmax, hi[1]);
+        if (tmin > hi[2] || lo[2] > tmax) ok = false;
+        tmin = fmaxf(tmin, lo[2]); tmax = fminf(tmax, hi[2]);
+        if (!ok) { tmin = -1.0f; tmax = -2.0f; }
+        v = tmax > tmin;
+        ray_start[r] = tmin; ray_end[r] = tmax; valid[r] = v ? 1 : 0;
+    }
+    // wave reduce then one atomic per wave
+    int kmin = v ? f2ord(tmin) : 0x7fffffff;
+    int kmax = v ? f2ord(tmin) : (int)0x80000000;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        kmin = min(kmin, __shfl_xor(kmin, d));
+        kmax = max(kmax, __shfl_xor(kmax, d));
+    }
+    const unsigned long long any = __ballot(v);
+    if ((threadIdx.x & 63) == 0 && any) {
+        atomicMin(&gstate[0], kmin);
+        atomicMax(&gstate[1], kmax);
+        atomicOr(&gstate[2], 1);
+    }
+}
+
+// ray_marcher.py:46-50: nan_to_num(inf) then clamp to the global [min, max] of all depths of the call
+__global__ void depth_clamp_kernel(float* __restrict__ depth, int nrays, const int* __restrict__ gstate)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrays) return;
+    const float lo = ord2f(gstate[3]), hi = ord2f(gstate[4]);
+    float v = depth[r];
+    if (v != v) v = INFINITY;
+    depth[r] = fminf(fmaxf(v, lo), hi);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Decoder weights staged in LDS in MFMA A-fragment order (shared by the block's waves)
+// -------------------------------------------------------------------------------------------------
+struct DecoderLds {
+    float w1f[4 * 8 * 64];     // [mt][kk][lane]  = W1eff[16mt+(l&15)][8(l>>4)+kk]
+    float w2f[2 * 16 * 64];    // [ot][mt*4+reg][lane] = W2eff[1+16ot+(l&15)][16mt+4(l>>4)+reg]
+    float w2s[kHid];           // W2eff[0][:]  (density row, evaluated on the VALU)
+    float b1[kHid];
+    float b2[kOut];            // b2[0] density bias, b2[1..32] colour biases
+};
+
+__device__ __forceinline__ void stage_decoder(DecoderLds& L, const float* __restrict__ w1,
+                                              const float* __restrict__ b1, const float* __restrict__ w2,
+                                              const float* __restrict__ b2)
+{
+    // FullyConnectedLayer: w * (1/sqrt(in_features))  (networks_stylegan2.py:115,119)
+    const float g1 = 0.17677669529663687f;  // 1/sqrt(32)
+    const float g2 = 0.125f;                // 1/sqrt(64)
+    for (int i = threadIdx.x; i < 4 * 8 * 64; i += blockDim.x) {
+        const int l = i & 63, kk = (i >> 6) & 7, mt = i >> 9;
+        L.w1f[i] = w1[(16 * mt + (l & 15)) * kC + 8 * (l >> 4) + kk] * g1;
+    }
+    for (int i = threadIdx.x; i < 2 * 16 * 64; i += blockDim.x) {
+        const int l = i & 63, ks = (i >> 6) & 15, ot = i >> 10;
+        const int mt = ks >> 2, reg = ks & 3;
+        L.w2f[i] = w2[(1 + 16 * ot + (l & 15)) * kHid + 16 * mt + 4 * (l >> 4) + reg] * g2;
+    }
+    for (int i = threadIdx.x; i < kHid; i += blockDim.x) { L.w2s[i] = w2[i] * g2; L.b1[i] = b1[i]; }
+    for (int i = threadIdx.x; i < kOut; i += blockDim.x) L.b2[i] = b2[i];
+}
+
+// -------------------------------------------------------------------------------------------------
+// A4 tri-plane gather for one sample (this lane: channels 8q..8q+7).  grid_sample semantics:
+// bilinear, zeros padding, align_corners=False (renderer.py:71-74); plane0 (x,y), plane1 (x,z),
+// plane2 (z,x); first coordinate indexes W.  planes: [3][H][W][32] floats viewed as float4.
+// -------------------------------------------------------------------------------------------------
+struct Tap { int idx; float w; };
+
+__device__ __forceinline__ void plane_taps(float u, float v, int H, int W, int plane_base4, Tap t[4])
+{
+    const float ix = ((u + 1.0f) * (float)W - 1.0f) * 0.5f;
+    const float iy = ((v + 1.0f) * (float)H - 1.0f) * 0.5f;
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float fx1 = ix - x0f, fy1 = iy - y0f;          // weight of the +1 neighbour
+    const float fx0 = (x0f + 1.0f) - ix, fy0 = (y0f + 1.0f) - iy;
+    // clamp before the int conversion so NaN/inf coordinates become "out of range"
+    const float xc = fminf(fmaxf(x0f, -2.0f), (float)W + 1.0f);
+    const float yc = fminf(fmaxf(y0f, -2.0f), (float)H + 1.0f);
+    const int x0 = (int)xc, y0 = (int)yc;
+    const bool okc = (xc == x0f) && (yc == y0f);
+    const bool vx0 = okc && x0 >= 0 && x0 < W, vx1 = okc && x0 + 1 >= 0 && x0 + 1 < W;
+    const bool vy0 = okc && y0 >= 0 && y0 < H, vy1 = okc && y0 + 1 >= 0 && y0 + 1 < H;
+    const int xa = min(max(x0, 0), W - 1), xb = min(max(x0 + 1, 0), W - 1);
+    const int ya = min(max(y0, 0), H - 1), yb = min(max(y0 + 1, 0), H - 1);
+    t[0].idx = plane_base4 + (ya * W + xa) * 8; t[0].w = (vx0 && vy0) ? fx0 * fy0 : 0.0f;
+    t[1].idx = plane_base4 + (ya * W + xb) * 8; t[1].w = (vx1 && vy0) ? fx1 * fy0 : 0.0f;
+    t[2].idx = plane_base4 + (yb * W + xa) * 8; t[2].w = (vx0 && vy1) ? fx0 * fy1 : 0.0f;
+    t[3].idx = plane_base4 + (yb * W + xb) * 8; t[3].w = (vx1 && vy1) ? fx1 * fy1 : 0.0f;
+}
+
+__device__ __forceinline__ void gather_sample(const float4* __restrict__ planes4, int H, int W, int q,
+                                              float px, float py, float pz, float scale, float x[8])
+{
+    const float qx = px * scale, qy = py * scale, qz = pz * scale;
+    Tap t[12];
+    const int HW8 = H * W * 8;
+    plane_taps(qx, qy, H, W, 0 * HW8 + 2 * q, t + 0);
+    plane_taps(qx, qz, H, W, 1 * HW8 + 2 * q, t + 4);
+    plane_taps(qz, qx, H, W, 2 * HW8 + 2 * q, t + 8);
+    float4 lo[12], hi[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) { lo[i] = planes4[t[i].idx]; hi[i] = planes4[t[i].idx + 1]; }
+    float acc[3][8];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[p][c] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float w = t[4 * p + k].w;
+            const float4 a = lo[4 * p + k], b = hi[4 * p + k];
+            acc[p][0] += a.x * w; acc[p][1] += a.y * w; acc[p][2] += a.z * w; acc[p][3] += a.w * w;
+            acc[p][4] += b.x * w; acc[p][5] += b.y * w; acc[p][6] += b.z * w; acc[p][7] += b.w * w;
+        }
+    }
+    // mean over the three planes (triplane.py:179)
+#pragma unroll
+    for (int c = 0; c < 8; ++c) x[c] = (acc[0][c] + acc[1][c] + acc[2][c]) * (1.0f / 3.0f);
+}
+
+// -------------------------------------------------------------------------------------------------
+// A5 decoder for NT tiles of 16 samples.  X[nt][kk]: this lane's 8 gathered channels per tile.
+// Out: col[ot][nt] (4 regs each) = colour channel 16ot+4q+reg of sample 16nt+s  (after the sigmoid
+// clamp of triplane.py:187); sig[nt] = density of sample 16nt+s (replicated over q).
+// -------------------------------------------------------------------------------------------------
+template <int NT>
+__device__ __forceinline__ void decode_tiles(const DecoderLds& L, int lane, const float (&X)[NT][8],
+                                             f32x4 (&col)[2][NT], float (&sig)[NT])
+{
+    const int q = lane >> 4;
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+        f32x4 b;
+        b[0] = L.b2[1 + 16 * ot + 4 * q + 0]; b[1] = L.b2[1 + 16 * ot + 4 * q + 1];
+        b[2] = L.b2[1 + 16 * ot + 4 * q + 2]; b[3] = L.b2[1 + 16 * ot + 4 * q + 3];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) col[ot][nt] = b;
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) sig[nt] = 0.0f;
+
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        f32x4 h[NT];
+        f32x4 bias;
+        bias[0] = L.b1[16 * mt + 4 * q + 0]; bias[1] = L.b1[16 * mt + 4 * q + 1];
+        bias[2] = L.b1[16 * mt + 4 * q + 2]; bias[3] = L.b1[16 * mt + 4 * q + 3];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) h[nt] = bias;
+        // layer 1: H^T[16mt.., samples] += W1[16mt.., ch] X^T
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const float a = L.w1f[(mt * 8 + kk) * 64 + lane];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                h[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, X[nt][kk], h[nt], 0, 0, 0);
+        }
+        // softplus in place; density row on the VALU
+        float ws[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ws[r] = L.w2s[16 * mt + 4 * q + r];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                h[nt][r] = softplus20(h[nt][r]);
+                sig[nt] += h[nt][r] * ws[r];
+            }
+        }
+        // layer 2 partial: Y^T[1+16ot.., samples] += W2[.., 16mt+4q+reg] H^T
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+                const float a = L.w2f[(ot * 16 + mt * 4 + r) * 64 + lane];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    col[ot][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, h[nt][r], col[ot][nt], 0, 0, 0);
+            }
+        }
+    }
+    // density: reduce the 4 k-slot rows (lanes l, l^16, l^32, l^48), add bias
+    const float bs = L.b2[0];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        float v = sig[nt];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        sig[nt] = v + bs;
+    }
+    // sigmoid clamp from MipNeRF: sigmoid(y)*(1+2*0.001)-0.001
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) col[ot][nt][r] = sigmoidf(col[ot][nt][r]) * 1.002f - 0.001f;
+}
+
+// -------------------------------------------------------------------------------------------------
+// wave scans
+// -------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_incl_mul(float v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const float o = __shfl_up(v, d); if (lane >= d) v *= o; }
+    return v;
+}
+__device__ __forceinline__ float wave_incl_add(float v, int lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const float o = __shfl_up(v, d); if (lane >= d) v += o; }
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+__device__ __forceinline__ void wave_lds_sync() {
+    // LDS traffic of one wave is in order; this only stops the compiler from reordering around it
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// per-wave scratch
+struct RayLds {
+    float t[kRayArr];      // depths: [0,Nc) coarse as generated, [Nc,Nc+Nf) fine
+    float sg[kRayArr];     // densities, same indexing
+    float ts[kRayArr];     // depth-sorted depths
+    float ss[kRayArr];     // depth-sorted densities
+    float wv[kRayArr];     // interval weights (coarse order first, later sorted order)
+    float om[kRayArr];     // omega per ORIGINAL sample index
+    float cdf[104];
+};
+
+// A6 on n samples T/S (LDS, in the order to march): writes interval weights to wv[0..n-2],
+// returns (sum w, sum w*tmid) wave-uniform.   ray_marcher.py:26-45
+template <int SLOTS>
+__device__ __forceinline__ void march(const float* T, const float* S, float* wv, int n, int lane,
+                                      float& wsum, float& dsum)
+{
+    float carry = 1.0f, ws = 0.0f, ds = 0.0f;
+#pragma unroll
+    for (int sl = 0; sl < SLOTS; ++sl) {
+        const int i = sl * 64 + lane;
+        const bool act = i < n - 1;
+        const int i0 = act ? i : 0;
+        const float t0 = T[i0], t1 = T[i0 + 1], s0 = S[i0], s1 = S[i0 + 1];
+        const float delta = t1 - t0;
+        const float dmid = (s0 + s1) * 0.5f;
+        const float tmid = (t0 + t1) * 0.5f;
+        const float sp = softplus20(dmid - 1.0f);
+        const float alpha = 1.0f - fexp(-(sp * delta));
+        const float om1 = act ? (1.0f - alpha + 1e-10f) : 1.0f;
+        const float incl = wave_incl_mul(om1, lane);
+        float excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = 1.0f;
+        const float w = act ? alpha * (carry * excl) : 0.0f;
+        carry *= __shfl(incl, 63);
+        if (act) wv[i] = w;
+        ws += w;
+        ds += w * tmid;
+    }
+    wsum = wave_sum(ws);
+    dsum = wave_sum(ds);
+}
+
+struct RenderArgs {
+    const float4* planes4; int N, H, W, M;
+    const float* w1; const float* b1; const float* w2; const float* b2;
+    const float* origins; const float* dirs;
+    const float* ray_start; const float* ray_end; const uint8_t* valid;
+    int* gstate;
+    int Nc, Nf; float scale; int white_back;
+    const float* noise_c; const float* u_f; unsigned long long seed;
+    float* rgb; float* depth; float* wsum;
+};
+
+// Ray order: XCD x (= blockIdx % 8, the observed dispatch rule -- speed only) renders the column strip
+// [x*R/8, (x+1)*R/8) of every image, walking DOWN columns, so that the waves resident on one XCD share
+// the XZ / ZX plane rows in that XCD's L2 and vertical neighbours hit the same taps in L1.
+__device__ __forceinline__ bool next_ray(const RenderArgs& a, int R, int iter, int wave, int& ray)
+{
+    const int nrays = a.N * a.M;
+    if (R > 0 && (R & 7) == 0 && (gridDim.x & 7) == 0) {
+        const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+        const int strip = R >> 3;
+        const long long wj = (long long)iter * nbx * kWavesPerBlock + bx * kWavesPerBlock + wave;
+        const long long per_img = (long long)strip * R;
+        if (wj >= per_img * a.N) return false;
+        const int n = (int)(wj / per_img);
+        const int rem = (int)(wj - (long long)n * per_img);
+        const int col = xcd * strip + rem / R, row = rem % R;
+        ray = n * a.M + row * R + col;
+        return true;
+    }
+    const long long wi = (long long)iter * gridDim.x * kWavesPerBlock + blockIdx.x * kWavesPerBlock + wave;
+    if (wi >= nrays) return false;
+    ray = (int)wi;
+    return true;
+}
+
+template <int NTC, int NTF>
+__global__ __launch_bounds__(256, 2) void render_kernel(RenderArgs a, int R)
+{
+    constexpr int SLOTS = (16 * (NTC + NTF) + 63) / 64;
+    constexpr int CSLOTS = (16 * NTC + 63) / 64;
+    constexpr int FSLOTS = NTF > 0 ? (16 * NTF + 63) / 64 : 1;
+    __shared__ __attribute__((aligned(16))) DecoderLds dec;
+    __shared__ __attribute__((aligned(16))) RayLds rl[kWavesPerBlock];
+
+    stage_decoder(dec, a.w1, a.b1, a.w2, a.b2);
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, s = lane & 15;
+    RayLds& L = rl[wave];
+    const int Nc = a.Nc, Nf = a.Nf, S = Nc + Nf;
+    const float gmin_start = ord2f(a.gstate[0]), gmax_start = ord2f(a.gstate[1]);
+    const bool any_valid = a.gstate[2] != 0;
+    float run_min = INFINITY, run_max = -INFINITY;
+
+    for (int iter = 0;; ++iter) {
+        int ray;
+        if (!next_ray(a, R, iter, wave, ray)) break;
+        const int n = ray / a.M;
+        const float4* P = a.planes4 + (size_t)n * 3 * a.H * a.W * 8;
+        const float ox = a.origins[3 * (size_t)ray], oy = a.origins[3 * (size_t)ray + 1], oz = a.origins[3 * (size_t)ray + 2];
+        const float dx = a.dirs[3 * (size_t)ray], dy = a.dirs[3 * (size_t)ray + 1], dz = a.dirs[3 * (size_t)ray + 2];
+        float start = a.ray_start[ray], end = a.ray_end[ray];
+        if (!a.valid[ray] && any_valid) { start = gmin_start; end = gmax_start; }   // renderer.py:125-126
+
+        // ---- A3 stratified depths: linspace(start,end,Nc) + U*delta  (renderer.py:223-226) --------------
+        const float span = end - start;
+        const float delta = span / (float)(Nc - 1);
+        float tc[NTC];
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt) {
+            const int k = 16 * nt + s;
+            const bool act = k < Nc;
+            const float step = (float)k / (float)(Nc - 1);
+            float u = 0.0f;
+            if (act) u = a.noise_c ? a.noise_c[(size_t)ray * Nc + k] : hash_uniform(a.seed, 0, (uint64_t)ray * Nc + k);
+            tc[nt] = act ? (start + step * span) + u * delta : start;
+        }
+        // ---- coarse pass: gather + decode ----------------------------------------------------------------
+        f32x4 colc[2][NTC];
+        float sigc[NTC];
+        {
+            float X[NTC][8];
+#pragma unroll
+            for (int nt = 0; nt < NTC; ++nt)
+            {
+                gather_sample(P, a.H, a.W, q, ox + tc[nt] * dx, oy + tc[nt] * dy, oz + tc[nt] * dz, a.scale, X[nt]);
+                __builtin_amdgcn_sched_barrier(0);   // one tile's 24 loads in flight at a time (VGPR budget)
+            }
+            decode_tiles<NTC>(dec, lane, X, colc, sigc);
+        }
+        if (q == 0) {
+#pragma unroll
+            for (int nt = 0; nt < NTC; ++nt) {
+                const int k = 16 * nt + s;
+                if (k < Nc) { L.t[k] = tc[nt]; L.sg[k] = sigc[nt]; }
+            }
+        }
+        wave_lds_sync();
+
+        float wsum, dsum;
+        f32x4 colf[2][NTF > 0 ? NTF : 1];
+        bool fine_done = false;
+        if constexpr (NTF > 0) { if (Nf > 0) {
+            fine_done = true;
+            // ---- coarse weights (ray_marcher on the samples as generated, renderer.py:147) ----------------
+            march<CSLOTS>(L.t, L.sg, L.wv, Nc, lane, wsum, dsum);
+            wave_lds_sync();
+            // ---- A7 importance sampling (renderer.py:241-296) ------------------------------------------
+            const int ns = Nc - 3;
+            float omega[CSLOTS], tot = 0.0f;
+#pragma unroll
+            for (int sl = 0; sl < CSLOTS; ++sl) {
+                const int i = sl * 64 + lane;
+                const bool act = i < ns;
+                const int i0 = act ? i : 0;
+                const float w0 = L.wv[i0], w1v = L.wv[i0 + 1], w2v = L.wv[i0 + 2];
+                const float sv = (fmaxf(w0, w1v) + fmaxf(w1v, w2v)) * 0.5f + 0.01f;
+                omega[sl] = act ? sv + 1e-5f : 0.0f;
+                tot += omega[sl];
+            }
+            tot = wave_sum(tot);
+            float carry = 0.0f;
+            if (lane == 0) L.cdf[0] = 0.0f;
+#pragma unroll
+            for (int sl = 0; sl < CSLOTS; ++sl) {
+                const int i = sl * 64 + lane;
+                const float incl = wave_incl_add(omega[sl] / tot, lane);
+                if (i < ns) L.cdf[i + 1] = carry + incl;
+                carry += __shfl(incl, 63);
+            }
+            wave_lds_sync();
+#pragma unroll
+            for (int sl = 0; sl < FSLOTS; ++sl) {
+                const int j = sl * 64 + lane;
+                if (j < Nf) {
+                    const float u = a.u_f ? a.u_f[(size_t)ray * Nf + j] : hash_uniform(a.seed, 1, (uint64_t)ray * Nf + j);
+                    int lo = 0, hi = ns + 1;          // searchsorted(cdf, u, right=True)
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (L.cdf[mid] <= u) lo = mid + 1; else hi = mid; }
+                    const int below = max(lo - 1, 0), above = min(lo, ns);
+                    const float cb = L.cdf[below], ca = L.cdf[above];
+                    const float bb = 0.5f * (L.t[below] + L.t[below + 1]);
+                    const float ba = 0.5f * (L.t[above] + L.t[above + 1]);
+                    float den = ca - cb;
+                    if (den < 1e-5f) den = 1.0f;
+                    L.t[Nc + j] = bb + (u - cb) / den * (ba - bb);
+                }
+            }
+            wave_lds_sync();
+            // ---- fine pass ----------------------------------------------------------------------------------
+            float sigf[NTF > 0 ? NTF : 1];
+            {
+                float X[NTF > 0 ? NTF : 1][8];
+#pragma unroll
+                for (int nt = 0; nt < NTF; ++nt) {
+                    const int k = 16 * nt + s;
+                    const float tf = L.t[Nc + (k < Nf ? k : 0)];
+                    gather_sample(P, a.H, a.W, q, ox + tf * dx, oy + tf * dy, oz + tf * dz, a.scale, X[nt]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                decode_tiles<(NTF > 0 ? NTF : 1)>(dec, lane, X, colf, sigf);
+            }
+            if (q == 0) {
+#pragma unroll
+                for (int nt = 0; nt < NTF; ++nt) {
+                    const int k = 16 * nt + s;
+                    if (k < Nf) L.sg[Nc + k] = sigf[nt];
+                }
+            }
+            wave_lds_sync();
+            // ---- A8 merge: rank of every sample in depth order (stable), scatter (t, sigma) ----------------
+            int rank[SLOTS];
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                const int i = sl * 64 + lane;
+                const float ti = L.t[i < S ? i : 0];
+                int cnt = 0;
+                for (int j = 0; j < S; ++j) {
+                    const float tj = L.t[j];
+                    cnt += (tj < ti || (tj == ti && j < i)) ? 1 : 0;
+                }
+                rank[sl] = cnt;
+                if (i < S) { L.ts[cnt] = ti; L.ss[cnt] = L.sg[i]; }
+            }
+            wave_lds_sync();
+            march<SLOTS>(L.ts, L.ss, L.wv, S, lane, wsum, dsum);
+            wave_lds_sync();
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                const int i = sl * 64 + lane, r = rank[sl];
+                if (i < S) {
+                    const float wl = r > 0 ? L.wv[r - 1] : 0.0f;
+                    const float wr = r < S - 1 ? L.wv[r] : 0.0f;
+                    L.om[i] = 0.5f * (wl + wr);
+                }
+            }
+        } }
+        if (!fine_done) {
+            march<CSLOTS>(L.t, L.sg, L.wv, Nc, lane, wsum, dsum);
+            wave_lds_sync();
+#pragma unroll
+            for (int sl = 0; sl < CSLOTS; ++sl) {
+                const int i = sl * 64 + lane;
+                if (i < Nc) {
+                    const float wl = i > 0 ? L.wv[i - 1] : 0.0f;
+                    const float wr = i < Nc - 1 ? L.wv[i] : 0.0f;
+                    L.om[i] = 0.5f * (wl + wr);
+                }
+            }
+        }
+        wave_lds_sync();
+
+        // ---- composite colour:  sum_i omega_i c_i  (== sum_k w_k (c_k + c_{k+1})/2, ray_marcher.py:44) ---
+        f32x4 acc[2];
+        acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[1] = acc[0];
+#pragma unroll
+        for (int nt = 0; nt < NTC; ++nt) {
+            const int k = 16 * nt + s;
+            const float om = k < Nc ? L.om[k] : 0.0f;
+            acc[0] += colc[0][nt] * om;
+            acc[1] += colc[1][nt] * om;
+        }
+        if constexpr (NTF > 0) {
+#pragma unroll
+            for (int nt = 0; nt < NTF; ++nt) {
+                const int k = 16 * nt + s;
+                const float om = (fine_done && k < Nf) ? L.om[Nc + k] : 0.0f;
+                acc[0] += colf[0][nt] * om;
+                acc[1] += colf[1][nt] * om;
+            }
+        }
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = acc[ot][r];
+                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                if (a.white_back) v = v + 1.0f - wsum;
+                acc[ot][r] = v * 2.0f - 1.0f;            // ray_marcher.py:52-55
+            }
+        if (s == 0) {
+            float4* o4 = reinterpret_cast<float4*>(a.rgb + (size_t)ray * kC);
+            o4[q] = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+            o4[4 + q] = make_float4(acc[1][0], acc[1][1], acc[1][2], acc[1][3]);
+        }
+        // depth range of the marched samples (global clamp, ray_marcher.py:50)
+        float lmin = INFINITY, lmax = -INFINITY;
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            const int i = sl * 64 + lane;
+            if (i < S) { const float v = L.t[i]; lmin = fminf(lmin, v); lmax = fmaxf(lmax, v); }
+        }
+        run_min = fminf(run_min, lmin); run_max = fmaxf(run_max, lmax);
+        if (lane == 0) {
+            a.depth[ray] = dsum / wsum;                  // NaN handled + clamped by depth_clamp_kernel
+            a.wsum[ray] = wsum;
+        }
+        wave_lds_sync();
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        run_min = fminf(run_min, __shfl_xor(run_min, d));
+        run_max = fmaxf(run_max, __shfl_xor(run_max, d));
+    }
+    if (lane == 0 && run_min <= run_max) {
+        atomicMin(&a.gstate[3], f2ord(run_min));
+        atomicMax(&a.gstate[4], f2ord(run_max));
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// run_model (renderer.py:169-188): point queries, 64 points per wave iteration
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void run_model_kernel(const float4* __restrict__ planes4, int N, int H, int W,
+                                                          const float* w1, const float* b1, const float* w2, const float* b2,
+                                                          const float* __restrict__ coords, int npts, float scale,
+                                                          float* __restrict__ rgb, float* __restrict__ sigma)
+{
+    __shared__ __attribute__((aligned(16))) DecoderLds dec;
+    stage_decoder(dec, w1, b1, w2, b2);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int q = lane >> 4, s = lane & 15;
+    const long long total = (long long)N * npts;
+    const long long chunks = (total + 63) / 64;
+    for (long long ch = (long long)blockIdx.x * kWavesPerBlock + wave; ch < chunks; ch += (long long)gridDim.x * kWavesPerBlock) {
+        float X[4][8];
+        long long idx[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            idx[nt] = ch * 64 + 16 * nt + s;
+            const long long ii = idx[nt] < total ? idx[nt] : total - 1;
+            const int n = (int)(ii / npts);
+            const float4* P = planes4 + (size_t)n * 3 * H * W * 8;
+            gather_sample(P, H, W, q, coords[3 * ii], coords[3 * ii + 1], coords[3 * ii + 2], scale, X[nt]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        f32x4 col[2][4];
+        float sig[4];
+        decode_tiles<4>(dec, lane, X, col, sig);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            if (idx[nt] < total) {
+                float4* o4 = reinterpret_cast<float4*>(rgb + (size_t)idx[nt] * kC);
+                o4[q] = make_float4(col[0][nt][0], col[0][nt][1], col[0][nt][2], col[0][nt][3]);
+                o4[4 + q] = make_float4(col[1][nt][0], col[1][nt][1], col[1][nt][2], col[1][nt][3]);
+                if (q == 0) sigma[idx[nt]] = sig[nt];
+            }
+        }
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// host side
+// -------------------------------------------------------------------------------------------------
+struct RenderWs { int gstate[8]; };   // followed by ray_start[nrays], ray_end[nrays]
+
+template <int NTC, int NTF>
+static void launch_render(const RenderArgs& a, int R, int grid, hipStream_t st)
+{
+    hipLaunchKernelGGL((render_kernel<NTC, NTF>), dim3(grid), dim3(256), 0, st, a, R);
+}
+
+}  // namespace r3d
+
+using namespace r3d;
+
+extern "C" int r3d_planes_to_nhwc(const float* planes_nchw, const float* add_nchw, float* planes_nhwc,
+                                  int N, int C, int H, int W, r3d_stream_t stream)
+{
+    if (!planes_nchw || !planes_nhwc || N <= 0 || C <= 0 || H <= 0 || W <= 0) { set_error("planes_to_nhwc: bad argument"); return R3D_ERR_INVALID_ARG; }
+    const int HW = H * W;
+    dim3 grid((HW + 31) / 32, (C + 31) / 32, N * 3), block(32, 8);
+    hipLaunchKernelGGL(planes_to_nhwc_kernel, grid, block, 0, (hipStream_t)stream, planes_nchw, add_nchw, planes_nhwc, C, HW);
+    return check_launch("planes_to_nhwc");
+}
+
+extern "C" int r3d_raygen(const float* c2w, const float* intrinsics, int N, int R,
+                          float* origins, float* dirs, r3d_stream_t stream)
+{
+    if (!c2w || !intrinsics || !origins || !dirs || N <= 0 || R <= 0) { set_error("raygen: bad argument"); return R3D_ERR_INVALID_ARG; }
+    dim3 grid((R * R + 255) / 256, N);
+    hipLaunchKernelGGL(raygen_kernel, grid, dim3(256), 0, (hipStream_t)stream, c2w, intrinsics, R, origins, dirs);
+    return check_launch("raygen");
+}
+
+extern "C" size_t r3d_render_workspace_bytes(int N, int M, int Nc, int Nf)
+{
+    (void)Nc; (void)Nf;
+    const size_t nrays = (size_t)N * M;
+    return sizeof(RenderWs) + 2 * nrays * sizeof(float) + 64;
+}
+
+extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
+                                  const float* w1, const float* b1, const float* w2, const float* b2,
+                                  const float* origins, const float* dirs, int M,
+                                  int Nc, int Nf, float box_warp, int white_back,
+                                  const float* noise_c, const float* u_f, uint64_t seed,
+                                  float* rgb, float* depth, float* wsum, uint8_t* valid,
+                                  void* workspace, size_t workspace_bytes, r3d_stream_t stream)
+{
+    if (!planes_nhwc || !w1 || !b1 || !w2 || !b2 || !origins || !dirs || !rgb || !depth || !wsum || !valid) {
+        set_error("render_forward: NULL pointer"); return R3D_ERR_INVALID_ARG;
+    }
+    if (N <= 0 || M <= 0 || H <= 1 || W <= 1 || !(box_warp > 0.f)) { set_error("render_forward: bad shape"); return R3D_ERR_INVALID_ARG; }
+    if (Nc < 4 || Nc > 96 || Nf < 0 || Nf > 96) {
+        set_error("render_forward: depth_resolution %d / importance %d outside [4,96] / [0,96]", Nc, Nf);
+        return R3D_ERR_INVALID_ARG;
+    }
+    if ((size_t)H * W * 3 * 8 * (size_t)1 >= (size_t)0x7fffffff) { set_error("render_forward: planes too large for 32-bit tap index"); return R3D_ERR_INVALID_ARG; }
+    if (!workspace || workspace_bytes < r3d_render_workspace_bytes(N, M, Nc, Nf)) { set_error("render_forward: workspace too small"); return R3D_ERR_WORKSPACE; }
+    hipStream_t st = (hipStream_t)stream;
+    const int nrays = N * M;
+    int* gstate = reinterpret_cast<int*>(workspace);
+    float* ray_start = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + sizeof(RenderWs));
+    float* ray_end = ray_start + nrays;
+
+    hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, st, gstate);
+    hipLaunchKernelGGL(ray_limits_kernel, dim3((nrays + 255) / 256), dim3(256), 0, st, origins, dirs, nrays,
+                       box_warp * 0.5f, ray_start, ray_end, valid, gstate);
+
+    RenderArgs a;
+    a.planes4 = reinterpret_cast<const float4*>(planes_nhwc); a.N = N; a.H = H; a.W = W; a.M = M;
+    a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
+    a.origins = origins; a.dirs = dirs; a.ray_start = ray_start; a.ray_end = ray_end; a.valid = valid;
+    a.gstate = gstate; a.Nc = Nc; a.Nf = Nf; a.scale = 2.0f / box_warp; a.white_back = white_back;
+    a.noise_c = noise_c; a.u_f = u_f; a.seed = seed;
+    a.rgb = rgb; a.depth = depth; a.wsum = wsum;
+
+    // square image -> XCD strip order; otherwise linear order
+    int R = 0;
+    for (int r = 1; r * r <= M; ++r) if (r * r == M) R = r;
+    const int waves_needed = nrays;
+    int grid = 512;                                   // 2 blocks per CU on 256 CUs, multiple of 8 (XCD strips)
+    const int max_blocks = ((waves_needed + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8;
+    if (grid > max_blocks) grid = max_blocks;
+
+    const int ntc = (Nc + 15) / 16, ntf = (Nf + 15) / 16;
+#define R3D_CASE(C_, F_) else if (ntc == C_ && ntf == F_) launch_render<C_, F_>(a, R, grid, st)
+    if (false) {}
+    R3D_CASE(1, 0); R3D_CASE(1, 1); R3D_CASE(2, 0); R3D_CASE(2, 1); R3D_CASE(2, 2);
+    R3D_CASE(3, 0); R3D_CASE(3, 1); R3D_CASE(3, 2); R3D_CASE(3, 3);
+    R3D_CASE(4, 0); R3D_CASE(4, 4); R3D_CASE(6, 0); R3D_CASE(6, 6);
+    else if (ntf == 0 && ntc <= 6) launch_render<6, 0>(a, R, grid, st);
+    else if (ntc <= 3 && ntf <= 3) launch_render<3, 3>(a, R, grid, st);
+    else if (ntc <= 4 && ntf <= 4) launch_render<4, 4>(a, R, grid, st);
+    else launch_render<6, 6>(a, R, grid, st);
+#undef R3D_CASE
+    hipLaunchKernelGGL(depth_clamp_kernel, dim3((nrays + 255) / 256), dim3(256), 0, st, depth, nrays, gstate);
+    return check_launch("render_forward");
+}
+
+extern "C" int r3d_run_model(const float* planes_nhwc, int N, int H, int W,
+                             const float* w1, const float* b1, const float* w2, const float* b2,
+                             const float* coords, int npts, float box_warp,
+                             float* rgb, float* sigma, r3d_stream_t stream)
+{
+    if (!planes_nhwc || !w1 || !b1 || !w2 || !b2 || !coords || !rgb || !sigma || N <= 0 || npts <= 0 || !(box_warp > 0.f)) {
+        set_error("run_model: bad argument"); return R3D_ERR_INVALID_ARG;
+    }
+    const long long chunks = ((long long)N * npts + 63) / 64;
+    int grid = (int)((chunks + kWavesPerBlock - 1) / kWavesPerBlock);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(run_model_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(planes_nhwc), N, H, W, w1, b1, w2, b2, coords, npts,
+                       2.0f / box_warp, rgb, sigma);
+    return check_launch("run_model");
+}

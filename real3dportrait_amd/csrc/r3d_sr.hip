@@ -1,0 +1,514 @@
+// StyleGAN2-style super-resolution SynthesisBlock for gfx950 (MI355X), fp32 in / fp32 accumulate.
+//
+// Behaviour restated from the upstream repo: modules/eg3ds/models/networks_stylegan2.py:37-94 (modulated_conv2d),
+// :286-373 (SynthesisLayer / ToRGBLayer), :429-473 (SynthesisBlock.forward);
+// modules/eg3ds/torch_utils/ops/conv2d_resample.py:116-133 (up=2 = conv_transpose2d stride 2 + 4x4 FIR, gain 4);
+// ops/upfirdn2d.py:72-116,171-215,317-354 (FIR taps outer([1,3,3,1])/64, upsample2d); ops/bias_act.py:93-122.
+//
+// MI355X design:
+//  * activations live channel-blocked "CB8": [N][C/8][H][W][8] fp32, so a pixel's 8-channel group is one
+//    32-byte unit: patch staging, MFMA operand reads (ds_read_b128) and epilogue stores are all 16-byte
+//    vectors and a wave's epilogue store covers 1 KB contiguous;
+//  * every 3x3 / transposed conv is ONE implicit-GEMM kernel on v_mfma_f32_32x32x2_f32 computed
+//    transposed, D[cout][pixel] = sum_tap W_tap[cout][ci] X[ci][pixel+off(tap)]: the 10x18 input patch of a
+//    block's 8x16 pixel tile is staged once in LDS and re-read at 9 shifted positions (9x less global
+//    traffic than im2col), weights stream from L2 straight into A-operand registers (packed so that a
+//    wave's load is 1 KB contiguous), bias + lrelu*sqrt(2) (+clamp) run in the epilogue;
+//  * the stride-2 transposed conv runs as 4 output phases with 4/2/2/1 taps (9 tap-GEMMs per 4 output
+//    pixels: no multiply-by-zero work), followed by a fused FIR4x4 + bias + lrelu kernel;
+//  * modulation/demodulation is a per-forward packing kernel (no host sync, any ws), not a grouped conv.
+#include "r3d_common.h"
+
+namespace r3d {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static constexpr int TILE_H = 8, TILE_W = 16;          // output pixels per block
+static constexpr int PATCH_H = TILE_H + 2, PATCH_W = TILE_W + 2, PATCH_PIX = PATCH_H * PATCH_W;   // 180
+static constexpr int CHUNKS_PER_STAGE = 4;             // 4 x 8 = 32 input channels per LDS stage
+static constexpr int BLOCK_M = 128;                    // output channels per block
+
+// -------------------------------------------------------------------------------------------------
+// layout kernels
+// -------------------------------------------------------------------------------------------------
+__global__ void nchw_to_cb8_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int HW)
+{
+    // one thread per (cb, pixel): gathers 8 channels
+    const int n = blockIdx.z, cb = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    const float* s = src + ((size_t)n * C + cb * 8) * HW + p;
+    float v[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) v[c] = s[(size_t)c * HW];
+    float4* d = reinterpret_cast<float4*>(dst + (((size_t)n * (C / 8) + cb) * HW + p) * 8);
+    d[0] = make_float4(v[0], v[1], v[2], v[3]);
+    d[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+__global__ void cb8_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int C, int HW)
+{
+    const int n = blockIdx.z, cb = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    const float4* s = reinterpret_cast<const float4*>(src + (((size_t)n * (C / 8) + cb) * HW + p) * 8);
+    const float4 a = s[0], b = s[1];
+    float* d = dst + ((size_t)n * C + cb * 8) * HW + p;
+    d[0] = a.x; d[(size_t)HW] = a.y; d[(size_t)2 * HW] = a.z; d[(size_t)3 * HW] = a.w;
+    d[(size_t)4 * HW] = b.x; d[(size_t)5 * HW] = b.y; d[(size_t)6 * HW] = b.z; d[(size_t)7 * HW] = b.w;
+}
+
+// -------------------------------------------------------------------------------------------------
+// weight packing: styles = affine(w) (networks_stylegan2.py:326, FullyConnectedLayer :99-131),
+// w'' = W*s*rsqrt(sum (W*s)^2 + 1e-8) (:62-70); toRGB: styles/sqrt(Cin), no demod (:366-368)
+// packed (floats, per batch item): see SrPackLayout
+// -------------------------------------------------------------------------------------------------
+struct SrPackLayout {
+    size_t styles0, styles1, styles2, wp0, wp1, wrgb, b0, b1, brgb, total;
+};
+static __host__ __device__ inline SrPackLayout sr_layout(int Cin, int Cout)
+{
+    SrPackLayout L;
+    size_t o = 0;
+    L.styles0 = o; o += Cin;
+    L.styles1 = o; o += Cout;
+    L.styles2 = o; o += Cout;
+    o = (o + 3) & ~(size_t)3;
+    L.wp0 = o; o += (size_t)9 * Cin * Cout;
+    L.wp1 = o; o += (size_t)9 * Cout * Cout;
+    L.wrgb = o; o += (size_t)3 * Cout;
+    L.b0 = o; o += Cout;
+    L.b1 = o; o += Cout;
+    L.brgb = o; o += 4;
+    L.total = (o + 3) & ~(size_t)3;
+    return L;
+}
+
+// grid (3 layers, N); each wave computes style rows
+__global__ void sr_styles_kernel(const float* __restrict__ ws3, int WD, int Cin, int Cout,
+                                 const float* __restrict__ aw0, const float* __restrict__ ab0,
+                                 const float* __restrict__ aw1, const float* __restrict__ ab1,
+                                 const float* __restrict__ aw2, const float* __restrict__ ab2,
+                                 float* __restrict__ packed, size_t stride_n)
+{
+    const int layer = blockIdx.x, n = blockIdx.y;
+    const SrPackLayout L = sr_layout(Cin, Cout);
+    const float* aw = layer == 0 ? aw0 : (layer == 1 ? aw1 : aw2);
+    const float* ab = layer == 0 ? ab0 : (layer == 1 ? ab1 : ab2);
+    const int C = layer == 0 ? Cin : Cout;
+    float* out = packed + n * stride_n + (layer == 0 ? L.styles0 : (layer == 1 ? L.styles1 : L.styles2));
+    const float* w = ws3 + ((size_t)n * 3 + layer) * WD;
+    const float g = rsqrtf((float)WD);
+    const float post = layer == 2 ? rsqrtf((float)Cout) : 1.0f;     // ToRGB weight_gain
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int c = wave; c < C; c += nw) {
+        float acc = 0.f;
+        for (int j = lane; j < WD; j += 64) acc += w[j] * (aw[(size_t)c * WD + j] * g);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+        if (lane == 0) out[c] = (acc + ab[c]) * post;
+    }
+}
+
+// grid (Cout, N, 2): one block per output channel of conv0 (z=0) / conv1 (z=1)
+// packed conv weights: [tap][ci/8][cout][ci%8]
+__global__ void sr_modulate_kernel(int Cin, int Cout, const float* __restrict__ w0, const float* __restrict__ w1,
+                                   float* __restrict__ packed, size_t stride_n)
+{
+    const int co = blockIdx.x, n = blockIdx.y, layer = blockIdx.z;
+    const SrPackLayout L = sr_layout(Cin, Cout);
+    const int Ci = layer == 0 ? Cin : Cout;
+    const float* W = (layer == 0 ? w0 : w1) + (size_t)co * Ci * 9;
+    float* base = packed + n * stride_n;
+    const float* st = base + (layer == 0 ? L.styles0 : L.styles1);
+    float* wp = base + (layer == 0 ? L.wp0 : L.wp1);
+    __shared__ float red[4];
+    float ss = 0.f;
+    for (int i = threadIdx.x; i < Ci * 9; i += blockDim.x) { const float v = W[i] * st[i / 9]; ss += v * v; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) ss += __shfl_xor(ss, d);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    float tot = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) tot += red[i];
+    const float dco = rsqrtf(tot + 1e-8f);
+    for (int i = threadIdx.x; i < Ci * 9; i += blockDim.x) {
+        const int ci = i / 9, tap = i - ci * 9;
+        wp[(((size_t)tap * (Ci / 8) + (ci >> 3)) * Cout + co) * 8 + (ci & 7)] = W[i] * st[ci] * dco;
+    }
+}
+
+__global__ void sr_pack_misc_kernel(int Cin, int Cout, const float* __restrict__ wrgb, const float* __restrict__ b0,
+                                    const float* __restrict__ b1, const float* __restrict__ brgb,
+                                    float* __restrict__ packed, size_t stride_n)
+{
+    const int n = blockIdx.y;
+    const SrPackLayout L = sr_layout(Cin, Cout);
+    float* base = packed + n * stride_n;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 3 * Cout) base[L.wrgb + i] = wrgb[i] * base[L.styles2 + (i % Cout)];
+    if (i < Cout) { base[L.b0 + i] = b0[i]; base[L.b1 + i] = b1[i]; }
+    if (i < 3) base[L.brgb + i] = brgb[i];
+}
+
+// -------------------------------------------------------------------------------------------------
+// implicit-GEMM conv on f32 MFMA.  A "phase" is a set of taps writing to a strided output lattice.
+// -------------------------------------------------------------------------------------------------
+struct ConvPhase {
+    int outH, outW;          // logical output extent (i in [0,outH), j in [0,outW))
+    int oy_mul, oy_add, ox_mul, ox_add;   // stored at (i*oy_mul+oy_add, j*ox_mul+ox_add)
+    int ntaps;
+    int dy[9], dx[9], widx[9];            // input pixel = (i+dy, j+dx); weight tap index
+};
+struct ConvArgs {
+    const float* x;  size_t x_stride_n;       // CB8 input  [Cin/8][H][W][8]
+    const float* wp; size_t wp_stride_n;      // packed weights [9][Cin/8][Cout][8]
+    const float* bias; size_t bias_stride_n;  // [Cout] or nullptr
+    float* y; size_t y_stride_n;              // CB8 output [Cout/8][OH][OW][8]
+    int Cin, Cout, H, W, OH, OW;
+    int nphase, act; float clamp;
+    ConvPhase ph[4];
+};
+
+template <int NTAPS>
+__device__ __forceinline__ void conv_block(const ConvArgs& a, const ConvPhase& ph, int n, float* patch)
+{
+    const int tiles_x = (ph.outW + TILE_W - 1) / TILE_W;
+    const int tile = blockIdx.x;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int i0 = ty * TILE_H, j0 = tx * TILE_W;
+    const int m0 = blockIdx.y * BLOCK_M;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;          // wave tile: couts [m0+64wm, +64), rows [4wn, 4wn+4)
+    const int li = lane & 31, h = lane >> 5;
+    const int nchunks = a.Cin >> 3;
+    const float* X = a.x + (size_t)n * a.x_stride_n;
+    const float4* WP = reinterpret_cast<const float4*>(a.wp + (size_t)n * a.wp_stride_n);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    // B-operand patch offsets (float4 units within one chunk's patch) per N-tile and tap
+    int boff[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int row = wn * 4 + nt * 2 + (li >> 4), col = li & 15;
+        boff[nt] = ((row + 1) * PATCH_W + (col + 1)) * 2 + h;
+    }
+    const float4* patch4 = reinterpret_cast<const float4*>(patch);
+
+    for (int c0 = 0; c0 < nchunks; c0 += CHUNKS_PER_STAGE) {
+        const int nc = min(CHUNKS_PER_STAGE, nchunks - c0);
+        __syncthreads();
+        // ---- stage the (TILE+halo) patch of nc channel blocks: zero outside the image ------------
+        for (int e = threadIdx.x; e < nc * PATCH_PIX * 2; e += blockDim.x) {
+            const int half = e & 1, pp = (e >> 1) % PATCH_PIX, c = (e >> 1) / PATCH_PIX;
+            const int py = pp / PATCH_W, px = pp - py * PATCH_W;
+            const int iy = i0 + py - 1, ix = j0 + px - 1;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+                v = *reinterpret_cast<const float4*>(X + (((size_t)(c0 + c) * a.H + iy) * a.W + ix) * 8 + half * 4);
+            reinterpret_cast<float4*>(patch)[(c * PATCH_PIX + pp) * 2 + half] = v;
+        }
+        __syncthreads();
+        for (int c = 0; c < nc; ++c) {
+            // A fragments for every tap of this channel block straight from L2
+            float4 af[NTAPS][2];
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    af[t][mt] = WP[(((size_t)ph.widx[t] * nchunks + (c0 + c)) * a.Cout + (m0 + 64 * wm + 32 * mt + li)) * 2 + h];
+            const float4* pc = patch4 + c * PATCH_PIX * 2;
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) {
+                const int toff = (ph.dy[t] * PATCH_W + ph.dx[t]) * 2;
+                float4 bf[2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) bf[nt] = pc[boff[nt] + toff];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(
+                                reinterpret_cast<const float*>(&af[t][mt])[k], reinterpret_cast<const float*>(&bf[nt])[k],
+                                acc[mt][nt], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: bias + lrelu(0.2)*sqrt(2) (+clamp)  (bias_act.py:93-122), CB8 store ------------
+    float* Y = a.y + (size_t)n * a.y_stride_n;
+    const float* B = a.bias ? a.bias + (size_t)n * a.bias_stride_n : nullptr;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int i = i0 + wn * 4 + nt * 2 + (li >> 4), j = j0 + (li & 15);
+        if (i >= ph.outH || j >= ph.outW) continue;
+        const int oy = i * ph.oy_mul + ph.oy_add, ox = j * ph.ox_mul + ph.ox_add;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = m0 + 64 * wm + 32 * mt + 8 * g + 4 * h;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = acc[mt][nt][4 * g + r];
+                    if (a.act) {
+                        t += B[co + r];
+                        t = (t < 0.f ? t * 0.2f : t) * 1.4142135623730951f;
+                        if (a.clamp >= 0.f) t = fminf(fmaxf(t, -a.clamp), a.clamp);
+                    }
+                    v[r] = t;
+                }
+                *reinterpret_cast<float4*>(Y + ((((size_t)(co >> 3)) * a.OH + oy) * a.OW + ox) * 8 + (co & 7)) =
+                    make_float4(v[0], v[1], v[2], v[3]);
+            }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float patch[CHUNKS_PER_STAGE * PATCH_PIX * 8];
+    const int n = blockIdx.z / a.nphase, p = blockIdx.z - n * a.nphase;
+    const ConvPhase& ph = a.ph[p];
+    const int tiles = ((ph.outW + TILE_W - 1) / TILE_W) * ((ph.outH + TILE_H - 1) / TILE_H);
+    if ((int)blockIdx.x >= tiles) return;
+    switch (ph.ntaps) {
+        case 9: conv_block<9>(a, ph, n, patch); break;
+        case 4: conv_block<4>(a, ph, n, patch); break;
+        case 2: conv_block<2>(a, ph, n, patch); break;
+        default: conv_block<1>(a, ph, n, patch); break;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// FIR 4x4 (outer([1,3,3,1])/64 * gain 4, pad 1) + bias + lrelu*sqrt(2)  on the transposed-conv output
+// T [C/8][2H+1][2W+1][8] -> y [C/8][2H][2W][8]      (conv2d_resample.py:130, upfirdn2d.py:171-215)
+// One thread: one output pixel x 4 channels.
+// -------------------------------------------------------------------------------------------------
+__global__ void fir_bias_act_kernel(const float* __restrict__ T, size_t t_stride_n, const float* __restrict__ bias,
+                                    size_t bias_stride_n, float* __restrict__ y, size_t y_stride_n,
+                                    int C, int OH, int OW, float clamp)
+{
+    const int n = blockIdx.z;
+    const int cb = blockIdx.y;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;     // (pixel, half)
+    if (e >= OH * OW * 2) return;
+    const int half = e & 1, p = e >> 1;
+    const int oy = p / OW, ox = p - oy * OW;
+    const int TH = OH + 1, TW = OW + 1;
+    const float* Tn = T + (size_t)n * t_stride_n + (size_t)cb * TH * TW * 8 + half * 4;
+    const float f1[4] = {0.25f, 0.75f, 0.75f, 0.25f};        // [1,3,3,1]/8 * 2 per axis
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int aa = 0; aa < 4; ++aa) {
+        const int ty = oy + aa - 1;
+        if (ty < 0 || ty >= TH) continue;
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            const int tx = ox + bb - 1;
+            if (tx < 0 || tx >= TW) continue;
+            const float4 v = *reinterpret_cast<const float4*>(Tn + ((size_t)ty * TW + tx) * 8);
+            const float w = f1[aa] * f1[bb];
+            acc.x += v.x * w; acc.y += v.y * w; acc.z += v.z * w; acc.w += v.w * w;
+        }
+    }
+    const float* b = bias + (size_t)n * bias_stride_n + cb * 8 + half * 4;
+    float o[4] = {acc.x + b[0], acc.y + b[1], acc.z + b[2], acc.w + b[3]};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float t = o[r];
+        t = (t < 0.f ? t * 0.2f : t) * 1.4142135623730951f;
+        if (clamp >= 0.f) t = fminf(fmaxf(t, -clamp), clamp);
+        o[r] = t;
+    }
+    *reinterpret_cast<float4*>(y + (size_t)n * y_stride_n + (((size_t)cb * OH + oy) * OW + ox) * 8 + half * 4) =
+        make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// -------------------------------------------------------------------------------------------------
+// toRGB (1x1 modulated conv, no demod, linear bias_act; networks_stylegan2.py:365-370) fused with the
+// RGB-skip upsample2d (upfirdn2d.py:317-354) and the add (:463-469).
+// x CB8 [C/8][H][W][8]; img_prev NCHW [3][H/2][W/2]; img_out NCHW [3][H][W]
+// -------------------------------------------------------------------------------------------------
+__global__ void torgb_upsample_kernel(const float* __restrict__ x, size_t x_stride_n,
+                                      const float* __restrict__ wrgb, const float* __restrict__ brgb, size_t pk_stride_n,
+                                      const float* __restrict__ img_prev, float* __restrict__ img_out,
+                                      int C, int H, int W, float clamp)
+{
+    extern __shared__ float sw[];      // [3][C]
+    const int n = blockIdx.y;
+    for (int i = threadIdx.x; i < 3 * C; i += blockDim.x) sw[i] = wrgb[(size_t)n * pk_stride_n + i];
+    __syncthreads();
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= H * W) return;
+    const int y = p / W, xx = p - y * W;
+    const float* X = x + (size_t)n * x_stride_n;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    const int ncb = C >> 3;
+    for (int cb = 0; cb < ncb; ++cb) {
+        const float4* s = reinterpret_cast<const float4*>(X + ((size_t)cb * H * W + p) * 8);
+        const float4 u = s[0], v = s[1];
+        const float xv[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            a0 += xv[c] * sw[cb * 8 + c];
+            a1 += xv[c] * sw[C + cb * 8 + c];
+            a2 += xv[c] * sw[2 * C + cb * 8 + c];
+        }
+    }
+    const float* br = brgb + (size_t)n * pk_stride_n;
+    float o[3] = {a0 + br[0], a1 + br[1], a2 + br[2]};
+    if (clamp >= 0.f) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) o[c] = fminf(fmaxf(o[c], -clamp), clamp);
+    }
+    // upsample2d: zero-insert x2, pad (2,1), FIR [1,3,3,1]^2/64 * 4: per axis even -> (1/4, 3/4) on (k-1, k),
+    // odd -> (3/4, 1/4) on (k, k+1) with k = coord>>1
+    const int Hh = H >> 1, Wh = W >> 1;
+    const int ky = y >> 1, kx = xx >> 1;
+    int r0, r1, c0, c1; float wy0, wy1, wx0, wx1;
+    if (y & 1) { r0 = ky; r1 = ky + 1; wy0 = 0.75f; wy1 = 0.25f; } else { r0 = ky - 1; r1 = ky; wy0 = 0.25f; wy1 = 0.75f; }
+    if (xx & 1) { c0 = kx; c1 = kx + 1; wx0 = 0.75f; wx1 = 0.25f; } else { c0 = kx - 1; c1 = kx; wx0 = 0.25f; wx1 = 0.75f; }
+    const bool vr0 = r0 >= 0 && r0 < Hh, vr1 = r1 >= 0 && r1 < Hh, vc0 = c0 >= 0 && c0 < Wh, vc1 = c1 >= 0 && c1 < Wh;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float* I = img_prev + ((size_t)n * 3 + c) * Hh * Wh;
+        float up = 0.f;
+        if (vr0 && vc0) up += I[(size_t)r0 * Wh + c0] * (wy0 * wx0);
+        if (vr0 && vc1) up += I[(size_t)r0 * Wh + c1] * (wy0 * wx1);
+        if (vr1 && vc0) up += I[(size_t)r1 * Wh + c0] * (wy1 * wx0);
+        if (vr1 && vc1) up += I[(size_t)r1 * Wh + c1] * (wy1 * wx1);
+        img_out[((size_t)n * 3 + c) * H * W + p] = up + o[c];
+    }
+}
+
+static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+}  // namespace r3d
+
+using namespace r3d;
+
+extern "C" size_t r3d_sr_block_packed_bytes(int N, int Cin, int Cout)
+{
+    return (size_t)N * sr_layout(Cin, Cout).total * sizeof(float);
+}
+
+extern "C" size_t r3d_sr_block_workspace_bytes(int N, int Cin, int Cout, int Hin, int Win)
+{
+    const size_t xin = align256((size_t)N * Cin * Hin * Win * 4);
+    const size_t T = align256((size_t)N * Cout * (2 * Hin + 1) * (2 * Win + 1) * 4);
+    const size_t y0 = align256((size_t)N * Cout * 4 * Hin * Win * 4);
+    const size_t xo = align256((size_t)N * Cout * 4 * Hin * Win * 4);
+    return xin + T + y0 + xo;
+}
+
+extern "C" int r3d_sr_block_pack(const float* ws3, int N, int WD, int Cin, int Cout,
+                                 const float* c0_w, const float* c0_b, const float* c0_aw, const float* c0_ab,
+                                 const float* c1_w, const float* c1_b, const float* c1_aw, const float* c1_ab,
+                                 const float* rgb_w, const float* rgb_b, const float* rgb_aw, const float* rgb_ab,
+                                 void* packed, r3d_stream_t stream)
+{
+    if (!ws3 || !c0_w || !c0_b || !c0_aw || !c0_ab || !c1_w || !c1_b || !c1_aw || !c1_ab || !rgb_w || !rgb_b || !rgb_aw || !rgb_ab || !packed) {
+        set_error("sr_block_pack: NULL pointer"); return R3D_ERR_INVALID_ARG;
+    }
+    if (N <= 0 || WD <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 7) || (Cout % BLOCK_M)) {
+        set_error("sr_block_pack: Cin %d must be a multiple of 8 and Cout %d a multiple of %d", Cin, Cout, BLOCK_M);
+        return R3D_ERR_INVALID_ARG;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    float* pk = reinterpret_cast<float*>(packed);
+    const size_t stride = sr_layout(Cin, Cout).total;
+    hipLaunchKernelGGL(sr_styles_kernel, dim3(3, N), dim3(256), 0, st, ws3, WD, Cin, Cout, c0_aw, c0_ab, c1_aw, c1_ab, rgb_aw, rgb_ab, pk, stride);
+    hipLaunchKernelGGL(sr_modulate_kernel, dim3(Cout, N, 2), dim3(256), 0, st, Cin, Cout, c0_w, c1_w, pk, stride);
+    hipLaunchKernelGGL(sr_pack_misc_kernel, dim3((3 * Cout + 255) / 256, N), dim3(256), 0, st, Cin, Cout, rgb_w, c0_b, c1_b, rgb_b, pk, stride);
+    return check_launch("sr_block_pack");
+}
+
+extern "C" int r3d_sr_block_forward(const void* packed, int N, int Cin, int Cout, int Hin, int Win,
+                                    const float* x, int x_blocked, const float* img, float clamp,
+                                    float* x_out, int x_out_nchw, float* img_out,
+                                    void* workspace, size_t workspace_bytes, r3d_stream_t stream)
+{
+    if (!packed || !x || !img || !img_out || N <= 0 || Hin <= 0 || Win <= 0 || (Cin & 7) || (Cout % BLOCK_M)) {
+        set_error("sr_block_forward: bad argument"); return R3D_ERR_INVALID_ARG;
+    }
+    if (!workspace || workspace_bytes < r3d_sr_block_workspace_bytes(N, Cin, Cout, Hin, Win)) {
+        set_error("sr_block_forward: workspace too small"); return R3D_ERR_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const SrPackLayout L = sr_layout(Cin, Cout);
+    const float* pk = reinterpret_cast<const float*>(packed);
+    const int OH = 2 * Hin, OW = 2 * Win, TH = OH + 1, TW = OW + 1;
+    char* wsb = reinterpret_cast<char*>(workspace);
+    float* xin = reinterpret_cast<float*>(wsb); wsb += align256((size_t)N * Cin * Hin * Win * 4);
+    float* T = reinterpret_cast<float*>(wsb);   wsb += align256((size_t)N * Cout * TH * TW * 4);
+    float* y0 = reinterpret_cast<float*>(wsb);  wsb += align256((size_t)N * Cout * OH * OW * 4);
+    float* xo = reinterpret_cast<float*>(wsb);
+
+    const float* xcb = x;
+    if (!x_blocked) {
+        hipLaunchKernelGGL(nchw_to_cb8_kernel, dim3((Hin * Win + 255) / 256, Cin / 8, N), dim3(256), 0, st, x, xin, Cin, Hin * Win);
+        xcb = xin;
+    }
+    // ---- conv0: transposed conv stride 2 as 4 phases -> T ------------------------------------------------
+    {
+        ConvArgs a;
+        a.x = xcb; a.x_stride_n = (size_t)Cin * Hin * Win;
+        a.wp = pk + L.wp0; a.wp_stride_n = L.total;
+        a.bias = nullptr; a.bias_stride_n = 0;
+        a.y = T; a.y_stride_n = (size_t)Cout * TH * TW;
+        a.Cin = Cin; a.Cout = Cout; a.H = Hin; a.W = Win; a.OH = TH; a.OW = TW;
+        a.nphase = 4; a.act = 0; a.clamp = -1.f;
+        int maxtiles = 0;
+        for (int pa = 0; pa < 2; ++pa)
+            for (int pb = 0; pb < 2; ++pb) {
+                ConvPhase& p = a.ph[pa * 2 + pb];
+                p.outH = Hin + (pa == 0); p.outW = Win + (pb == 0);
+                p.oy_mul = 2; p.oy_add = pa; p.ox_mul = 2; p.ox_add = pb;
+                p.ntaps = 0;
+                // T[2i+pa][2j+pb] = sum_{ky = pa (mod 2), kx = pb (mod 2)} x[i - ky/2][j - kx/2] w[ky][kx]
+                for (int ky = pa; ky < 3; ky += 2)
+                    for (int kx = pb; kx < 3; kx += 2) {
+                        p.dy[p.ntaps] = -(ky >> 1); p.dx[p.ntaps] = -(kx >> 1); p.widx[p.ntaps] = ky * 3 + kx;
+                        ++p.ntaps;
+                    }
+                const int tiles = ((p.outW + TILE_W - 1) / TILE_W) * ((p.outH + TILE_H - 1) / TILE_H);
+                if (tiles > maxtiles) maxtiles = tiles;
+            }
+        hipLaunchKernelGGL(conv_mfma_kernel, dim3(maxtiles, Cout / BLOCK_M, N * 4), dim3(256), 0, st, a);
+    }
+    hipLaunchKernelGGL(fir_bias_act_kernel, dim3((OH * OW * 2 + 255) / 256, Cout / 8, N), dim3(256), 0, st,
+                       T, (size_t)Cout * TH * TW, pk + L.b0, L.total, y0, (size_t)Cout * OH * OW, Cout, OH, OW, clamp);
+    // ---- conv1: 3x3 pad 1 --------------------------------------------------------------------------------
+    float* xo_cb = (x_out && !x_out_nchw) ? x_out : xo;
+    {
+        ConvArgs a;
+        a.x = y0; a.x_stride_n = (size_t)Cout * OH * OW;
+        a.wp = pk + L.wp1; a.wp_stride_n = L.total;
+        a.bias = pk + L.b1; a.bias_stride_n = L.total;
+        a.y = xo_cb; a.y_stride_n = (size_t)Cout * OH * OW;
+        a.Cin = Cout; a.Cout = Cout; a.H = OH; a.W = OW; a.OH = OH; a.OW = OW;
+        a.nphase = 1; a.act = 1; a.clamp = clamp;
+        ConvPhase& p = a.ph[0];
+        p.outH = OH; p.outW = OW; p.oy_mul = 1; p.oy_add = 0; p.ox_mul = 1; p.ox_add = 0; p.ntaps = 9;
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) { p.dy[ky * 3 + kx] = ky - 1; p.dx[ky * 3 + kx] = kx - 1; p.widx[ky * 3 + kx] = ky * 3 + kx; }
+        const int tiles = ((OW + TILE_W - 1) / TILE_W) * ((OH + TILE_H - 1) / TILE_H);
+        hipLaunchKernelGGL(conv_mfma_kernel, dim3(tiles, Cout / BLOCK_M, N), dim3(256), 0, st, a);
+    }
+    // ---- toRGB + skip upsample ---------------------------------------------------------------------------
+    hipLaunchKernelGGL(torgb_upsample_kernel, dim3((OH * OW + 255) / 256, N), dim3(256), 3 * Cout * sizeof(float), st,
+                       xo_cb, (size_t)Cout * OH * OW, pk + L.wrgb, pk + L.brgb, L.total, img, img_out, Cout, OH, OW, clamp);
+    if (x_out && x_out_nchw)
+        hipLaunchKernelGGL(cb8_to_nchw_kernel, dim3((OH * OW + 255) / 256, Cout / 8, N), dim3(256), 0, st, xo_cb, x_out, Cout, OH * OW);
+    return check_launch("sr_block_forward");
+}

@@ -1,0 +1,99 @@
+"""Frame-sharded clip rendering: frames of a driving sequence are independent units (the loop body at
+inference/real3d_infer.py:480-492 depends only on per-frame inputs and clip constants), so rank r of W renders
+the contiguous chunk [r*ceil(T/W), (r+1)*ceil(T/W)) with NO data-path collective, and the uint8 frames are
+re-assembled on rank 0 with one gather (RCCL over xGMI when the backend is 'nccl'; each peer has its own
+link to the root, so a gather -- not a ring -- is the natural collective here).
+
+The host logic is backend-agnostic (tests run it with gloo on CPU and a fake frame renderer).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_frames(num_frames, world_size, rank):
+    """Contiguous chunking: rank r gets [lo, hi); the last ranks may get fewer (or zero) frames."""
+    per = (num_frames + world_size - 1) // world_size
+    lo = min(rank * per, num_frames)
+    hi = min(lo + per, num_frames)
+    return lo, hi
+
+
+def frame_seed(base_seed, frame_index):
+    """Sampling-noise seed of a frame: a function of the frame index only, so a sharded run renders the
+    same pixels as a serial run (the reference consumes one global generator sequentially)."""
+    return (int(base_seed) * 0x9E3779B97F4A7C15 + int(frame_index) * 0xD1B54A32D192ED03 + 1) & 0xFFFFFFFFFFFFFFFF
+
+
+def gather_frames(local, num_frames, group=None):
+    """local: uint8 [per, H, W, 3] on every rank (per = ceil(T/W), tail rows unused).
+    Returns uint8 [T, H, W, 3] on rank 0 and None elsewhere."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local[:num_frames]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    bufs = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
+    dist.gather(local, bufs, dst=0, group=group)
+    if rank != 0:
+        return None
+    parts = []
+    for r in range(world):
+        lo, hi = shard_frames(num_frames, world, r)
+        parts.append(bufs[r][: hi - lo])
+    return torch.cat(parts, dim=0)
+
+
+def render_clip_sharded(render_frame, num_frames, frame_hw=(512, 512), device="cuda", group=None):
+    """render_frame(t) -> uint8 [H, W, 3] tensor on `device` for global frame index t.
+    Every rank renders its chunk into a device-resident ring, then one gather assembles the clip."""
+    if dist.is_available() and dist.is_initialized():
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+    else:
+        world, rank = 1, 0
+    per = (num_frames + world - 1) // world
+    lo, hi = shard_frames(num_frames, world, rank)
+    ring = torch.zeros(per, frame_hw[0], frame_hw[1], 3, dtype=torch.uint8, device=device)
+    for i, t in enumerate(range(lo, hi)):
+        ring[i] = render_frame(t)
+    return gather_frames(ring, num_frames, group)
+
+
+class ClipRenderer:
+    """Per-frame driver around a (HIP) TriPlaneGenerator: planes_t = cano + residual_t (the reference's
+    secc2plane residual add, modules/real3d/secc_img2plane.py:73-81, fused into the layout kernel),
+    render + SR, clamp, uint8 HWC conversion on device."""
+
+    def __init__(self, generator, cano_planes, residuals, cameras, ws, base_seed=0):
+        from . import _lib
+        self._lib = _lib
+        self.G = generator
+        self.cano = cano_planes            # [1,3,32,H,W]
+        self.residuals = residuals         # list of [1,3,32,H,W] (cycled) or None
+        self.cameras = cameras             # [T,25]
+        self.ws = ws
+        self.base_seed = base_seed
+        self.G.renderer.noise_mode = "hash"
+
+    def planes_for(self, t):
+        add = self.residuals[t % len(self.residuals)] if self.residuals else None
+        nhwc = self.G.renderer.prepare_planes(self.cano, add)
+        nhwc._r3d_nhwc = True
+        return nhwc
+
+    def render_image(self, t):
+        G = self.G
+        G.renderer.seed = frame_seed(self.base_seed, t)
+        cam = self.cameras[t: t + 1]
+        o, d = G.ray_sampler(cam[:, :16].view(-1, 4, 4), cam[:, 16:25].view(-1, 3, 3), G.neural_rendering_resolution)
+        feat, depth, wsum, valid = G.renderer(self.planes_for(t), G.decoder, o, d, G.rendering_kwargs)
+        R = G.neural_rendering_resolution
+        fimg = feat.permute(0, 2, 1).reshape(1, 32, R, R).contiguous()
+        return G.superresolution(fimg[:, :3], fimg, self.ws, noise_mode="none")
+
+    def render_u8(self, t, out=None):
+        lib = self._lib.load()
+        img = self.render_image(t).contiguous()
+        N, _, H, W = img.shape
+        if out is None:
+            out = torch.empty(N, H, W, 3, dtype=torch.uint8, device=img.device)
+        self._lib.check(lib.r3d_frames_to_u8(self._lib.ptr(img), N, H, W, self._lib.ptr(out), self._lib.stream_ptr()),
+                        "frames_to_u8")
+        return out[0] if out.dim() == 4 else out

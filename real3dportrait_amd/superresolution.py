@@ -1,0 +1,176 @@
+"""Drop-in replacements for the reference's super-resolution modules, backed by libr3d_hip.so.
+
+Mirrors (same constructor arguments, state_dict keys/shapes, forward signatures):
+  * SynthesisLayer / ToRGBLayer parameter containers   modules/eg3ds/models/networks_stylegan2.py:286-373
+  * SynthesisBlock.forward(x, img, ws, **kw) -> (x, img)  networks_stylegan2.py:377-476 (architecture 'skip',
+    in_channels != 0, fp32, noise_mode in {'none','const' with zero strength})
+  * SuperresolutionHybrid8XDC.forward(rgb, x, ws, **kw) -> rgb   modules/eg3ds/models/superresolution.py:331-359
+
+A checkpoint saved from the reference loads with strict=True (keys: block{0,1}.{conv0,conv1,torgb}.
+{weight,bias,affine.weight,affine.bias}, conv*.noise_strength, buffers noise_const / resample_filter).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+from .volumetric_rendering import _FC, _f32c
+
+
+def _setup_filter():
+    f = torch.tensor([1.0, 3.0, 3.0, 1.0])
+    f = torch.outer(f, f)
+    return f / f.sum()          # upfirdn2d.setup_filter([1,3,3,1]) (ops/upfirdn2d.py:72-116)
+
+
+class SynthesisLayer(nn.Module):
+    """Parameter container with the reference's names/shapes (networks_stylegan2.py:286-320)."""
+
+    def __init__(self, in_channels, out_channels, w_dim, resolution, kernel_size=3, up=1, use_noise=True,
+                 activation="lrelu", resample_filter=(1, 3, 3, 1), conv_clamp=None, channels_last=False, **_):
+        super().__init__()
+        assert kernel_size == 3 and activation == "lrelu" and tuple(resample_filter) == (1, 3, 3, 1)
+        self.in_channels, self.out_channels, self.w_dim = in_channels, out_channels, w_dim
+        self.resolution, self.up, self.use_noise, self.conv_clamp = resolution, up, use_noise, conv_clamp
+        self.register_buffer("resample_filter", _setup_filter())
+        self.affine = _FC(w_dim, in_channels, bias_init=1.0)
+        self.weight = nn.Parameter(torch.randn(out_channels, in_channels, kernel_size, kernel_size))
+        if use_noise:
+            self.register_buffer("noise_const", torch.randn(resolution, resolution))
+            self.noise_strength = nn.Parameter(torch.zeros([]))
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+
+
+class ToRGBLayer(nn.Module):
+    """networks_stylegan2.py:352-364."""
+
+    def __init__(self, in_channels, out_channels, w_dim, kernel_size=1, conv_clamp=None, channels_last=False):
+        super().__init__()
+        assert kernel_size == 1 and out_channels == 3
+        self.in_channels, self.out_channels, self.w_dim, self.conv_clamp = in_channels, out_channels, w_dim, conv_clamp
+        self.affine = _FC(w_dim, in_channels, bias_init=1.0)
+        self.weight = nn.Parameter(torch.randn(out_channels, in_channels, kernel_size, kernel_size))
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+        self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
+
+
+class SynthesisBlock(nn.Module):
+    """networks_stylegan2.py:377-476 for the configuration the SR path instantiates: in_channels != 0,
+    architecture 'skip', up=2 conv0 + conv1 + toRGB, fp32.
+
+    forward(x, img, ws, ...) -> (x, img) like the reference.  `x` may be NCHW (reference layout) or a
+    channel-blocked tensor produced by a previous block (tagged `_r3d_cb8`); the returned x is
+    channel-blocked by default when `self.blocked_output` (used inside SuperresolutionHybrid8XDC) and
+    NCHW otherwise (drop-in use, e.g. sr_with_ref.py:83,124)."""
+
+    def __init__(self, in_channels, out_channels, w_dim, resolution, img_channels, is_last, architecture="skip",
+                 resample_filter=(1, 3, 3, 1), conv_clamp=256, use_fp16=False, fp16_channels_last=False,
+                 fused_modconv_default=True, **layer_kwargs):
+        super().__init__()
+        if in_channels == 0 or architecture != "skip" or img_channels != 3:
+            raise NotImplementedError("HIP SynthesisBlock covers the SR configuration only "
+                                      "(in_channels != 0, architecture 'skip', 3 image channels)")
+        if use_fp16:
+            raise NotImplementedError("use_fp16 SR blocks: the Real3D shells run SR in fp32 "
+                                      "(img2plane_baseline.py:102); fp16 is not built")
+        self.in_channels, self.out_channels, self.w_dim = in_channels, out_channels, w_dim
+        self.resolution, self.img_channels, self.is_last, self.architecture = resolution, img_channels, is_last, architecture
+        self.use_fp16 = False
+        self.fused_modconv_default = fused_modconv_default
+        self.register_buffer("resample_filter", _setup_filter())
+        self.num_conv, self.num_torgb = 2, 1
+        self.conv0 = SynthesisLayer(in_channels, out_channels, w_dim=w_dim, resolution=resolution, up=2,
+                                    conv_clamp=conv_clamp, **layer_kwargs)
+        self.conv1 = SynthesisLayer(out_channels, out_channels, w_dim=w_dim, resolution=resolution,
+                                    conv_clamp=conv_clamp, **layer_kwargs)
+        self.torgb = ToRGBLayer(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp)
+        self.conv_clamp = conv_clamp
+        self.blocked_output = False
+        self.return_x = True           # False: skip materialising x (last block of SuperresolutionHybrid8XDC)
+        self._packed = None
+        self._workspace = None
+
+    def _buf(self, name, nbytes, dev):
+        t = getattr(self, name)
+        if t is None or t.numel() < nbytes or t.device != dev:
+            t = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+            setattr(self, name, t)
+        return t
+
+    def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, noise_mode="random",
+                **layer_kwargs):
+        lib = _lib.load()
+        if noise_mode == "random" or (noise_mode == "const" and
+                                      (float(self.conv0.noise_strength) != 0 or float(self.conv1.noise_strength) != 0)):
+            raise NotImplementedError("noise_mode=%r: the inference path uses 'none' "
+                                      "(img2plane_baseline.py:113)" % noise_mode)
+        if img is None:
+            raise NotImplementedError("img=None (first block of a synthesis network) is not on the SR path")
+        blocked_in = bool(getattr(x, "_r3d_cb8", False))
+        x = _f32c(x)
+        img = _f32c(img)
+        ws = _f32c(ws)
+        N = img.shape[0]
+        Hin, Win = img.shape[-2], img.shape[-1]
+        Cin, Cout = self.in_channels, self.out_channels
+        assert ws.shape[1] == self.num_conv + self.num_torgb and ws.shape[2] == self.w_dim, ws.shape
+        dev = img.device
+        st = _lib.stream_ptr()
+        packed = self._buf("_packed", int(lib.r3d_sr_block_packed_bytes(N, Cin, Cout)), dev)
+        p = lambda t: _lib.ptr(_f32c(t))
+        c0, c1, tr = self.conv0, self.conv1, self.torgb
+        keep = [_f32c(t) for t in (c0.weight, c0.bias, c0.affine.weight, c0.affine.bias,
+                                   c1.weight, c1.bias, c1.affine.weight, c1.affine.bias,
+                                   tr.weight, tr.bias, tr.affine.weight, tr.affine.bias)]
+        _lib.check(lib.r3d_sr_block_pack(_lib.ptr(ws), N, self.w_dim, Cin, Cout, *[_lib.ptr(t) for t in keep],
+                                         _lib.ptr(packed), st), "sr_block_pack")
+        need = int(lib.r3d_sr_block_workspace_bytes(N, Cin, Cout, Hin, Win))
+        work = self._buf("_workspace", need, dev)
+        OH, OW = 2 * Hin, 2 * Win
+        img_out = torch.empty(N, 3, OH, OW, device=dev, dtype=torch.float32)
+        if not self.return_x:
+            x_out = None
+        elif self.blocked_output:
+            x_out = torch.empty(N, Cout // 8, OH, OW, 8, device=dev, dtype=torch.float32)
+        else:
+            x_out = torch.empty(N, Cout, OH, OW, device=dev, dtype=torch.float32)
+        clamp = -1.0 if self.conv_clamp is None else float(self.conv_clamp)
+        _lib.check(lib.r3d_sr_block_forward(_lib.ptr(packed), N, Cin, Cout, Hin, Win, _lib.ptr(x), int(blocked_in),
+                                            _lib.ptr(img), clamp, _lib.ptr(x_out), int(not self.blocked_output),
+                                            _lib.ptr(img_out), _lib.ptr(work), need, st), "sr_block_forward")
+        if self.blocked_output and x_out is not None:
+            x_out._r3d_cb8 = True
+        return x_out, img_out
+
+
+class SuperresolutionHybrid8XDC(nn.Module):
+    """superresolution.py:331-359: 128^2 x 32ch -> 512^2 RGB through two SynthesisBlocks (32->256 @256, 256->128 @512)."""
+
+    def __init__(self, channels, img_resolution, sr_num_fp16_res, sr_antialias, large_sr=False, **block_kwargs):
+        super().__init__()
+        assert img_resolution == 512
+        if large_sr:
+            raise NotImplementedError("large_sr variants are not on the released inference path")
+        use_fp16 = sr_num_fp16_res > 0
+        if use_fp16:
+            raise NotImplementedError("sr_num_fp16_res > 0: the Real3D shells pass 0 (img2plane_baseline.py:102)")
+        self.input_resolution = 128
+        self.sr_antialias = sr_antialias
+        self.block0 = SynthesisBlock(channels, 256, w_dim=512, resolution=256, img_channels=3, is_last=False,
+                                     use_fp16=False, conv_clamp=None, **block_kwargs)
+        self.block1 = SynthesisBlock(256, 128, w_dim=512, resolution=512, img_channels=3, is_last=True,
+                                     use_fp16=False, conv_clamp=None, **block_kwargs)
+        self.block0.blocked_output = True      # block0 -> block1 hand-off stays channel-blocked
+        self.block1.return_x = False           # forward() only returns rgb (:359)
+
+    def forward(self, rgb, x, ws, **block_kwargs):
+        ws = ws[:, -1:, :].repeat(1, 3, 1)
+        if x.shape[-1] != self.input_resolution:      # cold path, same ATen op as the reference (:351-355)
+            x = F.interpolate(x, size=(self.input_resolution, self.input_resolution), mode="bilinear",
+                              align_corners=False, antialias=self.sr_antialias)
+            rgb = F.interpolate(rgb, size=(self.input_resolution, self.input_resolution), mode="bilinear",
+                                align_corners=False, antialias=self.sr_antialias)
+        x, rgb = self.block0(x, rgb, ws, **block_kwargs)
+        x, rgb = self.block1(x, rgb, ws, **block_kwargs)
+        return rgb

@@ -1,0 +1,213 @@
+"""Drop-in replacements for the reference's volume-rendering operators, backed by libr3d_hip.so.
+
+Mirrors (same class names, call signatures, option keys, return values):
+  * RaySampler.forward(cam2world_matrix, intrinsics, resolution)
+        modules/eg3ds/volumetric_rendering/ray_sampler.py:24-63
+  * ImportanceRenderer.forward(planes, decoder, ray_origins, ray_directions, rendering_options)
+        modules/eg3ds/volumetric_rendering/renderer.py:118-167
+  * ImportanceRenderer.run_model(planes, decoder, sample_coordinates, sample_directions, options)
+        renderer.py:169-188
+  * OSGDecoder (parameter container with the checkpoint keys net.0.weight/bias, net.2.weight/bias)
+        modules/eg3ds/models/triplane.py:166-189, modules/img2plane/triplane.py:122-146
+
+There is no eager/PyTorch fallback: tensors must live on the GPU and the HIP library must be built.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def _f32c(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+class RaySampler(nn.Module):
+    """ray_sampler.py:18-63.  (N,4,4) cam2world + (N,3,3) normalised intrinsics -> origins, dirs [N,R*R,3]."""
+
+    def __init__(self):
+        super().__init__()
+
+    def forward(self, cam2world_matrix, intrinsics, resolution):
+        lib = _lib.load()
+        c2w, K = _f32c(cam2world_matrix), _f32c(intrinsics)
+        N, R = c2w.shape[0], int(resolution)
+        origins = torch.empty(N, R * R, 3, device=c2w.device, dtype=torch.float32)
+        dirs = torch.empty_like(origins)
+        _lib.check(lib.r3d_raygen(_lib.ptr(c2w), _lib.ptr(K), N, R, _lib.ptr(origins), _lib.ptr(dirs),
+                                  _lib.stream_ptr()), "raygen")
+        return origins, dirs
+
+
+class _FC(nn.Module):
+    """FullyConnectedLayer parameter layout (networks_stylegan2.py:99-131), linear activation only."""
+
+    def __init__(self, in_features, out_features, lr_multiplier=1.0, bias_init=0.0):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.randn(out_features, in_features) / lr_multiplier)
+        self.bias = nn.Parameter(torch.full([out_features], float(bias_init)))
+        self.weight_gain = lr_multiplier / (in_features ** 0.5)
+        self.bias_gain = lr_multiplier
+
+    def forward(self, x):   # utility only; the renderer never calls this, it reads the parameters
+        return torch.addmm((self.bias * self.bias_gain).unsqueeze(0), x, (self.weight * self.weight_gain).t())
+
+
+class OSGDecoder(nn.Module):
+    """Same constructor / state_dict keys as the reference decoder (triplane.py:166-176).
+
+    The HIP renderer evaluates this MLP inside the fused ray kernel from the raw parameters; `forward`
+    is kept (plain torch) only for callers that decode pre-sampled features outside the renderer."""
+
+    def __init__(self, n_features=32, options=None):
+        super().__init__()
+        options = options or {"decoder_lr_mul": 1, "decoder_output_dim": 32}
+        self.hidden_dim = 64
+        self.net = nn.Sequential(
+            _FC(n_features, self.hidden_dim, lr_multiplier=options["decoder_lr_mul"]),
+            nn.Softplus(),
+            _FC(self.hidden_dim, 1 + options["decoder_output_dim"], lr_multiplier=options["decoder_lr_mul"]))
+
+    def forward(self, sampled_features, ray_directions=None):
+        x = sampled_features.mean(1)
+        N, M, C = x.shape
+        x = self.net(x.reshape(N * M, C)).view(N, M, -1)
+        return {"rgb": torch.sigmoid(x[..., 1:]) * (1 + 2 * 0.001) - 0.001, "sigma": x[..., 0:1]}
+
+
+def decoder_params(decoder):
+    """Raw (w1, b1, w2, b2) of any module shaped like OSGDecoder (ours or the reference's)."""
+    l0, l2 = decoder.net[0], decoder.net[2]
+    for l in (l0, l2):
+        if abs(float(getattr(l, "bias_gain", 1.0)) - 1.0) > 1e-12 or \
+           abs(float(l.weight_gain) * (l.weight.shape[1] ** 0.5) - 1.0) > 1e-6:
+            raise NotImplementedError("decoder_lr_mul != 1 is not supported by the fused HIP decoder")
+    w1, b1, w2, b2 = _f32c(l0.weight), _f32c(l0.bias), _f32c(l2.weight), _f32c(l2.bias)
+    if tuple(w1.shape) != (64, 32) or tuple(w2.shape) != (33, 64):
+        raise NotImplementedError("fused HIP decoder is built for 32 -> 64 -> 33, got %s, %s"
+                                  % (tuple(w1.shape), tuple(w2.shape)))
+    return w1, b1, w2, b2
+
+
+class ImportanceRenderer(nn.Module):
+    """renderer.py:107-297 restated as one fused HIP kernel per frame (see csrc/r3d_render.hip).
+
+    rendering_options keys read (same as the reference): ray_start, ray_end (must both be 'auto': the
+    numeric branch is broken upstream), box_warp, depth_resolution,
+    depth_resolution_importance, disparity_space_sampling (must be False), clamp_mode ('softplus'),
+    white_back, density_noise (must be 0 / absent at inference).
+
+    Sampling noise: by default the two draws of the reference (torch.rand_like at renderer.py:226 and
+    torch.rand at renderer.py:281) are drawn here with the same shapes, in the same order, from torch's
+    generator, so a seeded run consumes the RNG exactly like the reference does.  Pass explicit tensors
+    through `self.noise_override = (noise_coarse, u_fine)` (parity tests), or set
+    `self.noise_mode = 'hash'` to let the kernel derive the noise from (`self.seed`, ray, sample) -- the
+    mode the frame-sharded driver uses, because it makes a frame independent of its rank."""
+
+    def __init__(self, hp=None):
+        super().__init__()
+        self.hparams = dict(hp) if hp is not None else {}
+        self.triplane_feature_type = self.hparams.get("triplane_feature_type", "triplane")
+        self.noise_mode = "torch"
+        self.noise_override = None
+        self.seed = 0
+        self._plane_cache = None       # (key, nhwc tensor)
+        self._workspace = None
+
+    # -- plane layout ---------------------------------------------------------------------------------
+    def prepare_planes(self, planes, add=None):
+        """NCHW [N,3,C,H,W] (+ optional per-frame residual, secc_img2plane.py:76-77) -> channel-last."""
+        lib = _lib.load()
+        planes = _f32c(planes)
+        N, P, C, H, W = planes.shape
+        assert P == 3, "expected tri-planes [N,3,C,H,W]"
+        if C != 32:
+            raise NotImplementedError("HIP renderer is built for 32 feature channels, got %d" % C)
+        out = torch.empty(N, 3, H, W, C, device=planes.device, dtype=torch.float32)
+        addc = _f32c(add).reshape(planes.shape) if add is not None else None
+        _lib.check(lib.r3d_planes_to_nhwc(_lib.ptr(planes), _lib.ptr(addc), _lib.ptr(out), N, C, H, W,
+                                          _lib.stream_ptr()), "planes_to_nhwc")
+        return out
+
+    def _planes_nhwc(self, planes):
+        if getattr(planes, "_r3d_nhwc", False):
+            return planes
+        key = (planes.data_ptr(), planes._version, tuple(planes.shape), planes.device)
+        if self._plane_cache is not None and self._plane_cache[0] == key:
+            return self._plane_cache[1]
+        out = self.prepare_planes(planes)
+        self._plane_cache = (key, out)
+        return out
+
+    def _check_options(self, opts):
+        if self.triplane_feature_type != "triplane":
+            raise NotImplementedError("triplane_feature_type=%r (trigrid/3dgrid) is a 'next' row, not built"
+                                      % self.triplane_feature_type)
+        if not (opts.get("ray_start") == "auto" and opts.get("ray_end") == "auto"):
+            raise NotImplementedError("only ray_start == ray_end == 'auto' is supported "
+                                      "(the numeric branch raises UnboundLocalError upstream)")
+        if opts.get("disparity_space_sampling", False):
+            raise NotImplementedError("disparity_space_sampling")
+        if opts.get("clamp_mode", "softplus") != "softplus":
+            raise AssertionError("MipRayMarcher only supports `clamp_mode`=`softplus`!")
+        if opts.get("density_noise", 0) > 0:
+            raise NotImplementedError("density_noise is a training-only branch")
+
+    # -- forward ----------------------------------------------------------------------------------------
+    def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options):
+        lib = _lib.load()
+        self._check_options(rendering_options)
+        planes_nhwc = self._planes_nhwc(planes)
+        N, _, H, W, _ = planes_nhwc.shape
+        o, d = _f32c(ray_origins), _f32c(ray_directions)
+        M = o.shape[1]
+        Nc = int(rendering_options["depth_resolution"])
+        Nf = int(rendering_options["depth_resolution_importance"])
+        w1, b1, w2, b2 = decoder_params(decoder)
+        dev = o.device
+
+        noise_c = u_f = None
+        if self.noise_override is not None:
+            noise_c, u_f = self.noise_override
+            noise_c = _f32c(noise_c).reshape(N, M, Nc)
+            u_f = _f32c(u_f).reshape(N * M, Nf) if Nf > 0 else None
+        elif self.noise_mode == "torch":
+            noise_c = torch.rand(N, M, Nc, 1, device=dev, dtype=torch.float32)     # == rand_like(depths_coarse)
+            u_f = torch.rand(N * M, Nf, device=dev, dtype=torch.float32) if Nf > 0 else None
+        elif self.noise_mode != "hash":
+            raise ValueError("noise_mode must be 'torch' or 'hash'")
+
+        rgb = torch.empty(N, M, 32, device=dev, dtype=torch.float32)
+        depth = torch.empty(N, M, 1, device=dev, dtype=torch.float32)
+        wsum = torch.empty(N, M, 1, device=dev, dtype=torch.float32)
+        valid = torch.empty(N, M, 1, device=dev, dtype=torch.bool)
+        need = int(lib.r3d_render_workspace_bytes(N, M, Nc, Nf))
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
+            self._workspace = torch.empty(need, device=dev, dtype=torch.uint8)
+        _lib.check(lib.r3d_render_forward(
+            _lib.ptr(planes_nhwc), N, H, W, _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2),
+            _lib.ptr(o), _lib.ptr(d), M, Nc, Nf, float(rendering_options["box_warp"]),
+            int(bool(rendering_options.get("white_back", False))),
+            _lib.ptr(noise_c), _lib.ptr(u_f), int(self.seed) & 0xFFFFFFFFFFFFFFFF,
+            _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(wsum), _lib.ptr(valid),
+            _lib.ptr(self._workspace), need, _lib.stream_ptr()), "render_forward")
+        return rgb, depth, wsum, valid
+
+    def run_model(self, planes, decoder, sample_coordinates, sample_directions, options):
+        lib = _lib.load()
+        if self.triplane_feature_type != "triplane":
+            raise NotImplementedError("triplane_feature_type=%r" % self.triplane_feature_type)
+        if options.get("density_noise", 0) > 0:
+            raise NotImplementedError("density_noise is a training-only branch")
+        planes_nhwc = self._planes_nhwc(planes)
+        N, _, H, W, _ = planes_nhwc.shape
+        coords = _f32c(sample_coordinates)
+        npts = coords.shape[1]
+        w1, b1, w2, b2 = decoder_params(decoder)
+        rgb = torch.empty(N, npts, 32, device=coords.device, dtype=torch.float32)
+        sigma = torch.empty(N, npts, 1, device=coords.device, dtype=torch.float32)
+        _lib.check(lib.r3d_run_model(_lib.ptr(planes_nhwc), N, H, W, _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2),
+                                     _lib.ptr(b2), _lib.ptr(coords), npts, float(options["box_warp"]),
+                                     _lib.ptr(rgb), _lib.ptr(sigma), _lib.stream_ptr()), "run_model")
+        return {"rgb": rgb, "sigma": sigma}

@@ -1,0 +1,291 @@
+"""GPU parity tests (run on the MI355X box with `-m gpu`): every call goes Python operator -> ctypes ->
+C ABI (include/r3d_hip.h) -> HIP kernels, and is compared with (a) the golden vectors produced by the
+reference's own PyTorch code and (b) the pinned C oracle on fresh seeded inputs.
+
+Tolerances (fp32 everywhere; rgb in [-1,1]):  rgb / wsum <= 2e-4 abs, depth <= 1e-4 abs;
+SR outputs <= 2e-4 * max(1, max|ref|).
+"""
+import numpy as np
+import pytest
+
+from conftest import golden_planes, load_golden
+
+pytestmark = pytest.mark.gpu
+
+RGB_TOL, DEPTH_TOL, SR_TOL = 2e-4, 1e-4, 2e-4
+RENDER_CASES = ["render_a_r16_16p16", "render_b_n2_r16_48p48", "render_c_invalid_r16_16p0",
+                "render_e_white_r12_32p16_bw", "render_d_cfg1_r64_16p16"]
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    from real3dportrait_amd import _lib
+    _lib.load()          # raises if the HIP extension is missing: no fallback
+    return torch
+
+
+def T(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def make_decoder(torch, dec_np):
+    from real3dportrait_amd import OSGDecoder
+    dec = OSGDecoder(32, {"decoder_lr_mul": 1, "decoder_output_dim": 32}).cuda()
+    with torch.no_grad():
+        dec.net[0].weight.copy_(T(torch, dec_np[0])); dec.net[0].bias.copy_(T(torch, dec_np[1]))
+        dec.net[2].weight.copy_(T(torch, dec_np[2])); dec.net[2].bias.copy_(T(torch, dec_np[3]))
+    return dec
+
+
+def opts(Nc, Nf, box_warp=1.0, white_back=False):
+    return {"ray_start": "auto", "ray_end": "auto", "box_warp": box_warp, "depth_resolution": Nc,
+            "depth_resolution_importance": Nf, "disparity_space_sampling": False, "clamp_mode": "softplus",
+            "white_back": white_back}
+
+
+def hip_render(torch, planes, dec_np, o, d, Nc, Nf, noise_c, u_f, box_warp=1.0, white_back=False):
+    from real3dportrait_amd import ImportanceRenderer
+    ren = ImportanceRenderer(hp={"triplane_feature_type": "triplane"})
+    ren.noise_override = (T(torch, noise_c), T(torch, u_f) if Nf > 0 else None)
+    out = ren(T(torch, planes), make_decoder(torch, dec_np), T(torch, o), T(torch, d), opts(Nc, Nf, box_warp, white_back))
+    torch.cuda.synchronize()
+    return [t.cpu().numpy() for t in out]
+
+
+def dec_of(g):
+    return g["dec_w1"], g["dec_b1"], g["dec_w2"], g["dec_b2"]
+
+
+@pytest.mark.parametrize("name", RENDER_CASES)
+def test_raygen_golden(torch_cuda, name):
+    torch = torch_cuda
+    from real3dportrait_amd import RaySampler
+    g = load_golden(name)
+    cams = T(torch, g["cams"])
+    o, d = RaySampler()(cams[:, :16].view(-1, 4, 4), cams[:, 16:].view(-1, 3, 3), int(g["R"]))
+    assert np.abs(o.cpu().numpy() - g["origins"]).max() <= 1e-6
+    assert np.abs(d.cpu().numpy() - g["dirs"]).max() <= 2e-6
+
+
+@pytest.mark.parametrize("name", RENDER_CASES)
+def test_render_golden(torch_cuda, name):
+    g = load_golden(name)
+    rgb, depth, wsum, valid = hip_render(torch_cuda, golden_planes(g), dec_of(g), g["origins"], g["dirs"],
+                                         int(g["Nc"]), int(g["Nf"]), g["noise_c"], g["u_f"],
+                                         float(g["box_warp"]), bool(g["white_back"]))
+    assert np.array_equal(valid, g["valid"])
+    assert np.abs(rgb - g["rgb"]).max() <= RGB_TOL
+    assert np.abs(wsum - g["wsum"]).max() <= RGB_TOL
+    assert np.abs(depth - g["depth"]).max() <= DEPTH_TOL
+
+
+def test_run_model_golden(torch_cuda):
+    torch = torch_cuda
+    from real3dportrait_amd import ImportanceRenderer
+    g = load_golden("run_model_a")
+    ren = ImportanceRenderer(hp={})
+    out = ren.run_model(T(torch, g["planes"]), make_decoder(torch, dec_of(g)), T(torch, g["coords"]), None, opts(16, 0))
+    assert np.abs(out["rgb"].cpu().numpy() - g["rgb"]).max() <= 2e-5
+    assert np.abs(out["sigma"].cpu().numpy() - g["sigma"]).max() <= 2e-4
+
+
+def load_block(torch, block, p):
+    with torch.no_grad():
+        for name in ("conv0", "conv1", "torgb"):
+            layer = getattr(block, name)
+            w, b, aw, ab = p[name]
+            layer.weight.copy_(T(torch, w)); layer.bias.copy_(T(torch, b))
+            layer.affine.weight.copy_(T(torch, aw)); layer.affine.bias.copy_(T(torch, ab))
+
+
+def test_sr_blocks_golden(torch_cuda):
+    torch = torch_cuda
+    from real3dportrait_amd import SynthesisBlock, synth
+    g = load_golden("sr_small_a")
+    params = synth.synth_sr_params(int(g["seed"]))
+    b0 = SynthesisBlock(32, 256, w_dim=512, resolution=32, img_channels=3, is_last=False, conv_clamp=None).cuda()
+    b1 = SynthesisBlock(256, 128, w_dim=512, resolution=64, img_channels=3, is_last=True, conv_clamp=None).cuda()
+    load_block(torch, b0, params[0]); load_block(torch, b1, params[1])
+    ws = T(torch, g["ws"])
+    x0, r0 = b0(T(torch, g["x"]), T(torch, g["rgb"]), ws, noise_mode="none")
+    x1, r1 = b1(x0, r0, ws, noise_mode="none")
+    for got, ref in ((x0[:, ::4], g["x0"]), (r0, g["rgb0"]), (x1[:, ::8], g["x1"]), (r1, g["rgb1"])):
+        assert np.abs(got.cpu().numpy() - ref).max() <= SR_TOL * max(1.0, np.abs(ref).max())
+
+
+def test_sr_full_golden(torch_cuda):
+    torch = torch_cuda
+    from real3dportrait_amd import SuperresolutionHybrid8XDC, synth
+    g = load_golden("sr_full_a")
+    seed = int(g["seed"])
+    params = synth.synth_sr_params(seed)
+    sr = SuperresolutionHybrid8XDC(channels=32, img_resolution=512, sr_num_fp16_res=0, sr_antialias=True).cuda()
+    load_block(torch, sr.block0, params[0]); load_block(torch, sr.block1, params[1])
+    x = T(torch, synth.hash_unitvar(seed, (1, 32, 128, 128), stream=1))
+    out = sr(x[:, :3].contiguous(), x, torch.ones(1, 14, 512, device="cuda"), noise_mode="none").cpu().numpy()
+    tol = SR_TOL * max(1.0, np.abs(g["strided"]).max())
+    assert np.abs(out[:, :, ::4, ::4] - g["strided"]).max() <= tol
+    assert np.abs(out[:, :, :96, :96] - g["corner"]).max() <= tol
+    assert np.abs(out[:, :, -64:, -64:] - g["tail"]).max() <= tol
+    assert abs(float(np.abs(out).mean()) - float(g["absmean"])) <= 1e-4
+
+
+def test_synthesis_golden(torch_cuda):
+    """TriPlaneGenerator.synthesis at the reference default (R=128, 48+48, SR -> 512^2) against the
+    reference's own output on identical planes / camera / noise."""
+    torch = torch_cuda
+    from real3dportrait_amd import TriPlaneGenerator, synth
+    g = load_golden("synthesis_ref_a")
+    seed = int(g["seed"])
+    G = TriPlaneGenerator().cuda()
+    dec_np = synth.synth_decoder(seed, sigma_bias=4.0)
+    with torch.no_grad():
+        G.decoder.net[0].weight.copy_(T(torch, dec_np[0])); G.decoder.net[0].bias.copy_(T(torch, dec_np[1]))
+        G.decoder.net[2].weight.copy_(T(torch, dec_np[2])); G.decoder.net[2].bias.copy_(T(torch, dec_np[3]))
+    params = synth.synth_sr_params(seed)
+    load_block(torch, G.superresolution.block0, params[0]); load_block(torch, G.superresolution.block1, params[1])
+    G._last_planes = T(torch, synth.synth_planes(seed, N=1)).view(1, 96, 256, 256)
+    R, Nc, Nf = int(g["R"]), int(g["Nc"]), int(g["Nf"])
+    G.renderer.noise_override = (T(torch, synth.synth_noise(seed, (1, R * R, Nc, 1), stream=7)),
+                                 T(torch, synth.synth_noise(seed, (R * R, Nf), stream=8)))
+    out = G.synthesis(torch.ones(1, 14, 512, device="cuda"), T(torch, g["cam"]), use_cached_backbone=True,
+                      noise_mode="none")
+    img = out["image"].cpu().numpy()
+    assert out["image"].shape == (1, 3, 512, 512) and out["image_feature"].shape == (1, 29, 128, 128)
+    assert np.abs(out["image_raw"].cpu().numpy() - g["image_raw"]).max() <= RGB_TOL
+    assert np.abs(out["image_depth"].cpu().numpy() - g["image_depth"]).max() <= DEPTH_TOL
+    assert np.abs(out["image_feature"].cpu().numpy()[:, ::4] - g["image_feature_strided"]).max() <= RGB_TOL
+    # SR amplifies its input error by the network gain; the image is clamped to [-1,1]
+    assert np.abs(img[:, :, ::4, ::4] - g["image_strided"]).max() <= 1e-3
+    assert np.abs(img[:, :, :96, :96] - g["image_corner"]).max() <= 1e-3
+
+
+# ------------------------------------------------------------------------------------------------
+# HIP vs the pinned oracle on fresh inputs (sizes the oracle finishes in seconds)
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("R,Nc,Nf,N,HW", [(32, 48, 48, 1, 64), (24, 20, 10, 3, 32), (16, 96, 96, 1, 32),
+                                           (40, 64, 32, 1, 48), (128, 48, 48, 1, 256)])
+def test_render_vs_oracle(torch_cuda, oracle, R, Nc, Nf, N, HW):
+    from real3dportrait_amd import synth
+    seed = 1000 + R + Nc
+    planes = synth.synth_planes(seed, N=N, H=HW, W=HW)
+    dec_np = synth.synth_decoder(seed, sigma_bias=3.0)
+    cams = synth.camera_sweep(N, -0.3, 0.3) if N > 1 else synth.look_at_camera(0.2, 0.1)[None]
+    o, d = oracle.raygen(cams[:, :16], cams[:, 16:], R)
+    noise_c = synth.synth_noise(seed, (N, R * R, Nc, 1), stream=7)
+    u_f = synth.synth_noise(seed, (N * R * R, Nf), stream=8)
+    ref = oracle.render(planes, dec_np, o, d, Nc, Nf, noise_c, u_f)
+    got = hip_render(torch_cuda, planes, dec_np, o, d, Nc, Nf, noise_c, u_f)
+    assert np.array_equal(got[3], ref[3])
+    assert np.abs(got[0] - ref[0]).max() <= RGB_TOL
+    assert np.abs(got[2] - ref[2]).max() <= RGB_TOL
+    assert np.abs(got[1] - ref[1]).max() <= DEPTH_TOL
+
+
+def test_non_square_ray_set_and_all_invalid(torch_cuda, oracle):
+    from real3dportrait_amd import synth
+    planes = synth.synth_planes(5, N=1, H=32, W=32)
+    dec_np = synth.synth_decoder(6)
+    cam = synth.look_at_camera(0.0, 0.0)
+    o, d = oracle.raygen(cam[None, :16], cam[None, 16:], 12)
+    o, d = o[:, :100], d[:, :100]                      # M = 100: not a square image -> linear ray order
+    noise_c = synth.synth_noise(1, (1, 100, 16, 1)); u_f = synth.synth_noise(2, (100, 16))
+    ref = oracle.render(planes, dec_np, o, d, 16, 16, noise_c, u_f)
+    got = hip_render(torch_cuda, planes, dec_np, o, d, 16, 16, noise_c, u_f)
+    assert np.abs(got[0] - ref[0]).max() <= RGB_TOL and np.abs(got[1] - ref[1]).max() <= DEPTH_TOL
+    cam[3] += 5.0                                      # camera looks past the box: no valid ray
+    o, d = oracle.raygen(cam[None, :16], cam[None, 16:], 8)
+    noise_c = synth.synth_noise(1, (1, 64, 16, 1)); u_f = synth.synth_noise(2, (64, 16))
+    ref = oracle.render(planes, dec_np, o, d, 16, 16, noise_c, u_f)
+    got = hip_render(torch_cuda, planes, dec_np, o, d, 16, 16, noise_c, u_f)
+    assert not got[3].any() and np.isfinite(got[0]).all()
+    assert np.abs(got[0] - ref[0]).max() <= RGB_TOL and np.abs(got[1] - ref[1]).max() <= DEPTH_TOL
+
+
+# ------------------------------------------------------------------------------------------------
+# size-independent properties at BASELINE sizes
+# ------------------------------------------------------------------------------------------------
+def test_full_size_properties(torch_cuda):
+    """R=512, 48+48 on 256^2 planes (the literal '512x512 neural render'): determinism, batch consistency,
+    weight-sum bounds, and shard-independence of the hash noise."""
+    torch = torch_cuda
+    from real3dportrait_amd import ImportanceRenderer, RaySampler, synth
+    planes = T(torch, synth.synth_planes(77, N=1))
+    dec = make_decoder(torch, synth.synth_decoder(78, sigma_bias=3.0))
+    cam = T(torch, synth.look_at_camera(0.15, -0.05)[None])
+    o, d = RaySampler()(cam[:, :16].view(-1, 4, 4), cam[:, 16:].view(-1, 3, 3), 512)
+    ren = ImportanceRenderer(hp={})
+    ren.noise_mode, ren.seed = "hash", 1234
+    a = ren(planes, dec, o, d, opts(48, 48))
+    b = ren(planes, dec, o, d, opts(48, 48))
+    torch.cuda.synchronize()
+    for x, y in zip(a, b):
+        assert torch.equal(x, y), "same inputs + same seed must be bit-identical"
+    rgb, depth, wsum, valid = a
+    assert torch.isfinite(rgb).all() and torch.isfinite(depth).all()
+    assert float(wsum.min()) >= 0.0 and float(wsum.max()) <= 1.0 + 1e-5
+    assert float(rgb.min()) >= -1.0 - 3e-3 and float(rgb.max()) <= 1.0 + 3e-3
+    assert valid.all()
+    # batch of two identical items == the single item (global couplings are min/max, hence unchanged)
+    planes2 = planes.repeat(2, 1, 1, 1, 1)
+    o2, d2 = o[:, :4096].repeat(2, 1, 1), d[:, :4096].repeat(2, 1, 1)
+    ren2 = ImportanceRenderer(hp={})
+    n1 = T(torch, synth.synth_noise(3, (1, 4096, 48, 1))); u1 = T(torch, synth.synth_noise(4, (4096, 48)))
+    ren2.noise_override = (n1.repeat(2, 1, 1, 1), u1.repeat(2, 1))
+    r2 = ren2(planes2, dec, o2, d2, opts(48, 48))
+    assert torch.equal(r2[0][0], r2[0][1]) and torch.equal(r2[1][0], r2[1][1])
+
+
+def test_sr_rgb_skip_is_linear(torch_cuda):
+    """The RGB skip path is linear: SR(rgb + delta, x) - SR(rgb, x) == upsample2d(upsample2d(delta)) and does not
+    depend on x (networks_stylegan2.py:463-469)."""
+    torch = torch_cuda
+    from real3dportrait_amd import SuperresolutionHybrid8XDC, synth
+    sr = SuperresolutionHybrid8XDC(channels=32, img_resolution=512, sr_num_fp16_res=0, sr_antialias=True).cuda()
+    params = synth.synth_sr_params(9)
+    load_block(torch, sr.block0, params[0]); load_block(torch, sr.block1, params[1])
+    x = T(torch, synth.hash_unitvar(9, (1, 32, 128, 128), stream=1))
+    rgb = x[:, :3].contiguous()
+    delta = torch.zeros_like(rgb); delta[0, 1, 40, 70] = 1.0
+    ws = torch.ones(1, 14, 512, device="cuda")
+    a = sr(rgb, x, ws, noise_mode="none"); b = sr(rgb + delta, x, ws, noise_mode="none")
+    diff = (b - a)[0]
+    assert float(diff[0].abs().max()) <= 1e-5 and float(diff[2].abs().max()) <= 1e-5
+    # impulse response of two [1,3,3,1]x[1,3,3,1]/16 upsamplings integrates to 16 (gain 4 each) and is local
+    assert abs(float(diff[1].sum()) - 16.0) <= 1e-3
+    nz = diff[1].abs() > 1e-6
+    ys, xs = torch.nonzero(nz, as_tuple=True)
+    assert int(ys.min()) >= 4 * 40 - 8 and int(ys.max()) <= 4 * 40 + 8 and int(xs.min()) >= 4 * 70 - 8 and int(xs.max()) <= 4 * 70 + 8
+
+
+def test_torch_rng_stream_matches_reference_order(torch_cuda):
+    """noise_mode='torch' must consume the generator like the reference: rand_like([N,M,Nc,1]) then rand([N*M,Nf])."""
+    torch = torch_cuda
+    from real3dportrait_amd import ImportanceRenderer, RaySampler, synth
+    planes = T(torch, synth.synth_planes(5, N=1, H=32, W=32))
+    dec = make_decoder(torch, synth.synth_decoder(6, sigma_bias=2.0))
+    cam = T(torch, synth.look_at_camera(0.0, 0.0)[None])
+    o, d = RaySampler()(cam[:, :16].view(-1, 4, 4), cam[:, 16:].view(-1, 3, 3), 16)
+    ren = ImportanceRenderer(hp={})
+    torch.manual_seed(99)
+    a = ren(planes, dec, o, d, opts(16, 16))
+    torch.manual_seed(99)
+    nc = torch.rand(1, 256, 16, 1, device="cuda"); uf = torch.rand(256, 16, device="cuda")
+    ren.noise_override = (nc, uf)
+    b = ren(planes, dec, o, d, opts(16, 16))
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+def test_unsupported_options_raise(torch_cuda):
+    torch = torch_cuda
+    from real3dportrait_amd import ImportanceRenderer
+    ren = ImportanceRenderer(hp={})
+    o = torch.zeros(1, 4, 3, device="cuda")
+    bad = opts(16, 0); bad["ray_start"] = 2.25; bad["ray_end"] = 3.3
+    with pytest.raises(NotImplementedError):
+        ren(torch.zeros(1, 3, 32, 8, 8, device="cuda"), None, o, o, bad)
+    bad = opts(16, 0); bad["clamp_mode"] = "relu"
+    with pytest.raises(AssertionError):
+        ren(torch.zeros(1, 3, 32, 8, 8, device="cuda"), None, o, o, bad)
