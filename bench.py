@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Benchmark of the per-frame hot path: TriPlaneGenerator.synthesis() on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one 512x512 frame per GPU: (cano + residual_t) tri-planes -> channel-last layout -> 128^2 rays ->
+48 coarse + 48 importance samples/ray (the reference's "48 depth samples": num_samples_coarse/fine,
+egs/egs_bases/eg3d/base.yaml:39-40) -> fused ray kernel -> SuperresolutionHybrid8XDC 128^2 -> 512^2 ->
+clamp -> uint8 frame in a device ring.  Frames are independent units: rank r renders its own K frames
+(weak scaling, no data-path collective) and ONE gather to rank 0 re-assembles the clip inside the timed region.
+Synthetic tri-planes / decoder / SR weights / cameras (no checkpoints offline).
+
+Prints ONE JSON line on rank 0 (see README of the task): metric, value (whole-job frames/s), roofline of the
+dominant kernel (conv_mfma_kernel, MFMA-bound) from HIP events recorded on the launch stream inside the timed
+region, and the CPU oracle timed on this box's host cores (a baseline, not the target).
+"""
+import argparse
+import json
+import math
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_TBPS = 8.0
+
+# algorithmic conv FLOPs of one frame: 2*taps*Cin*Cout*pixels for the four conv launches
+def conv_flops_per_frame(r=128):
+    t0 = 2 * 9 * 32 * 256 * r * r              # block0.conv0 transposed conv (9 taps per INPUT pixel)
+    c1 = 2 * 9 * 256 * 256 * (2 * r) ** 2      # block0.conv1
+    t2 = 2 * 9 * 256 * 128 * (2 * r) ** 2      # block1.conv0 transposed conv
+    c3 = 2 * 9 * 128 * 128 * (4 * r) ** 2      # block1.conv1
+    return [t0, c1, t2, c3]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    return ap.parse_args()
+
+
+def build_scene(torch, dev, seed=7, n_frames=64):
+    import numpy as np
+    from real3dportrait_amd import TriPlaneGenerator, synth
+    from real3dportrait_amd.frames import ClipRenderer
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    G = TriPlaneGenerator().to(dev).eval()
+    dec = synth.synth_decoder(seed, sigma_bias=4.0)
+    with torch.no_grad():
+        G.decoder.net[0].weight.copy_(T(dec[0])); G.decoder.net[0].bias.copy_(T(dec[1]))
+        G.decoder.net[2].weight.copy_(T(dec[2])); G.decoder.net[2].bias.copy_(T(dec[3]))
+        for blk, p in zip((G.superresolution.block0, G.superresolution.block1), synth.synth_sr_params(seed)):
+            for name in ("conv0", "conv1", "torgb"):
+                l = getattr(blk, name); w, b, aw, ab = p[name]
+                l.weight.copy_(T(w)); l.bias.copy_(T(b)); l.affine.weight.copy_(T(aw)); l.affine.bias.copy_(T(ab))
+    cano = T(synth.synth_planes(seed, N=1))
+    residuals = [T(synth.synth_planes(seed + 1 + i, N=1, scale=0.1)) for i in range(4)]
+    cams = T(synth.camera_sweep(n_frames, -0.4, 0.4))
+    ws = torch.ones(1, 14, 512, device=dev)
+    clip = ClipRenderer(G, cano, residuals, cams, ws, base_seed=seed)
+    return G, clip, dec, (cano, residuals, cams)
+
+
+def cpu_baseline(seed=7):
+    """The C oracle (oracle/r3d_oracle.c, OpenMP) renders the same frame on the host cores."""
+    import numpy as np
+    from oracle import Oracle
+    from real3dportrait_amd import synth
+    orc = Oracle()
+    planes = synth.synth_planes(seed, N=1) + synth.synth_planes(seed + 1, N=1, scale=0.1)
+    dec = synth.synth_decoder(seed, sigma_bias=4.0)
+    sr = synth.synth_sr_params(seed)
+    cam = synth.camera_sweep(64, -0.4, 0.4)[:1]
+    R, Nc, Nf = 128, 48, 48
+    noise_c = synth.synth_noise(seed, (1, R * R, Nc, 1)); u_f = synth.synth_noise(seed + 1, (R * R, Nf))
+    t0 = time.perf_counter()
+    o, d = orc.raygen(cam[:, :16], cam[:, 16:], R)
+    rgb, depth, wsum, valid = orc.render(planes, dec, o, d, Nc, Nf, noise_c, u_f)
+    t_render = time.perf_counter() - t0
+    feat = np.ascontiguousarray(rgb[0].T.reshape(32, R, R))
+    ws = np.ones((14, 512), np.float32)
+    # bounded: time the SR on the top-left 64^2 quarter first (1/4 of the conv work)
+    t0 = time.perf_counter()
+    orc.superresolution(np.ascontiguousarray(feat[:3, :64, :64]), np.ascontiguousarray(feat[:, :64, :64]), sr, ws)
+    t_q = time.perf_counter() - t0
+    if t_render + 4 * t_q <= 45.0:
+        t0 = time.perf_counter()
+        orc.superresolution(np.ascontiguousarray(feat[:3]), feat, sr, ws)
+        t_sr = time.perf_counter() - t0
+        sample = "1 full frame: render R=128 48+48 (%.2fs) + SR 128^2->512^2 (%.2fs)" % (t_render, t_sr)
+    else:
+        t_sr = 4 * t_q
+        sample = "render R=128 48+48 (%.2fs) + SR on a 64^2 quarter x4 (%.2fs extrapolated)" % (t_render, t_sr)
+    return {"value": 1.0 / (t_render + t_sr), "unit": "frames/s", "cores": orc.num_threads, "kind": "port",
+            "sample": sample}
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:      # convenience: self-launch one process per GPU
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", "29511", os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+    import torch
+    import torch.distributed as dist
+    from real3dportrait_amd import _lib
+    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback exists)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+    lib = _lib.load()
+
+    K, W = args.steps, args.warmup
+    G, clip, dec, scene = build_scene(torch, dev, n_frames=max(64, K * world))
+    ring = torch.zeros(K, 512, 512, 3, dtype=torch.uint8, device=dev)
+
+    def step(i):
+        t = rank * K + i
+        clip.render_u8(t, out=ring[i:i + 1])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(W):
+        step(i % K)
+    if world > 1:                                        # warm the gather path too
+        clip_out = __import__("real3dportrait_amd.frames", fromlist=["gather_frames"]).gather_frames(ring, K * world)
+    barrier()
+    lib.r3d_profile_configure(1 << 1)                    # bracket conv_mfma_kernel launches only (4 per frame)
+    lib.r3d_profile_reset()
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(i)
+    if world > 1:
+        from real3dportrait_amd.frames import gather_frames
+        clip_out = gather_frames(ring, K * world)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    lib.r3d_profile_configure(0)
+    el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+
+    # ---- roofline of the dominant kernel: conv_mfma_kernel (4 launches/frame), MFMA-bound ---------------------
+    import ctypes
+    ms, cnt = ctypes.c_double(0), ctypes.c_int(0)
+    _lib.check(lib.r3d_profile_read(1, ctypes.byref(ms), ctypes.byref(cnt)), "profile_read")
+    flops = conv_flops_per_frame(128)
+    conv_ms_per_frame = ms.value / max(1, cnt.value) * 4
+    achieved_tf = sum(flops) / (conv_ms_per_frame * 1e-3) / 1e12 if cnt.value else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("conv_mfma_kernel_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"kernel": "conv_mfma_kernel", "bound": "mfma", "achieved": round(achieved_tf, 2),
+                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved_tf / PEAK_F32_MFMA_TFLOPS, 4),
+                "traffic": traffic, "launches_per_frame": 4,
+                "avg_launch_ms": round(ms.value / max(1, cnt.value), 4),
+                "algorithmic_gflop_per_launch": round(sum(flops) / 4 / 1e9, 3)}
+
+    out = None
+    if rank == 0:
+        fps = K * world / elapsed
+        out = {"metric": "rendered frames/sec @ 512x512, 48 depth samples", "value": round(fps, 2), "unit": "frames/s",
+               "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "ref_frame_512: TriPlaneGenerator.synthesis path, 1 frame/step/GPU: "
+                                      "planes cano+residual [1,3,32,256,256] -> 128^2 rays x (48 coarse + 48 importance) "
+                                      "-> SuperresolutionHybrid8XDC -> 512^2 uint8; clip gathered to rank 0",
+                          "neural_rendering_resolution": 128, "depth_samples": "48+48", "final_resolution": 512,
+                          "frames_total": K * world, "parallelism": "frame-sharded dp%d + gather" % world},
+               "roofline": roofline}
+
+    # ---- per-family breakdown + the literal 512^2 neural render (untimed extras, rank 0 of a 1-GPU run) -------
+    if rank == 0 and world == 1 and not args.no_extras:
+        lib.r3d_profile_configure(0x7F); lib.r3d_profile_reset()
+        nb = 10
+        for i in range(nb):
+            step(i % K)
+        torch.cuda.synchronize()
+        names = ["render", "conv_mfma", "fir", "torgb", "sr_pack", "layout", "misc"]
+        bd = {}
+        for j, nme in enumerate(names):
+            _lib.check(lib.r3d_profile_read(j, ctypes.byref(ms), ctypes.byref(cnt)), "profile_read")
+            bd[nme] = round(ms.value / nb, 4)
+        lib.r3d_profile_configure(0)
+        out["breakdown_ms_per_frame"] = bd
+        # renderer-only roofline (gather-bound view): algorithmic touched bytes S*1536 + outputs
+        S = 128 * 128 * 96
+        out["render_kernel"] = {"ms": bd["render"], "algorithmic_GBps": round((S * 1536 + 128 * 128 * 137) / (bd["render"] * 1e-3) / 1e9, 1),
+                                "mlp_TFLOPs": round(S * 8320 / (bd["render"] * 1e-3) / 1e12, 2)}
+        # literal "512x512 neural render, 48 depth samples": R=512 rays, no SR
+        cano, residuals, cams = scene
+        opts = dict(G.rendering_kwargs)
+        o, d = G.ray_sampler(cams[:1, :16].view(-1, 4, 4), cams[:1, 16:25].view(-1, 3, 3), 512)
+        planes = clip.planes_for(0)
+        alt = {}
+        for nf in (0, 48):
+            opts["depth_resolution_importance"] = nf
+            for _ in range(2):
+                G.renderer(planes, G.decoder, o, d, opts)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                G.renderer(planes, G.decoder, o, d, opts)
+            torch.cuda.synchronize()
+            alt["R512_48+%d_fps" % nf] = round(5 / (time.perf_counter() - t1), 2)
+        out["alt_neural_render_512"] = alt
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -97,23 +97,29 @@ int r3d_run_model(const float* planes_nhwc, int N, int H, int W,
  * and the three plugin calls it makes: bias_act_plugin.bias_act (ops/bias_act.cpp:36),
  * upfirdn2d_plugin.upfirdn2d (ops/upfirdn2d.cpp:20) for the post-T-conv FIR and the RGB-skip upsample2d.
  *
- * r3d_sr_block_pack: modulation + demodulation + re-layout of the raw parameters for one batch of
- * style vectors (runs every forward; ~1.7 M parameters):
- *   ws3 [N,3,WD] (conv0, conv1, torgb style inputs);  *_w/_b/_aw/_ab = layer.weight / .bias /
- *   .affine.weight / .affine.bias;   packed: r3d_sr_block_packed_bytes(N,Cin,Cout) bytes.
+ * Modulated convolution is evaluated as  y = d[cout] * conv(s[ci] * x, W)  (== conv(x, W*s*d), :62-70), so:
+ * r3d_sr_block_prepack: STATIC re-layout of conv0/conv1 weights ([tap][ci/8][cout][ci%8]); call once per
+ *   parameter update.  prepacked: r3d_sr_block_prepacked_bytes(Cin,Cout) bytes.
+ * r3d_sr_block_styles: per-forward small vectors for one batch of style inputs: styles s = affine(w) (:326),
+ *   demodulation d = rsqrt(sum (W*s)^2 + 1e-8) (:65-70), modulated toRGB weights (:366-368), biases.
+ *   ws3 [N,3,WD] (conv0, conv1, torgb);  *_w/_b/_aw/_ab = layer.weight / .bias / .affine.weight / .affine.bias;
+ *   styles: r3d_sr_block_styles_bytes(N,Cin,Cout) bytes.
  * r3d_sr_block_forward:
  *   x [N,Cin,Hin,Win] NCHW or channel-blocked (see x_blocked), img [N,3,Hin,Win] NCHW
- *   -> x_out (channel-blocked [N,Cout/8,2Hin,2Win,8]; NCHW if x_out_nchw != 0), img_out [N,3,2Hin,2Win] NCHW.
+ *   -> x_out (channel-blocked [N,Cout/8,2Hin,2Win,8]; NCHW if x_out_nchw != 0; may be NULL), img_out [N,3,2Hin,2Win] NCHW.
  *   clamp < 0 disables conv_clamp (the fp32 configuration Real3D uses, img2plane_baseline.py:102-104).
  */
-size_t r3d_sr_block_packed_bytes(int N, int Cin, int Cout);
+size_t r3d_sr_block_prepacked_bytes(int Cin, int Cout);
+size_t r3d_sr_block_styles_bytes(int N, int Cin, int Cout);
 size_t r3d_sr_block_workspace_bytes(int N, int Cin, int Cout, int Hin, int Win);
-int r3d_sr_block_pack(const float* ws3, int N, int WD, int Cin, int Cout,
-                      const float* c0_w, const float* c0_b, const float* c0_aw, const float* c0_ab,
-                      const float* c1_w, const float* c1_b, const float* c1_aw, const float* c1_ab,
-                      const float* rgb_w, const float* rgb_b, const float* rgb_aw, const float* rgb_ab,
-                      void* packed, r3d_stream_t stream);
-int r3d_sr_block_forward(const void* packed, int N, int Cin, int Cout, int Hin, int Win,
+int r3d_sr_block_prepack(int Cin, int Cout, const float* c0_w, const float* c1_w, void* prepacked,
+                         r3d_stream_t stream);
+int r3d_sr_block_styles(const float* ws3, int N, int WD, int Cin, int Cout,
+                        const float* c0_w, const float* c0_b, const float* c0_aw, const float* c0_ab,
+                        const float* c1_w, const float* c1_b, const float* c1_aw, const float* c1_ab,
+                        const float* rgb_w, const float* rgb_b, const float* rgb_aw, const float* rgb_ab,
+                        void* styles, r3d_stream_t stream);
+int r3d_sr_block_forward(const void* prepacked, const void* styles, int N, int Cin, int Cout, int Hin, int Win,
                          const float* x, int x_blocked, const float* img, float clamp,
                          float* x_out, int x_out_nchw, float* img_out,
                          void* workspace, size_t workspace_bytes, r3d_stream_t stream);
@@ -130,6 +136,24 @@ int r3d_event_create(void** ev);
 int r3d_event_record(void* ev, r3d_stream_t stream);
 int r3d_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
 int r3d_event_destroy(void* ev);
+
+/* --- per-kernel-family timing (bench.py's roofline leg) -------------------------------------------
+ * When a family's bit is set in `mask`, every launch site of that family is bracketed by a HIP event pair
+ * recorded on the launch stream.  r3d_profile_read() synchronises on the recorded events and returns the
+ * summed duration and the number of bracketed launches since the last r3d_profile_reset(). */
+enum r3d_prof_id {
+    R3D_PROF_RENDER = 0,     /* render_kernel<..> (fused ray kernel)                       */
+    R3D_PROF_CONV = 1,       /* conv_mfma_kernel (3x3 / transposed-conv implicit GEMM)     */
+    R3D_PROF_FIR = 2,        /* fir_bias_act_kernel                                        */
+    R3D_PROF_TORGB = 3,      /* torgb_upsample_kernel                                      */
+    R3D_PROF_PACK = 4,       /* SR weight modulation / packing kernels                     */
+    R3D_PROF_LAYOUT = 5,     /* layout kernels (planes_to_nhwc, nchw<->cb8, frames_to_u8)  */
+    R3D_PROF_MISC = 6,       /* raygen, limits, clamp, init                                */
+    R3D_PROF_COUNT = 7
+};
+int r3d_profile_configure(uint32_t mask);
+int r3d_profile_reset(void);
+int r3d_profile_read(int id, double* total_ms, int* launches);
 
 #ifdef __cplusplus
 }

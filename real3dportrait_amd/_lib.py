@@ -26,12 +26,17 @@ SIGNATURES = {
     "r3d_render_forward": (c_int, [P, c_int, c_int, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_int,
                                    P, P, c_uint64, P, P, P, P, P, c_size_t, P]),
     "r3d_run_model": (c_int, [P, c_int, c_int, c_int, P, P, P, P, P, c_int, c_float, P, P, P]),
-    "r3d_sr_block_packed_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "r3d_sr_block_prepacked_bytes": (c_size_t, [c_int, c_int]),
+    "r3d_sr_block_styles_bytes": (c_size_t, [c_int, c_int, c_int]),
     "r3d_sr_block_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "r3d_sr_block_pack": (c_int, [P, c_int, c_int, c_int, c_int] + [P] * 12 + [P, P]),
-    "r3d_sr_block_forward": (c_int, [P, c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_float, P, c_int, P,
+    "r3d_sr_block_prepack": (c_int, [c_int, c_int, P, P, P, P]),
+    "r3d_sr_block_styles": (c_int, [P, c_int, c_int, c_int, c_int] + [P] * 12 + [P, P]),
+    "r3d_sr_block_forward": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_float, P, c_int, P,
                                      P, c_size_t, P]),
     "r3d_frames_to_u8": (c_int, [P, c_int, c_int, c_int, P, P]),
+    "r3d_profile_configure": (c_int, [ctypes.c_uint32]),
+    "r3d_profile_reset": (c_int, []),
+    "r3d_profile_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
     "r3d_event_create": (c_int, [ctypes.POINTER(c_void_p)]),
     "r3d_event_record": (c_int, [P, P]),
     "r3d_event_elapsed_ms": (c_int, [P, P, ctypes.POINTER(c_float)]),
@@ -55,6 +60,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64.so.7; it must be the HIP runtime of the process (one runtime, one
+    # set of streams/devices), so make sure it is mapped before our library asks the loader for that SONAME.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(
             "real3dportrait_amd: HIP extension %s not built -- run `make -C %s` (there is no CPU/eager fallback)"

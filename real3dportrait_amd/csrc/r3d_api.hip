@@ -2,6 +2,9 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <utility>
+#include <vector>
+
 #include "r3d_common.h"
 
 namespace r3d {
@@ -24,6 +27,29 @@ int check_launch(const char* what)
         return R3D_ERR_LAUNCH;
     }
     return R3D_OK;
+}
+
+// ---- event-pair profiling of launch sites -------------------------------------------------------------
+static uint32_t g_prof_mask = 0;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev[R3D_PROF_COUNT];
+static size_t g_prof_used[R3D_PROF_COUNT] = {0};
+
+void prof_begin(int id, hipStream_t st)
+{
+    if (!(g_prof_mask & (1u << id))) return;
+    if (g_prof_used[id] == g_prof_ev[id].size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        g_prof_ev[id].push_back(std::make_pair(a, b));
+    }
+    (void)hipEventRecord(g_prof_ev[id][g_prof_used[id]].first, st);
+}
+void prof_end(int id, hipStream_t st)
+{
+    if (!(g_prof_mask & (1u << id))) return;
+    if (g_prof_used[id] >= g_prof_ev[id].size()) return;
+    (void)hipEventRecord(g_prof_ev[id][g_prof_used[id]].second, st);
+    ++g_prof_used[id];
 }
 
 // clamp(-1,1) -> uint8 HWC  (inference/real3d_infer.py:495-521 does this on the host after the loop)
@@ -53,8 +79,31 @@ extern "C" int r3d_frames_to_u8(const float* img, int N, int H, int W, uint8_t* 
 {
     if (!img || !out || N <= 0 || H <= 0 || W <= 0) { set_error("frames_to_u8: bad argument"); return R3D_ERR_INVALID_ARG; }
     dim3 grid((H * W + 255) / 256, N);
+    ProfScope ps(R3D_PROF_LAYOUT, (hipStream_t)stream);
     hipLaunchKernelGGL(frames_to_u8_kernel, grid, dim3(256), 0, (hipStream_t)stream, img, H * W, out);
     return check_launch("frames_to_u8");
+}
+
+extern "C" int r3d_profile_configure(uint32_t mask) { g_prof_mask = mask; return R3D_OK; }
+extern "C" int r3d_profile_reset(void)
+{
+    for (int i = 0; i < R3D_PROF_COUNT; ++i) g_prof_used[i] = 0;
+    return R3D_OK;
+}
+extern "C" int r3d_profile_read(int id, double* total_ms, int* launches)
+{
+    if (id < 0 || id >= R3D_PROF_COUNT || !total_ms || !launches) { set_error("profile_read: bad argument"); return R3D_ERR_INVALID_ARG; }
+    double tot = 0.0;
+    for (size_t i = 0; i < g_prof_used[id]; ++i) {
+        float ms = 0.f;
+        if (hipEventSynchronize(g_prof_ev[id][i].second) != hipSuccess ||
+            hipEventElapsedTime(&ms, g_prof_ev[id][i].first, g_prof_ev[id][i].second) != hipSuccess) {
+            set_error("profile_read: event query failed"); return R3D_ERR_LAUNCH;
+        }
+        tot += ms;
+    }
+    *total_ms = tot; *launches = (int)g_prof_used[id];
+    return R3D_OK;
 }
 
 extern "C" int r3d_event_create(void** ev)
@@ -76,4 +125,4 @@ extern "C" int r3d_event_elapsed_ms(void* start, void* stop, float* ms)
     }
     return R3D_OK;
 }
-extern "C" int r3d_event_destroy(void* ev) { hipEventDestroy((hipEvent_t)ev); return R3D_OK; }
+extern "C" int r3d_event_destroy(void* ev) { (void)hipEventDestroy((hipEvent_t)ev); return R3D_OK; }

@@ -10,6 +10,15 @@ namespace r3d {
 void set_error(const char* fmt, ...);
 int check_launch(const char* what);
 
+// Optional per-launch-site timing with HIP events recorded ON THE LAUNCH STREAM (r3d_profile_* in r3d_hip.h).
+void prof_begin(int id, hipStream_t st);
+void prof_end(int id, hipStream_t st);
+struct ProfScope {
+    int id; hipStream_t st;
+    ProfScope(int id_, hipStream_t st_) : id(id_), st(st_) { prof_begin(id, st); }
+    ~ProfScope() { prof_end(id, st); }
+};
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- ordered-int encoding so float min/max can use integer atomics --------------------------------

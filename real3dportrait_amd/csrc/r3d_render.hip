@@ -718,6 +718,7 @@ extern "C" int r3d_planes_to_nhwc(const float* planes_nchw, const float* add_nch
     if (!planes_nchw || !planes_nhwc || N <= 0 || C <= 0 || H <= 0 || W <= 0) { set_error("planes_to_nhwc: bad argument"); return R3D_ERR_INVALID_ARG; }
     const int HW = H * W;
     dim3 grid((HW + 31) / 32, (C + 31) / 32, N * 3), block(32, 8);
+    ProfScope ps(R3D_PROF_LAYOUT, (hipStream_t)stream);
     hipLaunchKernelGGL(planes_to_nhwc_kernel, grid, block, 0, (hipStream_t)stream, planes_nchw, add_nchw, planes_nhwc, C, HW);
     return check_launch("planes_to_nhwc");
 }
@@ -727,6 +728,7 @@ extern "C" int r3d_raygen(const float* c2w, const float* intrinsics, int N, int 
 {
     if (!c2w || !intrinsics || !origins || !dirs || N <= 0 || R <= 0) { set_error("raygen: bad argument"); return R3D_ERR_INVALID_ARG; }
     dim3 grid((R * R + 255) / 256, N);
+    ProfScope ps(R3D_PROF_MISC, (hipStream_t)stream);
     hipLaunchKernelGGL(raygen_kernel, grid, dim3(256), 0, (hipStream_t)stream, c2w, intrinsics, R, origins, dirs);
     return check_launch("raygen");
 }
@@ -762,9 +764,12 @@ extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
     float* ray_start = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + sizeof(RenderWs));
     float* ray_end = ray_start + nrays;
 
-    hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, st, gstate);
-    hipLaunchKernelGGL(ray_limits_kernel, dim3((nrays + 255) / 256), dim3(256), 0, st, origins, dirs, nrays,
-                       box_warp * 0.5f, ray_start, ray_end, valid, gstate);
+    {
+        ProfScope ps(R3D_PROF_MISC, st);
+        hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, st, gstate);
+        hipLaunchKernelGGL(ray_limits_kernel, dim3((nrays + 255) / 256), dim3(256), 0, st, origins, dirs, nrays,
+                           box_warp * 0.5f, ray_start, ray_end, valid, gstate);
+    }
 
     RenderArgs a;
     a.planes4 = reinterpret_cast<const float4*>(planes_nhwc); a.N = N; a.H = H; a.W = W; a.M = M;
@@ -783,6 +788,8 @@ extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
     if (grid > max_blocks) grid = max_blocks;
 
     const int ntc = (Nc + 15) / 16, ntf = (Nf + 15) / 16;
+    {
+    ProfScope ps(R3D_PROF_RENDER, st);
 #define R3D_CASE(C_, F_) else if (ntc == C_ && ntf == F_) launch_render<C_, F_>(a, R, grid, st)
     if (false) {}
     R3D_CASE(1, 0); R3D_CASE(1, 1); R3D_CASE(2, 0); R3D_CASE(2, 1); R3D_CASE(2, 2);
@@ -793,6 +800,8 @@ extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
     else if (ntc <= 4 && ntf <= 4) launch_render<4, 4>(a, R, grid, st);
     else launch_render<6, 6>(a, R, grid, st);
 #undef R3D_CASE
+    }
+    ProfScope ps2(R3D_PROF_MISC, st);
     hipLaunchKernelGGL(depth_clamp_kernel, dim3((nrays + 255) / 256), dim3(256), 0, st, depth, nrays, gstate);
     return check_launch("render_forward");
 }
@@ -808,6 +817,7 @@ extern "C" int r3d_run_model(const float* planes_nhwc, int N, int H, int W,
     const long long chunks = ((long long)N * npts + 63) / 64;
     int grid = (int)((chunks + kWavesPerBlock - 1) / kWavesPerBlock);
     if (grid > 1024) grid = 1024;
+    ProfScope ps(R3D_PROF_RENDER, (hipStream_t)stream);
     hipLaunchKernelGGL(run_model_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const float4*>(planes_nhwc), N, H, W, w1, b1, w2, b2, coords, npts,
                        2.0f / box_warp, rgb, sigma);

@@ -59,23 +59,24 @@ __global__ void cb8_to_nchw_kernel(const float* __restrict__ src, float* __restr
 }
 
 // -------------------------------------------------------------------------------------------------
-// weight packing: styles = affine(w) (networks_stylegan2.py:326, FullyConnectedLayer :99-131),
-// w'' = W*s*rsqrt(sum (W*s)^2 + 1e-8) (:62-70); toRGB: styles/sqrt(Cin), no demod (:366-368)
-// packed (floats, per batch item): see SrPackLayout
+// Modulated convolution without per-frame weight rewriting.
+//   reference (networks_stylegan2.py:62-70):  y = conv(x, W*s*d),  s = affine(w),  d = rsqrt(sum (W*s)^2 + 1e-8)
+//   here:                                     y = d[co] * conv(s[ci]*x, W)
+// so the conv weights are re-laid out ONCE (r3d_sr_block_prepack: [tap][ci/8][cout][ci%8], a wave's A-operand
+// load is 1 KB contiguous) and each forward only computes the small vectors s (styles), d (demodulation),
+// the 3xC modulated toRGB weights and copies the biases (r3d_sr_block_styles).
+// styles buffer (floats, per batch item): see SrStyleLayout
 // -------------------------------------------------------------------------------------------------
-struct SrPackLayout {
-    size_t styles0, styles1, styles2, wp0, wp1, wrgb, b0, b1, brgb, total;
-};
-static __host__ __device__ inline SrPackLayout sr_layout(int Cin, int Cout)
+struct SrStyleLayout { size_t s0, s1, s2, d0, d1, wrgb, b0, b1, brgb, total; };
+static __host__ __device__ inline SrStyleLayout sr_style_layout(int Cin, int Cout)
 {
-    SrPackLayout L;
+    SrStyleLayout L;
     size_t o = 0;
-    L.styles0 = o; o += Cin;
-    L.styles1 = o; o += Cout;
-    L.styles2 = o; o += Cout;
-    o = (o + 3) & ~(size_t)3;
-    L.wp0 = o; o += (size_t)9 * Cin * Cout;
-    L.wp1 = o; o += (size_t)9 * Cout * Cout;
+    L.s0 = o; o += Cin;
+    L.s1 = o; o += Cout;
+    L.s2 = o; o += Cout;
+    L.d0 = o; o += Cout;
+    L.d1 = o; o += Cout;
     L.wrgb = o; o += (size_t)3 * Cout;
     L.b0 = o; o += Cout;
     L.b1 = o; o += Cout;
@@ -84,69 +85,75 @@ static __host__ __device__ inline SrPackLayout sr_layout(int Cin, int Cout)
     return L;
 }
 
-// grid (3 layers, N); each wave computes style rows
+// static re-layout: prepacked = [conv0: 9][Cin/8][Cout][8] ++ [conv1: 9][Cout/8][Cout][8]; one thread per float4
+__global__ void sr_prepack_kernel(const float* __restrict__ w, int Ci, int Cout, float* __restrict__ out)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // (tap, chunk, cout, half)
+    const size_t total = (size_t)9 * (Ci / 8) * Cout * 2;
+    if (e >= total) return;
+    const int half = e & 1;
+    const int co = (e >> 1) % Cout;
+    const int chunk = ((e >> 1) / Cout) % (Ci / 8);
+    const int tap = (int)((e >> 1) / Cout / (Ci / 8));
+    const int ci = chunk * 8 + half * 4;
+    const float* src = w + ((size_t)co * Ci + ci) * 9 + tap;
+    reinterpret_cast<float4*>(out)[e] = make_float4(src[0], src[9], src[18], src[27]);
+}
+
+// grid (ceil(max(Cin,Cout)/4), 3 layers, N), one wave per style row: styles = affine(w)
+// (networks_stylegan2.py:326; FullyConnectedLayer :99-131); toRGB styles carry the 1/sqrt(Cin) gain (:366)
 __global__ void sr_styles_kernel(const float* __restrict__ ws3, int WD, int Cin, int Cout,
                                  const float* __restrict__ aw0, const float* __restrict__ ab0,
                                  const float* __restrict__ aw1, const float* __restrict__ ab1,
                                  const float* __restrict__ aw2, const float* __restrict__ ab2,
-                                 float* __restrict__ packed, size_t stride_n)
+                                 float* __restrict__ styles, size_t stride_n)
 {
-    const int layer = blockIdx.x, n = blockIdx.y;
-    const SrPackLayout L = sr_layout(Cin, Cout);
+    const int layer = blockIdx.y, n = blockIdx.z;
+    const SrStyleLayout L = sr_style_layout(Cin, Cout);
     const float* aw = layer == 0 ? aw0 : (layer == 1 ? aw1 : aw2);
     const float* ab = layer == 0 ? ab0 : (layer == 1 ? ab1 : ab2);
     const int C = layer == 0 ? Cin : Cout;
-    float* out = packed + n * stride_n + (layer == 0 ? L.styles0 : (layer == 1 ? L.styles1 : L.styles2));
+    const int lane = threadIdx.x & 63, c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (c >= C) return;
+    float* out = styles + n * stride_n + (layer == 0 ? L.s0 : (layer == 1 ? L.s1 : L.s2));
     const float* w = ws3 + ((size_t)n * 3 + layer) * WD;
     const float g = rsqrtf((float)WD);
-    const float post = layer == 2 ? rsqrtf((float)Cout) : 1.0f;     // ToRGB weight_gain
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    for (int c = wave; c < C; c += nw) {
-        float acc = 0.f;
-        for (int j = lane; j < WD; j += 64) acc += w[j] * (aw[(size_t)c * WD + j] * g);
+    const float post = layer == 2 ? rsqrtf((float)Cout) : 1.0f;
+    float acc = 0.f;
+    for (int j = lane; j < WD; j += 64) acc += w[j] * (aw[(size_t)c * WD + j] * g);
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
-        if (lane == 0) out[c] = (acc + ab[c]) * post;
-    }
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+    if (lane == 0) out[c] = (acc + ab[c]) * post;
 }
 
-// grid (Cout, N, 2): one block per output channel of conv0 (z=0) / conv1 (z=1)
-// packed conv weights: [tap][ci/8][cout][ci%8]
-__global__ void sr_modulate_kernel(int Cin, int Cout, const float* __restrict__ w0, const float* __restrict__ w1,
-                                   float* __restrict__ packed, size_t stride_n)
+// grid (Cout/4, N, 2): one WAVE per output channel: d = rsqrt(sum_{ci,k} (W*s)^2 + 1e-8)
+__global__ void sr_demod_kernel(int Cin, int Cout, const float* __restrict__ w0, const float* __restrict__ w1,
+                                float* __restrict__ styles, size_t stride_n)
 {
-    const int co = blockIdx.x, n = blockIdx.y, layer = blockIdx.z;
-    const SrPackLayout L = sr_layout(Cin, Cout);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int co = blockIdx.x * 4 + wave, n = blockIdx.y, layer = blockIdx.z;
+    if (co >= Cout) return;
+    const SrStyleLayout L = sr_style_layout(Cin, Cout);
     const int Ci = layer == 0 ? Cin : Cout;
     const float* W = (layer == 0 ? w0 : w1) + (size_t)co * Ci * 9;
-    float* base = packed + n * stride_n;
-    const float* st = base + (layer == 0 ? L.styles0 : L.styles1);
-    float* wp = base + (layer == 0 ? L.wp0 : L.wp1);
-    __shared__ float red[4];
+    float* base = styles + n * stride_n;
+    const float* st = base + (layer == 0 ? L.s0 : L.s1);
     float ss = 0.f;
-    for (int i = threadIdx.x; i < Ci * 9; i += blockDim.x) { const float v = W[i] * st[i / 9]; ss += v * v; }
+    for (int i = lane; i < Ci * 9; i += 64) { const float v = W[i] * st[i / 9]; ss += v * v; }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) ss += __shfl_xor(ss, d);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
-    __syncthreads();
-    float tot = 0.f;
-    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) tot += red[i];
-    const float dco = rsqrtf(tot + 1e-8f);
-    for (int i = threadIdx.x; i < Ci * 9; i += blockDim.x) {
-        const int ci = i / 9, tap = i - ci * 9;
-        wp[(((size_t)tap * (Ci / 8) + (ci >> 3)) * Cout + co) * 8 + (ci & 7)] = W[i] * st[ci] * dco;
-    }
+    if (lane == 0) base[(layer == 0 ? L.d0 : L.d1) + co] = rsqrtf(ss + 1e-8f);
 }
 
-__global__ void sr_pack_misc_kernel(int Cin, int Cout, const float* __restrict__ wrgb, const float* __restrict__ b0,
-                                    const float* __restrict__ b1, const float* __restrict__ brgb,
-                                    float* __restrict__ packed, size_t stride_n)
+__global__ void sr_style_misc_kernel(int Cin, int Cout, const float* __restrict__ wrgb, const float* __restrict__ b0,
+                                     const float* __restrict__ b1, const float* __restrict__ brgb,
+                                     float* __restrict__ styles, size_t stride_n)
 {
     const int n = blockIdx.y;
-    const SrPackLayout L = sr_layout(Cin, Cout);
-    float* base = packed + n * stride_n;
+    const SrStyleLayout L = sr_style_layout(Cin, Cout);
+    float* base = styles + n * stride_n;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 3 * Cout) base[L.wrgb + i] = wrgb[i] * base[L.styles2 + (i % Cout)];
+    if (i < 3 * Cout) base[L.wrgb + i] = wrgb[i] * base[L.s2 + (i % Cout)];
     if (i < Cout) { base[L.b0 + i] = b0[i]; base[L.b1 + i] = b1[i]; }
     if (i < 3) base[L.brgb + i] = brgb[i];
 }
@@ -162,8 +169,11 @@ struct ConvPhase {
 };
 struct ConvArgs {
     const float* x;  size_t x_stride_n;       // CB8 input  [Cin/8][H][W][8]
-    const float* wp; size_t wp_stride_n;      // packed weights [9][Cin/8][Cout][8]
-    const float* bias; size_t bias_stride_n;  // [Cout] or nullptr
+    const float* wp;                          // static pre-packed weights [9][Cin/8][Cout][8]
+    const float* in_scale;                    // styles  s[ci]  (per batch item, stride vec_stride_n)
+    const float* out_scale;                   // demod   d[cout]
+    const float* bias;                        // [Cout] or nullptr
+    size_t vec_stride_n;
     float* y; size_t y_stride_n;              // CB8 output [Cout/8][OH][OW][8]
     int Cin, Cout, H, W, OH, OW;
     int nphase, act; float clamp;
@@ -183,7 +193,8 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, const ConvPhase& p
     const int li = lane & 31, h = lane >> 5;
     const int nchunks = a.Cin >> 3;
     const float* X = a.x + (size_t)n * a.x_stride_n;
-    const float4* WP = reinterpret_cast<const float4*>(a.wp + (size_t)n * a.wp_stride_n);
+    const float4* WP = reinterpret_cast<const float4*>(a.wp);
+    const float4* SC = reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.vec_stride_n);
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -211,8 +222,11 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, const ConvPhase& p
             const int py = pp / PATCH_W, px = pp - py * PATCH_W;
             const int iy = i0 + py - 1, ix = j0 + px - 1;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
                 v = *reinterpret_cast<const float4*>(X + (((size_t)(c0 + c) * a.H + iy) * a.W + ix) * 8 + half * 4);
+                const float4 sc = SC[(c0 + c) * 2 + half];          // modulation: x * s[ci]
+                v.x *= sc.x; v.y *= sc.y; v.z *= sc.z; v.w *= sc.w;
+            }
             reinterpret_cast<float4*>(patch)[(c * PATCH_PIX + pp) * 2 + half] = v;
         }
         __syncthreads();
@@ -246,7 +260,8 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, const ConvPhase& p
 
     // ---- epilogue: bias + lrelu(0.2)*sqrt(2) (+clamp)  (bias_act.py:93-122), CB8 store ------------
     float* Y = a.y + (size_t)n * a.y_stride_n;
-    const float* B = a.bias ? a.bias + (size_t)n * a.bias_stride_n : nullptr;
+    const float* B = a.bias ? a.bias + (size_t)n * a.vec_stride_n : nullptr;
+    const float* D = a.out_scale + (size_t)n * a.vec_stride_n;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int i = i0 + wn * 4 + nt * 2 + (li >> 4), j = j0 + (li & 15);
@@ -260,7 +275,7 @@ __device__ __forceinline__ void conv_block(const ConvArgs& a, const ConvPhase& p
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float t = acc[mt][nt][4 * g + r];
+                    float t = acc[mt][nt][4 * g + r] * D[co + r];      // demodulation
                     if (a.act) {
                         t += B[co + r];
                         t = (t < 0.f ? t * 0.2f : t) * 1.4142135623730951f;
@@ -397,9 +412,14 @@ static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 using namespace r3d;
 
-extern "C" size_t r3d_sr_block_packed_bytes(int N, int Cin, int Cout)
+extern "C" size_t r3d_sr_block_prepacked_bytes(int Cin, int Cout)
 {
-    return (size_t)N * sr_layout(Cin, Cout).total * sizeof(float);
+    return ((size_t)9 * Cin * Cout + (size_t)9 * Cout * Cout) * sizeof(float);
+}
+
+extern "C" size_t r3d_sr_block_styles_bytes(int N, int Cin, int Cout)
+{
+    return (size_t)N * sr_style_layout(Cin, Cout).total * sizeof(float);
 }
 
 extern "C" size_t r3d_sr_block_workspace_bytes(int N, int Cin, int Cout, int Hin, int Win)
@@ -411,42 +431,66 @@ extern "C" size_t r3d_sr_block_workspace_bytes(int N, int Cin, int Cout, int Hin
     return xin + T + y0 + xo;
 }
 
-extern "C" int r3d_sr_block_pack(const float* ws3, int N, int WD, int Cin, int Cout,
-                                 const float* c0_w, const float* c0_b, const float* c0_aw, const float* c0_ab,
-                                 const float* c1_w, const float* c1_b, const float* c1_aw, const float* c1_ab,
-                                 const float* rgb_w, const float* rgb_b, const float* rgb_aw, const float* rgb_ab,
-                                 void* packed, r3d_stream_t stream)
+static int sr_check_dims(const char* what, int Cin, int Cout)
 {
-    if (!ws3 || !c0_w || !c0_b || !c0_aw || !c0_ab || !c1_w || !c1_b || !c1_aw || !c1_ab || !rgb_w || !rgb_b || !rgb_aw || !rgb_ab || !packed) {
-        set_error("sr_block_pack: NULL pointer"); return R3D_ERR_INVALID_ARG;
-    }
-    if (N <= 0 || WD <= 0 || Cin <= 0 || Cout <= 0 || (Cin & 7) || (Cout % BLOCK_M)) {
-        set_error("sr_block_pack: Cin %d must be a multiple of 8 and Cout %d a multiple of %d", Cin, Cout, BLOCK_M);
+    if (Cin <= 0 || Cout <= 0 || (Cin & 7) || (Cout % BLOCK_M)) {
+        set_error("%s: Cin %d must be a multiple of 8 and Cout %d a multiple of %d", what, Cin, Cout, BLOCK_M);
         return R3D_ERR_INVALID_ARG;
     }
-    hipStream_t st = (hipStream_t)stream;
-    float* pk = reinterpret_cast<float*>(packed);
-    const size_t stride = sr_layout(Cin, Cout).total;
-    hipLaunchKernelGGL(sr_styles_kernel, dim3(3, N), dim3(256), 0, st, ws3, WD, Cin, Cout, c0_aw, c0_ab, c1_aw, c1_ab, rgb_aw, rgb_ab, pk, stride);
-    hipLaunchKernelGGL(sr_modulate_kernel, dim3(Cout, N, 2), dim3(256), 0, st, Cin, Cout, c0_w, c1_w, pk, stride);
-    hipLaunchKernelGGL(sr_pack_misc_kernel, dim3((3 * Cout + 255) / 256, N), dim3(256), 0, st, Cin, Cout, rgb_w, c0_b, c1_b, rgb_b, pk, stride);
-    return check_launch("sr_block_pack");
+    return R3D_OK;
 }
 
-extern "C" int r3d_sr_block_forward(const void* packed, int N, int Cin, int Cout, int Hin, int Win,
+extern "C" int r3d_sr_block_prepack(int Cin, int Cout, const float* c0_w, const float* c1_w, void* prepacked,
+                                    r3d_stream_t stream)
+{
+    if (!c0_w || !c1_w || !prepacked) { set_error("sr_block_prepack: NULL pointer"); return R3D_ERR_INVALID_ARG; }
+    if (int rc = sr_check_dims("sr_block_prepack", Cin, Cout)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    float* out = reinterpret_cast<float*>(prepacked);
+    ProfScope ps(R3D_PROF_PACK, st);
+    const size_t n0 = (size_t)9 * (Cin / 8) * Cout * 2, n1 = (size_t)9 * (Cout / 8) * Cout * 2;
+    hipLaunchKernelGGL(sr_prepack_kernel, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, st, c0_w, Cin, Cout, out);
+    hipLaunchKernelGGL(sr_prepack_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, c1_w, Cout, Cout,
+                       out + (size_t)9 * Cin * Cout);
+    return check_launch("sr_block_prepack");
+}
+
+extern "C" int r3d_sr_block_styles(const float* ws3, int N, int WD, int Cin, int Cout,
+                                   const float* c0_w, const float* c0_b, const float* c0_aw, const float* c0_ab,
+                                   const float* c1_w, const float* c1_b, const float* c1_aw, const float* c1_ab,
+                                   const float* rgb_w, const float* rgb_b, const float* rgb_aw, const float* rgb_ab,
+                                   void* styles, r3d_stream_t stream)
+{
+    if (!ws3 || !c0_w || !c0_b || !c0_aw || !c0_ab || !c1_w || !c1_b || !c1_aw || !c1_ab || !rgb_w || !rgb_b || !rgb_aw || !rgb_ab || !styles) {
+        set_error("sr_block_styles: NULL pointer"); return R3D_ERR_INVALID_ARG;
+    }
+    if (N <= 0 || WD <= 0) { set_error("sr_block_styles: bad shape"); return R3D_ERR_INVALID_ARG; }
+    if (int rc = sr_check_dims("sr_block_styles", Cin, Cout)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    float* sv = reinterpret_cast<float*>(styles);
+    const size_t stride = sr_style_layout(Cin, Cout).total;
+    ProfScope ps(R3D_PROF_PACK, st);
+    hipLaunchKernelGGL(sr_styles_kernel, dim3(((Cin > Cout ? Cin : Cout) + 3) / 4, 3, N), dim3(256), 0, st, ws3, WD, Cin, Cout, c0_aw, c0_ab, c1_aw, c1_ab, rgb_aw, rgb_ab, sv, stride);
+    hipLaunchKernelGGL(sr_demod_kernel, dim3((Cout + 3) / 4, N, 2), dim3(256), 0, st, Cin, Cout, c0_w, c1_w, sv, stride);
+    hipLaunchKernelGGL(sr_style_misc_kernel, dim3((3 * Cout + 255) / 256, N), dim3(256), 0, st, Cin, Cout, rgb_w, c0_b, c1_b, rgb_b, sv, stride);
+    return check_launch("sr_block_styles");
+}
+
+extern "C" int r3d_sr_block_forward(const void* prepacked, const void* styles, int N, int Cin, int Cout, int Hin, int Win,
                                     const float* x, int x_blocked, const float* img, float clamp,
                                     float* x_out, int x_out_nchw, float* img_out,
                                     void* workspace, size_t workspace_bytes, r3d_stream_t stream)
 {
-    if (!packed || !x || !img || !img_out || N <= 0 || Hin <= 0 || Win <= 0 || (Cin & 7) || (Cout % BLOCK_M)) {
+    if (!prepacked || !styles || !x || !img || !img_out || N <= 0 || Hin <= 0 || Win <= 0 || (Cin & 7) || (Cout % BLOCK_M)) {
         set_error("sr_block_forward: bad argument"); return R3D_ERR_INVALID_ARG;
     }
     if (!workspace || workspace_bytes < r3d_sr_block_workspace_bytes(N, Cin, Cout, Hin, Win)) {
         set_error("sr_block_forward: workspace too small"); return R3D_ERR_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
-    const SrPackLayout L = sr_layout(Cin, Cout);
-    const float* pk = reinterpret_cast<const float*>(packed);
+    const SrStyleLayout L = sr_style_layout(Cin, Cout);
+    const float* pk = reinterpret_cast<const float*>(styles);
+    const float* wpk = reinterpret_cast<const float*>(prepacked);
     const int OH = 2 * Hin, OW = 2 * Win, TH = OH + 1, TW = OW + 1;
     char* wsb = reinterpret_cast<char*>(workspace);
     float* xin = reinterpret_cast<float*>(wsb); wsb += align256((size_t)N * Cin * Hin * Win * 4);
@@ -456,6 +500,7 @@ extern "C" int r3d_sr_block_forward(const void* packed, int N, int Cin, int Cout
 
     const float* xcb = x;
     if (!x_blocked) {
+        ProfScope ps(R3D_PROF_LAYOUT, st);
         hipLaunchKernelGGL(nchw_to_cb8_kernel, dim3((Hin * Win + 255) / 256, Cin / 8, N), dim3(256), 0, st, x, xin, Cin, Hin * Win);
         xcb = xin;
     }
@@ -463,8 +508,8 @@ extern "C" int r3d_sr_block_forward(const void* packed, int N, int Cin, int Cout
     {
         ConvArgs a;
         a.x = xcb; a.x_stride_n = (size_t)Cin * Hin * Win;
-        a.wp = pk + L.wp0; a.wp_stride_n = L.total;
-        a.bias = nullptr; a.bias_stride_n = 0;
+        a.wp = wpk; a.in_scale = pk + L.s0; a.out_scale = pk + L.d0; a.vec_stride_n = L.total;
+        a.bias = nullptr;
         a.y = T; a.y_stride_n = (size_t)Cout * TH * TW;
         a.Cin = Cin; a.Cout = Cout; a.H = Hin; a.W = Win; a.OH = TH; a.OW = TW;
         a.nphase = 4; a.act = 0; a.clamp = -1.f;
@@ -484,17 +529,21 @@ extern "C" int r3d_sr_block_forward(const void* packed, int N, int Cin, int Cout
                 const int tiles = ((p.outW + TILE_W - 1) / TILE_W) * ((p.outH + TILE_H - 1) / TILE_H);
                 if (tiles > maxtiles) maxtiles = tiles;
             }
+        ProfScope ps(R3D_PROF_CONV, st);
         hipLaunchKernelGGL(conv_mfma_kernel, dim3(maxtiles, Cout / BLOCK_M, N * 4), dim3(256), 0, st, a);
     }
+    {
+    ProfScope ps(R3D_PROF_FIR, st);
     hipLaunchKernelGGL(fir_bias_act_kernel, dim3((OH * OW * 2 + 255) / 256, Cout / 8, N), dim3(256), 0, st,
                        T, (size_t)Cout * TH * TW, pk + L.b0, L.total, y0, (size_t)Cout * OH * OW, Cout, OH, OW, clamp);
+    }
     // ---- conv1: 3x3 pad 1 --------------------------------------------------------------------------------
     float* xo_cb = (x_out && !x_out_nchw) ? x_out : xo;
     {
         ConvArgs a;
         a.x = y0; a.x_stride_n = (size_t)Cout * OH * OW;
-        a.wp = pk + L.wp1; a.wp_stride_n = L.total;
-        a.bias = pk + L.b1; a.bias_stride_n = L.total;
+        a.wp = wpk + (size_t)9 * Cin * Cout; a.in_scale = pk + L.s1; a.out_scale = pk + L.d1; a.vec_stride_n = L.total;
+        a.bias = pk + L.b1;
         a.y = xo_cb; a.y_stride_n = (size_t)Cout * OH * OW;
         a.Cin = Cout; a.Cout = Cout; a.H = OH; a.W = OW; a.OH = OH; a.OW = OW;
         a.nphase = 1; a.act = 1; a.clamp = clamp;
@@ -503,12 +552,18 @@ extern "C" int r3d_sr_block_forward(const void* packed, int N, int Cin, int Cout
         for (int ky = 0; ky < 3; ++ky)
             for (int kx = 0; kx < 3; ++kx) { p.dy[ky * 3 + kx] = ky - 1; p.dx[ky * 3 + kx] = kx - 1; p.widx[ky * 3 + kx] = ky * 3 + kx; }
         const int tiles = ((OW + TILE_W - 1) / TILE_W) * ((OH + TILE_H - 1) / TILE_H);
+        ProfScope ps(R3D_PROF_CONV, st);
         hipLaunchKernelGGL(conv_mfma_kernel, dim3(tiles, Cout / BLOCK_M, N), dim3(256), 0, st, a);
     }
     // ---- toRGB + skip upsample ---------------------------------------------------------------------------
+    {
+    ProfScope ps(R3D_PROF_TORGB, st);
     hipLaunchKernelGGL(torgb_upsample_kernel, dim3((OH * OW + 255) / 256, N), dim3(256), 3 * Cout * sizeof(float), st,
                        xo_cb, (size_t)Cout * OH * OW, pk + L.wrgb, pk + L.brgb, L.total, img, img_out, Cout, OH, OW, clamp);
-    if (x_out && x_out_nchw)
+    }
+    if (x_out && x_out_nchw) {
+        ProfScope ps(R3D_PROF_LAYOUT, st);
         hipLaunchKernelGGL(cb8_to_nchw_kernel, dim3((OH * OW + 255) / 256, Cout / 8, N), dim3(256), 0, st, xo_cb, x_out, Cout, OH * OW);
+    }
     return check_launch("sr_block_forward");
 }

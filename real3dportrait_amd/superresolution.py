@@ -88,7 +88,9 @@ class SynthesisBlock(nn.Module):
         self.conv_clamp = conv_clamp
         self.blocked_output = False
         self.return_x = True           # False: skip materialising x (last block of SuperresolutionHybrid8XDC)
-        self._packed = None
+        self._prepacked = None
+        self._prepack_key = None
+        self._styles = None
         self._workspace = None
 
     def _buf(self, name, nbytes, dev):
@@ -117,14 +119,21 @@ class SynthesisBlock(nn.Module):
         assert ws.shape[1] == self.num_conv + self.num_torgb and ws.shape[2] == self.w_dim, ws.shape
         dev = img.device
         st = _lib.stream_ptr()
-        packed = self._buf("_packed", int(lib.r3d_sr_block_packed_bytes(N, Cin, Cout)), dev)
-        p = lambda t: _lib.ptr(_f32c(t))
         c0, c1, tr = self.conv0, self.conv1, self.torgb
         keep = [_f32c(t) for t in (c0.weight, c0.bias, c0.affine.weight, c0.affine.bias,
                                    c1.weight, c1.bias, c1.affine.weight, c1.affine.bias,
                                    tr.weight, tr.bias, tr.affine.weight, tr.affine.bias)]
-        _lib.check(lib.r3d_sr_block_pack(_lib.ptr(ws), N, self.w_dim, Cin, Cout, *[_lib.ptr(t) for t in keep],
-                                         _lib.ptr(packed), st), "sr_block_pack")
+        # static weight re-layout, redone only when the conv parameters change (in-place updates bump _version)
+        key = (keep[0].data_ptr(), c0.weight._version, keep[4].data_ptr(), c1.weight._version, str(dev))
+        if self._prepack_key != key:
+            pre = self._buf("_prepacked", int(lib.r3d_sr_block_prepacked_bytes(Cin, Cout)), dev)
+            _lib.check(lib.r3d_sr_block_prepack(Cin, Cout, _lib.ptr(keep[0]), _lib.ptr(keep[4]), _lib.ptr(pre), st),
+                       "sr_block_prepack")
+            self._prepack_key = key
+        pre = self._prepacked
+        styles = self._buf("_styles", int(lib.r3d_sr_block_styles_bytes(N, Cin, Cout)), dev)
+        _lib.check(lib.r3d_sr_block_styles(_lib.ptr(ws), N, self.w_dim, Cin, Cout, *[_lib.ptr(t) for t in keep],
+                                           _lib.ptr(styles), st), "sr_block_styles")
         need = int(lib.r3d_sr_block_workspace_bytes(N, Cin, Cout, Hin, Win))
         work = self._buf("_workspace", need, dev)
         OH, OW = 2 * Hin, 2 * Win
@@ -136,7 +145,7 @@ class SynthesisBlock(nn.Module):
         else:
             x_out = torch.empty(N, Cout, OH, OW, device=dev, dtype=torch.float32)
         clamp = -1.0 if self.conv_clamp is None else float(self.conv_clamp)
-        _lib.check(lib.r3d_sr_block_forward(_lib.ptr(packed), N, Cin, Cout, Hin, Win, _lib.ptr(x), int(blocked_in),
+        _lib.check(lib.r3d_sr_block_forward(_lib.ptr(pre), _lib.ptr(styles), N, Cin, Cout, Hin, Win, _lib.ptr(x), int(blocked_in),
                                             _lib.ptr(img), clamp, _lib.ptr(x_out), int(not self.blocked_output),
                                             _lib.ptr(img_out), _lib.ptr(work), need, st), "sr_block_forward")
         if self.blocked_output and x_out is not None:

@@ -1,0 +1,101 @@
+"""CPU: host-side logic of the operators (no kernels launched)."""
+import numpy as np
+import pytest
+import torch
+
+EXPECTED_SR_KEYS = {
+    "block0.resample_filter": (4, 4), "block0.conv0.weight": (256, 32, 3, 3), "block0.conv0.noise_strength": (),
+    "block0.conv0.bias": (256,), "block0.conv0.resample_filter": (4, 4), "block0.conv0.noise_const": (256, 256),
+    "block0.conv0.affine.weight": (32, 512), "block0.conv0.affine.bias": (32,),
+    "block0.conv1.weight": (256, 256, 3, 3), "block0.conv1.noise_strength": (), "block0.conv1.bias": (256,),
+    "block0.conv1.resample_filter": (4, 4), "block0.conv1.noise_const": (256, 256),
+    "block0.conv1.affine.weight": (256, 512), "block0.conv1.affine.bias": (256,),
+    "block0.torgb.weight": (3, 256, 1, 1), "block0.torgb.bias": (3,), "block0.torgb.affine.weight": (256, 512),
+    "block0.torgb.affine.bias": (256,),
+    "block1.resample_filter": (4, 4), "block1.conv0.weight": (128, 256, 3, 3), "block1.conv0.noise_strength": (),
+    "block1.conv0.bias": (128,), "block1.conv0.resample_filter": (4, 4), "block1.conv0.noise_const": (512, 512),
+    "block1.conv0.affine.weight": (256, 512), "block1.conv0.affine.bias": (256,),
+    "block1.conv1.weight": (128, 128, 3, 3), "block1.conv1.noise_strength": (), "block1.conv1.bias": (128,),
+    "block1.conv1.resample_filter": (4, 4), "block1.conv1.noise_const": (512, 512),
+    "block1.conv1.affine.weight": (128, 512), "block1.conv1.affine.bias": (128,),
+    "block1.torgb.weight": (3, 128, 1, 1), "block1.torgb.bias": (3,), "block1.torgb.affine.weight": (128, 512),
+    "block1.torgb.affine.bias": (128,),
+}
+
+
+def test_sr_state_dict_keys_match_reference():
+    """Key/shape list dumped from the reference's SuperresolutionHybrid8XDC: a reference
+    checkpoint must load strict=True."""
+    from real3dportrait_amd import SuperresolutionHybrid8XDC
+    sr = SuperresolutionHybrid8XDC(channels=32, img_resolution=512, sr_num_fp16_res=0, sr_antialias=True,
+                                   channel_base=32768, channel_max=512, fused_modconv_default="inference_only")
+    got = {k: tuple(v.shape) for k, v in sr.state_dict().items()}
+    assert got == EXPECTED_SR_KEYS
+    f = sr.block0.resample_filter
+    assert torch.allclose(f, torch.outer(torch.tensor([1., 3, 3, 1]), torch.tensor([1., 3, 3, 1])) / 64)
+
+
+def test_decoder_and_generator_keys():
+    from real3dportrait_amd import OSGDecoder, TriPlaneGenerator
+    dec = OSGDecoder(32, {"decoder_lr_mul": 1, "decoder_output_dim": 32})
+    assert {k: tuple(v.shape) for k, v in dec.state_dict().items()} == {
+        "net.0.weight": (64, 32), "net.0.bias": (64,), "net.2.weight": (33, 64), "net.2.bias": (33,)}
+    G = TriPlaneGenerator()
+    keys = set(G.state_dict().keys())
+    assert {"decoder.net.0.weight", "decoder.net.2.bias", "superresolution.block1.torgb.affine.weight"} <= keys
+    assert not any(k.startswith(("renderer.", "ray_sampler.")) for k in keys)      # parameter-free like upstream
+    assert G.rendering_kwargs["depth_resolution"] == 48 and G.rendering_kwargs["depth_resolution_importance"] == 48
+
+
+def test_operators_refuse_cpu_tensors_and_bad_options():
+    from real3dportrait_amd import ImportanceRenderer, RaySampler
+    with pytest.raises(AssertionError):
+        RaySampler()(torch.eye(4)[None], torch.eye(3)[None], 8)          # device tensors only, no CPU fallback
+    ren = ImportanceRenderer(hp={"triplane_feature_type": "trigrid_v2"})
+    with pytest.raises(NotImplementedError):
+        ren._check_options({"ray_start": "auto", "ray_end": "auto"})
+    ren = ImportanceRenderer(hp={})
+    with pytest.raises(NotImplementedError):
+        ren._check_options({"ray_start": 2.25, "ray_end": 3.3})
+    with pytest.raises(NotImplementedError):
+        ren._check_options({"ray_start": "auto", "ray_end": "auto", "disparity_space_sampling": True})
+    with pytest.raises(AssertionError):
+        ren._check_options({"ray_start": "auto", "ray_end": "auto", "clamp_mode": "relu"})
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from real3dportrait_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libr3d_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU/eager fallback"):
+        _lib.load()
+
+
+def test_synth_is_deterministic_and_sane():
+    from real3dportrait_amd import synth
+    a = synth.synth_planes(3, N=1, C=4, H=8, W=8)
+    b = synth.synth_planes(3, N=1, C=4, H=8, W=8)
+    assert np.array_equal(a, b) and a.dtype == np.float32
+    big = synth.hash_unitvar(1, (200000,))
+    assert abs(float(big.mean())) < 0.01 and abs(float(big.std()) - 1.0) < 0.01
+    u = synth.synth_noise(5, (1000,))
+    assert 0.0 <= float(u.min()) and float(u.max()) < 1.0
+    cam = synth.look_at_camera(0.3, -0.1)
+    c2w = cam[:16].reshape(4, 4)
+    Rm = c2w[:3, :3]
+    assert np.allclose(Rm.T @ Rm, np.eye(3), atol=1e-6) and abs(np.linalg.norm(c2w[:3, 3] - [0, 0, 0.2]) - 2.7) < 1e-5
+    # the camera looks at the pivot: forward axis points from origin to lookat
+    fwd = (np.array([0, 0, 0.2]) - c2w[:3, 3]); fwd /= np.linalg.norm(fwd)
+    assert np.allclose(Rm[:, 2], fwd, atol=1e-6)
+
+
+def test_frame_sharding_arithmetic():
+    from real3dportrait_amd.frames import frame_seed, shard_frames
+    for T, W in [(125, 8), (7, 8), (16, 4), (1, 2), (0, 3)]:
+        chunks = [shard_frames(T, W, r) for r in range(W)]
+        covered = [t for lo, hi in chunks for t in range(lo, hi)]
+        assert covered == list(range(T))
+        assert max(hi - lo for lo, hi in chunks) == (T + W - 1) // W if T else True
+    assert shard_frames(125, 8, 0) == (0, 16) and shard_frames(125, 8, 7) == (112, 125)
+    seeds = {frame_seed(7, t) for t in range(1000)}
+    assert len(seeds) == 1000 and frame_seed(7, 3) == frame_seed(7, 3) != frame_seed(8, 3)

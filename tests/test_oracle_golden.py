@@ -76,3 +76,36 @@ def test_edge_cases_run(oracle):
     u = synth.synth_noise(2, (64, 16))
     rgb, depth, wsum, v = oracle.render(planes, synth.synth_decoder(1), o, d, 16, 16, noise, u)
     assert np.isfinite(rgb).all() and np.isfinite(depth).all() and not v.any()
+
+
+def test_sr_full_matches_reference(oracle):
+    """SuperresolutionHybrid8XDC 128^2 -> 512^2, all-ones ws: the full-size SR golden (about 12 s of CPU)."""
+    from real3dportrait_amd import synth
+    g = load_golden("sr_full_a")
+    seed = int(g["seed"])
+    x = synth.hash_unitvar(seed, (1, 32, 128, 128), stream=1)[0]
+    out = oracle.superresolution(np.ascontiguousarray(x[:3]), x, synth.synth_sr_params(seed), np.ones((14, 512), np.float32))
+    tol = 2e-5 * max(1.0, np.abs(g["strided"]).max())
+    assert np.abs(out[None][:, :, ::4, ::4] - g["strided"]).max() <= tol
+    assert np.abs(out[None][:, :, :96, :96] - g["corner"]).max() <= tol
+    assert np.abs(out[None][:, :, -64:, -64:] - g["tail"]).max() <= tol
+
+
+def test_synthesis_matches_reference(oracle):
+    """TriPlaneGenerator.synthesis at the reference default (R=128, 48+48, SR -> 512^2) restated end to end
+    with the oracle pieces (raygen -> render -> image assembly -> SR -> clamp)."""
+    from real3dportrait_amd import synth
+    g = load_golden("synthesis_ref_a")
+    seed, R, Nc, Nf = int(g["seed"]), int(g["R"]), int(g["Nc"]), int(g["Nf"])
+    cam = g["cam"]
+    o, d = oracle.raygen(cam[:, :16], cam[:, 16:], R)
+    rgb, depth, wsum, valid = oracle.render(synth.synth_planes(seed, N=1), synth.synth_decoder(seed, sigma_bias=4.0), o, d, Nc, Nf,
+                                            synth.synth_noise(seed, (1, R * R, Nc, 1), stream=7),
+                                            synth.synth_noise(seed, (R * R, Nf), stream=8))
+    feat = np.ascontiguousarray(rgb[0].T.reshape(32, R, R))          # triplane.py:120-122
+    assert np.abs(np.clip(feat[:3], -1, 1) - g["image_raw"][0]).max() <= RGB_TOL
+    assert np.abs(depth[0].reshape(R, R) - g["image_depth"][0, 0]).max() <= DEPTH_TOL
+    img = oracle.superresolution(np.ascontiguousarray(feat[:3]), feat, synth.synth_sr_params(seed), np.ones((14, 512), np.float32))
+    img = np.clip(img, -1, 1)[None]
+    assert np.abs(img[:, :, ::4, ::4] - g["image_strided"]).max() <= 5e-4
+    assert np.abs(img[:, :, :96, :96] - g["image_corner"]).max() <= 5e-4
