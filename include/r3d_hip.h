@@ -108,12 +108,18 @@ int r3d_run_model(const float* planes_nhwc, int N, int H, int W,
  *   x [N,Cin,Hin,Win] NCHW or channel-blocked (see x_blocked), img [N,3,Hin,Win] NCHW
  *   -> x_out (channel-blocked [N,Cout/8,2Hin,2Win,8]; NCHW if x_out_nchw != 0; may be NULL), img_out [N,3,2Hin,2Win] NCHW.
  *   clamp < 0 disables conv_clamp (the fp32 configuration Real3D uses, img2plane_baseline.py:102-104).
- */
+ *
+ * precision: R3D_SR_F32   exact fp32 on v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain);
+ *            R3D_SR_F16X3 fp32-accurate on the f16 matrix pipe: every operand is split x = hi + lo (two fp16
+ *                         terms, 2^-24 relative) and hi*hi + hi*lo + lo*hi is accumulated in fp32 by
+ *                         v_mfma_f32_32x32x16_f16 (3 MFMAs at 16x the f32 rate; ~1e-7 relative per dot product).
+ *            The prepacked buffer is precision-specific (same size). */
+enum r3d_sr_precision { R3D_SR_F32 = 0, R3D_SR_F16X3 = 1 };
 size_t r3d_sr_block_prepacked_bytes(int Cin, int Cout);
 size_t r3d_sr_block_styles_bytes(int N, int Cin, int Cout);
 size_t r3d_sr_block_workspace_bytes(int N, int Cin, int Cout, int Hin, int Win);
 int r3d_sr_block_prepack(int Cin, int Cout, const float* c0_w, const float* c1_w, void* prepacked,
-                         r3d_stream_t stream);
+                         int precision, r3d_stream_t stream);
 int r3d_sr_block_styles(const float* ws3, int N, int WD, int Cin, int Cout,
                         const float* c0_w, const float* c0_b, const float* c0_aw, const float* c0_ab,
                         const float* c1_w, const float* c1_b, const float* c1_aw, const float* c1_ab,
@@ -121,7 +127,7 @@ int r3d_sr_block_styles(const float* ws3, int N, int WD, int Cin, int Cout,
                         void* styles, r3d_stream_t stream);
 int r3d_sr_block_forward(const void* prepacked, const void* styles, int N, int Cin, int Cout, int Hin, int Win,
                          const float* x, int x_blocked, const float* img, float clamp,
-                         float* x_out, int x_out_nchw, float* img_out,
+                         float* x_out, int x_out_nchw, float* img_out, int precision,
                          void* workspace, size_t workspace_bytes, r3d_stream_t stream);
 
 /* --- output side --------------------------------------------------------------------------------

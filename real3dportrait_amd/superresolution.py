@@ -9,6 +9,8 @@ Mirrors (same constructor arguments, state_dict keys/shapes, forward signatures)
 A checkpoint saved from the reference loads with strict=True (keys: block{0,1}.{conv0,conv1,torgb}.
 {weight,bias,affine.weight,affine.bias}, conv*.noise_strength, buffers noise_const / resample_filter).
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -88,6 +90,9 @@ class SynthesisBlock(nn.Module):
         self.conv_clamp = conv_clamp
         self.blocked_output = False
         self.return_x = True           # False: skip materialising x (last block of SuperresolutionHybrid8XDC)
+        # 'f16x3': fp32-accurate 3-term fp16 split on the f16 matrix pipe (default, ~5x faster);
+        # 'f32': exact fp32 MFMA.  Override per module or with R3D_SR_PRECISION.
+        self.precision = os.environ.get("R3D_SR_PRECISION", "f16x3")
         self._prepacked = None
         self._prepack_key = None
         self._styles = None
@@ -124,10 +129,11 @@ class SynthesisBlock(nn.Module):
                                    c1.weight, c1.bias, c1.affine.weight, c1.affine.bias,
                                    tr.weight, tr.bias, tr.affine.weight, tr.affine.bias)]
         # static weight re-layout, redone only when the conv parameters change (in-place updates bump _version)
-        key = (keep[0].data_ptr(), c0.weight._version, keep[4].data_ptr(), c1.weight._version, str(dev))
+        prec = {"f32": 0, "f16x3": 1}[self.precision]
+        key = (keep[0].data_ptr(), c0.weight._version, keep[4].data_ptr(), c1.weight._version, str(dev), prec)
         if self._prepack_key != key:
             pre = self._buf("_prepacked", int(lib.r3d_sr_block_prepacked_bytes(Cin, Cout)), dev)
-            _lib.check(lib.r3d_sr_block_prepack(Cin, Cout, _lib.ptr(keep[0]), _lib.ptr(keep[4]), _lib.ptr(pre), st),
+            _lib.check(lib.r3d_sr_block_prepack(Cin, Cout, _lib.ptr(keep[0]), _lib.ptr(keep[4]), _lib.ptr(pre), prec, st),
                        "sr_block_prepack")
             self._prepack_key = key
         pre = self._prepacked
@@ -147,7 +153,7 @@ class SynthesisBlock(nn.Module):
         clamp = -1.0 if self.conv_clamp is None else float(self.conv_clamp)
         _lib.check(lib.r3d_sr_block_forward(_lib.ptr(pre), _lib.ptr(styles), N, Cin, Cout, Hin, Win, _lib.ptr(x), int(blocked_in),
                                             _lib.ptr(img), clamp, _lib.ptr(x_out), int(not self.blocked_output),
-                                            _lib.ptr(img_out), _lib.ptr(work), need, st), "sr_block_forward")
+                                            _lib.ptr(img_out), prec, _lib.ptr(work), need, st), "sr_block_forward")
         if self.blocked_output and x_out is not None:
             x_out._r3d_cb8 = True
         return x_out, img_out

@@ -100,7 +100,8 @@ def load_block(torch, block, p):
             layer.affine.weight.copy_(T(torch, aw)); layer.affine.bias.copy_(T(torch, ab))
 
 
-def test_sr_blocks_golden(torch_cuda):
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_sr_blocks_golden(torch_cuda, precision):
     torch = torch_cuda
     from real3dportrait_amd import SynthesisBlock, synth
     g = load_golden("sr_small_a")
@@ -108,6 +109,7 @@ def test_sr_blocks_golden(torch_cuda):
     b0 = SynthesisBlock(32, 256, w_dim=512, resolution=32, img_channels=3, is_last=False, conv_clamp=None).cuda()
     b1 = SynthesisBlock(256, 128, w_dim=512, resolution=64, img_channels=3, is_last=True, conv_clamp=None).cuda()
     load_block(torch, b0, params[0]); load_block(torch, b1, params[1])
+    b0.precision = b1.precision = precision
     ws = T(torch, g["ws"])
     x0, r0 = b0(T(torch, g["x"]), T(torch, g["rgb"]), ws, noise_mode="none")
     x1, r1 = b1(x0, r0, ws, noise_mode="none")
@@ -115,7 +117,8 @@ def test_sr_blocks_golden(torch_cuda):
         assert np.abs(got.cpu().numpy() - ref).max() <= SR_TOL * max(1.0, np.abs(ref).max())
 
 
-def test_sr_full_golden(torch_cuda):
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_sr_full_golden(torch_cuda, precision):
     torch = torch_cuda
     from real3dportrait_amd import SuperresolutionHybrid8XDC, synth
     g = load_golden("sr_full_a")
@@ -123,6 +126,7 @@ def test_sr_full_golden(torch_cuda):
     params = synth.synth_sr_params(seed)
     sr = SuperresolutionHybrid8XDC(channels=32, img_resolution=512, sr_num_fp16_res=0, sr_antialias=True).cuda()
     load_block(torch, sr.block0, params[0]); load_block(torch, sr.block1, params[1])
+    sr.block0.precision = sr.block1.precision = precision
     x = T(torch, synth.hash_unitvar(seed, (1, 32, 128, 128), stream=1))
     out = sr(x[:, :3].contiguous(), x, torch.ones(1, 14, 512, device="cuda"), noise_mode="none").cpu().numpy()
     tol = SR_TOL * max(1.0, np.abs(g["strided"]).max())
@@ -130,6 +134,7 @@ def test_sr_full_golden(torch_cuda):
     assert np.abs(out[:, :, :96, :96] - g["corner"]).max() <= tol
     assert np.abs(out[:, :, -64:, -64:] - g["tail"]).max() <= tol
     assert abs(float(np.abs(out).mean()) - float(g["absmean"])) <= 1e-4
+    print("sr_full %s max err %.3e (max|ref| %.2f)" % (precision, np.abs(out[:, :, ::4, ::4] - g["strided"]).max(), np.abs(g["strided"]).max()))
 
 
 def test_synthesis_golden(torch_cuda):
