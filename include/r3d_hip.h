@@ -105,8 +105,13 @@ int r3d_run_model(const float* planes_nhwc, int N, int H, int W,
  *   ws3 [N,3,WD] (conv0, conv1, torgb);  *_w/_b/_aw/_ab = layer.weight / .bias / .affine.weight / .affine.bias;
  *   styles: r3d_sr_block_styles_bytes(N,Cin,Cout) bytes.
  * r3d_sr_block_forward:
- *   x [N,Cin,Hin,Win] NCHW or channel-blocked (see x_blocked), img [N,3,Hin,Win] NCHW
- *   -> x_out (channel-blocked [N,Cout/8,2Hin,2Win,8]; NCHW if x_out_nchw != 0; may be NULL), img_out [N,3,2Hin,2Win] NCHW.
+ *   x [N,Cin,Hin,Win] in x_format, img [N,3,Hin,Win] NCHW fp32
+ *   -> x_out in x_out_format (may be NULL / R3D_FMT_NONE), img_out [N,3,2Hin,2Win] NCHW fp32.
+ *   Activation formats: R3D_FMT_NCHW fp32 (the reference layout); R3D_FMT_CB8 fp32 channel-blocked [N,C/8,H,W,8];
+ *   R3D_FMT_SPLIT (f16x3 only): two fp16 planes [N][hi|lo][C/8][H][W][8] holding the activation ALREADY MULTIPLIED
+ *   by the consumer conv's style vector -- as input it must have been scaled with this block's conv0 styles; as
+ *   output it is scaled with `next_scale` ([N][Cout] floats, stride next_scale_stride: the next block's conv0 styles,
+ *   i.e. the start of that block's styles buffer).
  *   clamp < 0 disables conv_clamp (the fp32 configuration Real3D uses, img2plane_baseline.py:102-104).
  *
  * precision: R3D_SR_F32   exact fp32 on v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain);
@@ -115,6 +120,7 @@ int r3d_run_model(const float* planes_nhwc, int N, int H, int W,
  *                         v_mfma_f32_32x32x16_f16 (3 MFMAs at 16x the f32 rate; ~1e-7 relative per dot product).
  *            The prepacked buffer is precision-specific (same size). */
 enum r3d_sr_precision { R3D_SR_F32 = 0, R3D_SR_F16X3 = 1 };
+enum r3d_act_format { R3D_FMT_NONE = -1, R3D_FMT_NCHW = 0, R3D_FMT_CB8 = 1, R3D_FMT_SPLIT = 2 };
 size_t r3d_sr_block_prepacked_bytes(int Cin, int Cout);
 size_t r3d_sr_block_styles_bytes(int N, int Cin, int Cout);
 size_t r3d_sr_block_workspace_bytes(int N, int Cin, int Cout, int Hin, int Win);
@@ -126,8 +132,9 @@ int r3d_sr_block_styles(const float* ws3, int N, int WD, int Cin, int Cout,
                         const float* rgb_w, const float* rgb_b, const float* rgb_aw, const float* rgb_ab,
                         void* styles, r3d_stream_t stream);
 int r3d_sr_block_forward(const void* prepacked, const void* styles, int N, int Cin, int Cout, int Hin, int Win,
-                         const float* x, int x_blocked, const float* img, float clamp,
-                         float* x_out, int x_out_nchw, float* img_out, int precision,
+                         const void* x, int x_format, const float* img, float clamp,
+                         void* x_out, int x_out_format, const float* next_scale, size_t next_scale_stride,
+                         float* img_out, int precision,
                          void* workspace, size_t workspace_bytes, r3d_stream_t stream);
 
 /* --- output side --------------------------------------------------------------------------------

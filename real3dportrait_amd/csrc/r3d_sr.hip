@@ -17,16 +17,14 @@
 //  * the stride-2 transposed conv runs as 4 output phases with 4/2/2/1 taps (9 tap-GEMMs per 4 output
 //    pixels: no multiply-by-zero work), followed by a fused FIR4x4 + bias + lrelu kernel;
 //  * modulation/demodulation is a per-forward packing kernel (no host sync, any ws), not a grouped conv.
-#include "r3d_common.h"
+#include "r3d_sr_common.h"
 
 namespace r3d {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static constexpr int TILE_H = 8, TILE_W = 16;          // output pixels per block
 static constexpr int PATCH_H = TILE_H + 2, PATCH_W = TILE_W + 2, PATCH_PIX = PATCH_H * PATCH_W;   // 180
 static constexpr int CHUNKS_PER_STAGE = 4;             // 4 x 8 = 32 input channels per LDS stage
-static constexpr int BLOCK_M = 128;                    // output channels per block
 
 // -------------------------------------------------------------------------------------------------
 // layout kernels
@@ -67,24 +65,6 @@ __global__ void cb8_to_nchw_kernel(const float* __restrict__ src, float* __restr
 // the 3xC modulated toRGB weights and copies the biases (r3d_sr_block_styles).
 // styles buffer (floats, per batch item): see SrStyleLayout
 // -------------------------------------------------------------------------------------------------
-struct SrStyleLayout { size_t s0, s1, s2, d0, d1, wrgb, b0, b1, brgb, total; };
-static __host__ __device__ inline SrStyleLayout sr_style_layout(int Cin, int Cout)
-{
-    SrStyleLayout L;
-    size_t o = 0;
-    L.s0 = o; o += Cin;
-    L.s1 = o; o += Cout;
-    L.s2 = o; o += Cout;
-    L.d0 = o; o += Cout;
-    L.d1 = o; o += Cout;
-    L.wrgb = o; o += (size_t)3 * Cout;
-    L.b0 = o; o += Cout;
-    L.b1 = o; o += Cout;
-    L.brgb = o; o += 4;
-    L.total = (o + 3) & ~(size_t)3;
-    return L;
-}
-
 // static re-layout: prepacked = [conv0: 9][Cin/8][Cout][8] ++ [conv1: 9][Cout/8][Cout][8]; one thread per float4
 __global__ void sr_prepack_kernel(const float* __restrict__ w, int Ci, int Cout, float* __restrict__ out)
 {
@@ -161,12 +141,6 @@ __global__ void sr_style_misc_kernel(int Cin, int Cout, const float* __restrict_
 // -------------------------------------------------------------------------------------------------
 // implicit-GEMM conv on f32 MFMA.  A "phase" is a set of taps writing to a strided output lattice.
 // -------------------------------------------------------------------------------------------------
-struct ConvPhase {
-    int outH, outW;          // logical output extent (i in [0,outH), j in [0,outW))
-    int oy_mul, oy_add, ox_mul, ox_add;   // stored at (i*oy_mul+oy_add, j*ox_mul+ox_add)
-    int ntaps;
-    int dy[9], dx[9], widx[9];            // input pixel = (i+dy, j+dx); weight tap index
-};
 struct ConvArgs {
     const float* x;  size_t x_stride_n;       // CB8 input  [Cin/8][H][W][8]
     const float* wp;                          // static pre-packed weights [9][Cin/8][Cout][8]
@@ -305,176 +279,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs a)
 }
 
 // -------------------------------------------------------------------------------------------------
-// "f16x3": fp32-accurate convolution on the f16 matrix pipe.  Every fp32 operand is split into two
-// fp16 terms (x = hi + lo, |x - hi - lo| <= 2^-24 |x|; probe: scripts/probes/mfma_f16_probe.hip) and the
-// product is evaluated as hi*hi + hi*lo + lo*hi with fp32 accumulation inside
-// v_mfma_f32_32x32x16_f16: 3 MFMAs at 16x the f32-MFMA rate = 5.3x the exact-f32 kernel, with a relative
-// error of ~1e-7 per dot product (same class as fp32 rounding; subnormal lo terms are not flushed).
-// Weights are split ONCE at prepack time ([tap][ci/8][cout][8 hi | 8 lo] halfs = same 32 B per
-// (tap, chunk, cout) as the f32 layout); activations stay fp32 in HBM and are scaled by the style,
-// split and written as separate hi / lo planes when the halo patch is staged into LDS.
-// Block = 128 couts x (16x16) pixels, 4 waves of 64 couts x 128 pixels (2x4 MFMA tiles, 128 accumulators).
-// -------------------------------------------------------------------------------------------------
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-static constexpr int F_TILE_H = 16, F_TILE_W = 16;
-static constexpr int F_PATCH_H = F_TILE_H + 2, F_PATCH_W = F_TILE_W + 2, F_PATCH_PIX = F_PATCH_H * F_PATCH_W;   // 324
-static constexpr int F_CHUNKS = 4;         // 32 input channels per LDS stage (two K=16 MFMA steps per tap)
-
-__global__ void sr_prepack_f16_kernel(const float* __restrict__ w, int Ci, int Cout, uint4* __restrict__ out)
-{
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // (tap, chunk, cout)
-    const size_t total = (size_t)9 * (Ci / 8) * Cout;
-    if (e >= total) return;
-    const int co = e % Cout;
-    const int chunk = (e / Cout) % (Ci / 8);
-    const int tap = (int)(e / Cout / (Ci / 8));
-    const float* src = w + ((size_t)co * Ci + chunk * 8) * 9 + tap;
-    h8 hi, lo;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float v = src[9 * j];
-        const _Float16 a = (_Float16)v;
-        hi[j] = a; lo[j] = (_Float16)(v - (float)a);
-    }
-    out[2 * e] = *reinterpret_cast<uint4*>(&hi);
-    out[2 * e + 1] = *reinterpret_cast<uint4*>(&lo);
-}
-
-template <int NTAPS>
-__device__ __forceinline__ void conv_block_f16x3(const ConvArgs& a, const ConvPhase& ph, int n, uint4* patch_hi, uint4* patch_lo)
-{
-    const int tiles_x = (ph.outW + F_TILE_W - 1) / F_TILE_W;
-    const int tile = blockIdx.x;
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const int i0 = ty * F_TILE_H, j0 = tx * F_TILE_W;
-    const int m0 = blockIdx.y * BLOCK_M;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;          // wave tile: couts [m0+64wm, +64), rows [8wn, 8wn+8)
-    const int li = lane & 31, h = lane >> 5;
-    const int nchunks = a.Cin >> 3;
-    const float* X = a.x + (size_t)n * a.x_stride_n;
-    const uint4* WP = reinterpret_cast<const uint4*>(a.wp);
-    const float4* SC = reinterpret_cast<const float4*>(a.in_scale + (size_t)n * a.vec_stride_n);
-
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
-
-    int boff[4];                                   // patch pixel index of this lane's pixel per N-tile
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int row = wn * 8 + nt * 2 + (li >> 4), col = li & 15;
-        boff[nt] = (row + 1) * F_PATCH_W + (col + 1);
-    }
-
-    for (int c0 = 0; c0 < nchunks; c0 += F_CHUNKS) {
-        const int nc = min(F_CHUNKS, nchunks - c0);
-        __syncthreads();
-        // ---- stage: x * style -> (hi, lo) fp16 planes; zero outside the image ---------------------------------
-        for (int e = threadIdx.x; e < nc * F_PATCH_PIX; e += blockDim.x) {
-            const int pp = e % F_PATCH_PIX, c = e / F_PATCH_PIX;
-            const int py = pp / F_PATCH_W, px = pp - py * F_PATCH_W;
-            const int iy = i0 + py - 1, ix = j0 + px - 1;
-            h8 hi, lo;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { hi[j] = (_Float16)0.f; lo[j] = (_Float16)0.f; }
-            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-                const float4* src = reinterpret_cast<const float4*>(X + (((size_t)(c0 + c) * a.H + iy) * a.W + ix) * 8);
-                const float4 u = src[0], v = src[1];
-                const float4 s0 = SC[(c0 + c) * 2], s1 = SC[(c0 + c) * 2 + 1];
-                const float f[8] = {u.x * s0.x, u.y * s0.y, u.z * s0.z, u.w * s0.w, v.x * s1.x, v.y * s1.y, v.z * s1.z, v.w * s1.w};
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float cl = fminf(fmaxf(f[j], -65504.f), 65504.f);
-                    const _Float16 t = (_Float16)cl;
-                    hi[j] = t; lo[j] = (_Float16)(f[j] - (float)t);
-                }
-            }
-            patch_hi[c * F_PATCH_PIX + pp] = *reinterpret_cast<uint4*>(&hi);
-            patch_lo[c * F_PATCH_PIX + pp] = *reinterpret_cast<uint4*>(&lo);
-        }
-        __syncthreads();
-        for (int cp = 0; cp < nc; cp += 2) {          // K = 16 input channels = chunks (cp, cp+1): lane half h picks the chunk
-            const int cb = min(cp + h, nc - 1);       // odd chunk count: the upper half re-reads the last chunk with zero weights
-            const bool dead = (cp + h) >= nc;
-#pragma unroll
-            for (int t = 0; t < NTAPS; ++t) {
-                h8 ah[2], al[2];
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const size_t wi = (((size_t)ph.widx[t] * nchunks + (c0 + cb)) * a.Cout + (m0 + 64 * wm + 32 * mt + li)) * 2;
-                    uint4 q0 = WP[wi], q1 = WP[wi + 1];
-                    if (dead) { q0 = make_uint4(0, 0, 0, 0); q1 = q0; }
-                    ah[mt] = *reinterpret_cast<h8*>(&q0); al[mt] = *reinterpret_cast<h8*>(&q1);
-                }
-                const int toff = ph.dy[t] * F_PATCH_W + ph.dx[t];
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    uint4 r0 = patch_hi[cb * F_PATCH_PIX + boff[nt] + toff];
-                    uint4 r1 = patch_lo[cb * F_PATCH_PIX + boff[nt] + toff];
-                    const h8 bh = *reinterpret_cast<h8*>(&r0), bl = *reinterpret_cast<h8*>(&r1);
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
-                    }
-                }
-            }
-        }
-    }
-
-    float* Y = a.y + (size_t)n * a.y_stride_n;
-    const float* B = a.bias ? a.bias + (size_t)n * a.vec_stride_n : nullptr;
-    const float* D = a.out_scale + (size_t)n * a.vec_stride_n;
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int i = i0 + wn * 8 + nt * 2 + (li >> 4), j = j0 + (li & 15);
-        if (i >= ph.outH || j >= ph.outW) continue;
-        const int oy = i * ph.oy_mul + ph.oy_add, ox = j * ph.ox_mul + ph.ox_add;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = m0 + 64 * wm + 32 * mt + 8 * g + 4 * h;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float t = acc[mt][nt][4 * g + r] * D[co + r];
-                    if (a.act) {
-                        t += B[co + r];
-                        t = (t < 0.f ? t * 0.2f : t) * 1.4142135623730951f;
-                        if (a.clamp >= 0.f) t = fminf(fmaxf(t, -a.clamp), a.clamp);
-                    }
-                    v[r] = t;
-                }
-                *reinterpret_cast<float4*>(Y + ((((size_t)(co >> 3)) * a.OH + oy) * a.OW + ox) * 8 + (co & 7)) =
-                    make_float4(v[0], v[1], v[2], v[3]);
-            }
-    }
-}
-
-__global__ __launch_bounds__(256, 2) void conv_mfma_f16x3_kernel(ConvArgs a)
-{
-    __shared__ uint4 patch_hi[F_CHUNKS * F_PATCH_PIX];
-    __shared__ uint4 patch_lo[F_CHUNKS * F_PATCH_PIX];
-    const int n = blockIdx.z / a.nphase, p = blockIdx.z - n * a.nphase;
-    const ConvPhase& ph = a.ph[p];
-    const int tiles = ((ph.outW + F_TILE_W - 1) / F_TILE_W) * ((ph.outH + F_TILE_H - 1) / F_TILE_H);
-    if ((int)blockIdx.x >= tiles) return;
-    switch (ph.ntaps) {
-        case 9: conv_block_f16x3<9>(a, ph, n, patch_hi, patch_lo); break;
-        case 4: conv_block_f16x3<4>(a, ph, n, patch_hi, patch_lo); break;
-        case 2: conv_block_f16x3<2>(a, ph, n, patch_hi, patch_lo); break;
-        default: conv_block_f16x3<1>(a, ph, n, patch_hi, patch_lo); break;
-    }
-}
-
-// -------------------------------------------------------------------------------------------------
 // FIR 4x4 (outer([1,3,3,1])/64 * gain 4, pad 1) + bias + lrelu*sqrt(2)  on the transposed-conv output
 // T [C/8][2H+1][2W+1][8] -> y [C/8][2H][2W][8]      (conv2d_resample.py:130, upfirdn2d.py:171-215)
 // One thread: one output pixel x 4 channels.
@@ -576,7 +380,6 @@ __global__ void torgb_upsample_kernel(const float* __restrict__ x, size_t x_stri
     }
 }
 
-static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
 
 }  // namespace r3d
 
@@ -598,8 +401,35 @@ extern "C" size_t r3d_sr_block_workspace_bytes(int N, int Cin, int Cout, int Hin
     const size_t T = align256((size_t)N * Cout * (2 * Hin + 1) * (2 * Win + 1) * 4);
     const size_t y0 = align256((size_t)N * Cout * 4 * Hin * Win * 4);
     const size_t xo = align256((size_t)N * Cout * 4 * Hin * Win * 4);
-    return xin + T + y0 + xo;
+    const size_t rgbp = align256((size_t)N * (Cout / BLOCK_M) * 3 * 4 * Hin * Win * 4);
+    return xin + T + y0 + xo + rgbp;
 }
+
+namespace r3d {
+// T[2i+pa][2j+pb] = sum_{ky = pa (mod 2), kx = pb (mod 2)} x[i - ky/2][j - kx/2] w[ky][kx]   (conv_transpose2d stride 2)
+void sr_fill_tconv_phases(ConvPhase* ph, int Hin, int Win)
+{
+    for (int pa = 0; pa < 2; ++pa)
+        for (int pb = 0; pb < 2; ++pb) {
+            ConvPhase& p = ph[pa * 2 + pb];
+            p.outH = Hin + (pa == 0); p.outW = Win + (pb == 0);
+            p.oy_mul = 2; p.oy_add = pa; p.ox_mul = 2; p.ox_add = pb;
+            p.ntaps = 0;
+            for (int ky = pa; ky < 3; ky += 2)
+                for (int kx = pb; kx < 3; kx += 2) {
+                    p.dy[p.ntaps] = -(ky >> 1); p.dx[p.ntaps] = -(kx >> 1); p.widx[p.ntaps] = ky * 3 + kx;
+                    ++p.ntaps;
+                }
+        }
+}
+void sr_fill_conv3x3_phase(ConvPhase* ph, int H, int W)
+{
+    ConvPhase& p = ph[0];
+    p.outH = H; p.outW = W; p.oy_mul = 1; p.oy_add = 0; p.ox_mul = 1; p.ox_add = 0; p.ntaps = 9;
+    for (int ky = 0; ky < 3; ++ky)
+        for (int kx = 0; kx < 3; ++kx) { p.dy[ky * 3 + kx] = ky - 1; p.dx[ky * 3 + kx] = kx - 1; p.widx[ky * 3 + kx] = ky * 3 + kx; }
+}
+}  // namespace r3d
 
 static int sr_check_dims(const char* what, int Cin, int Cout)
 {
@@ -619,14 +449,7 @@ extern "C" int r3d_sr_block_prepack(int Cin, int Cout, const float* c0_w, const 
     hipStream_t st = (hipStream_t)stream;
     float* out = reinterpret_cast<float*>(prepacked);
     ProfScope ps(R3D_PROF_PACK, st);
-    if (precision == R3D_SR_F16X3) {
-        const size_t m0 = (size_t)9 * (Cin / 8) * Cout, m1 = (size_t)9 * (Cout / 8) * Cout;
-        hipLaunchKernelGGL(sr_prepack_f16_kernel, dim3((unsigned)((m0 + 255) / 256)), dim3(256), 0, st, c0_w, Cin, Cout,
-                           reinterpret_cast<uint4*>(out));
-        hipLaunchKernelGGL(sr_prepack_f16_kernel, dim3((unsigned)((m1 + 255) / 256)), dim3(256), 0, st, c1_w, Cout, Cout,
-                           reinterpret_cast<uint4*>(out + (size_t)9 * Cin * Cout));
-        return check_launch("sr_block_prepack");
-    }
+    if (precision == R3D_SR_F16X3) return sr_prepack_f16x3(Cin, Cout, c0_w, c1_w, prepacked, st);
     const size_t n0 = (size_t)9 * (Cin / 8) * Cout * 2, n1 = (size_t)9 * (Cout / 8) * Cout * 2;
     hipLaunchKernelGGL(sr_prepack_kernel, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, st, c0_w, Cin, Cout, out);
     hipLaunchKernelGGL(sr_prepack_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, c1_w, Cout, Cout,
@@ -656,20 +479,31 @@ extern "C" int r3d_sr_block_styles(const float* ws3, int N, int WD, int Cin, int
 }
 
 extern "C" int r3d_sr_block_forward(const void* prepacked, const void* styles, int N, int Cin, int Cout, int Hin, int Win,
-                                    const float* x, int x_blocked, const float* img, float clamp,
-                                    float* x_out, int x_out_nchw, float* img_out, int precision,
+                                    const void* x, int x_format, const float* img, float clamp,
+                                    void* x_out, int x_out_format, const float* next_scale, size_t next_scale_stride,
+                                    float* img_out, int precision,
                                     void* workspace, size_t workspace_bytes, r3d_stream_t stream)
 {
     if (precision != R3D_SR_F32 && precision != R3D_SR_F16X3) { set_error("sr_block_forward: unknown precision %d", precision); return R3D_ERR_INVALID_ARG; }
-    const bool f16 = precision == R3D_SR_F16X3;
-    const int TH_ = f16 ? F_TILE_H : TILE_H, TW_ = f16 ? F_TILE_W : TILE_W;
     if (!prepacked || !styles || !x || !img || !img_out || N <= 0 || Hin <= 0 || Win <= 0 || (Cin & 7) || (Cout % BLOCK_M)) {
         set_error("sr_block_forward: bad argument"); return R3D_ERR_INVALID_ARG;
     }
     if (!workspace || workspace_bytes < r3d_sr_block_workspace_bytes(N, Cin, Cout, Hin, Win)) {
         set_error("sr_block_forward: workspace too small"); return R3D_ERR_WORKSPACE;
     }
+    if (!x_out) x_out_format = R3D_FMT_NONE;
+    const bool f16 = precision == R3D_SR_F16X3;
+    if (x_format < R3D_FMT_NCHW || x_format > R3D_FMT_SPLIT || x_out_format < R3D_FMT_NONE || x_out_format > R3D_FMT_SPLIT ||
+        (!f16 && (x_format == R3D_FMT_SPLIT || x_out_format == R3D_FMT_SPLIT)) ||
+        (x_out_format == R3D_FMT_SPLIT && !next_scale)) {
+        set_error("sr_block_forward: unsupported activation format (x %d, x_out %d, precision %d)", x_format, x_out_format, precision);
+        return R3D_ERR_INVALID_ARG;
+    }
     hipStream_t st = (hipStream_t)stream;
+    if (f16)
+        return sr_block_forward_f16x3(prepacked, styles, N, Cin, Cout, Hin, Win, x, x_format, img, clamp, x_out, x_out_format,
+                                      next_scale, next_scale_stride, img_out, workspace, workspace_bytes, st);
+
     const SrStyleLayout L = sr_style_layout(Cin, Cout);
     const float* pk = reinterpret_cast<const float*>(styles);
     const float* wpk = reinterpret_cast<const float*>(prepacked);
@@ -680,10 +514,10 @@ extern "C" int r3d_sr_block_forward(const void* prepacked, const void* styles, i
     float* y0 = reinterpret_cast<float*>(wsb);  wsb += align256((size_t)N * Cout * OH * OW * 4);
     float* xo = reinterpret_cast<float*>(wsb);
 
-    const float* xcb = x;
-    if (!x_blocked) {
+    const float* xcb = reinterpret_cast<const float*>(x);
+    if (x_format == R3D_FMT_NCHW) {
         ProfScope ps(R3D_PROF_LAYOUT, st);
-        hipLaunchKernelGGL(nchw_to_cb8_kernel, dim3((Hin * Win + 255) / 256, Cin / 8, N), dim3(256), 0, st, x, xin, Cin, Hin * Win);
+        hipLaunchKernelGGL(nchw_to_cb8_kernel, dim3((Hin * Win + 255) / 256, Cin / 8, N), dim3(256), 0, st, xcb, xin, Cin, Hin * Win);
         xcb = xin;
     }
     // ---- conv0: transposed conv stride 2 as 4 phases -> T ------------------------------------------------
@@ -695,25 +529,14 @@ extern "C" int r3d_sr_block_forward(const void* prepacked, const void* styles, i
         a.y = T; a.y_stride_n = (size_t)Cout * TH * TW;
         a.Cin = Cin; a.Cout = Cout; a.H = Hin; a.W = Win; a.OH = TH; a.OW = TW;
         a.nphase = 4; a.act = 0; a.clamp = -1.f;
+        sr_fill_tconv_phases(a.ph, Hin, Win);
         int maxtiles = 0;
-        for (int pa = 0; pa < 2; ++pa)
-            for (int pb = 0; pb < 2; ++pb) {
-                ConvPhase& p = a.ph[pa * 2 + pb];
-                p.outH = Hin + (pa == 0); p.outW = Win + (pb == 0);
-                p.oy_mul = 2; p.oy_add = pa; p.ox_mul = 2; p.ox_add = pb;
-                p.ntaps = 0;
-                // T[2i+pa][2j+pb] = sum_{ky = pa (mod 2), kx = pb (mod 2)} x[i - ky/2][j - kx/2] w[ky][kx]
-                for (int ky = pa; ky < 3; ky += 2)
-                    for (int kx = pb; kx < 3; kx += 2) {
-                        p.dy[p.ntaps] = -(ky >> 1); p.dx[p.ntaps] = -(kx >> 1); p.widx[p.ntaps] = ky * 3 + kx;
-                        ++p.ntaps;
-                    }
-                const int tiles = ((p.outW + TW_ - 1) / TW_) * ((p.outH + TH_ - 1) / TH_);
-                if (tiles > maxtiles) maxtiles = tiles;
-            }
+        for (int p = 0; p < 4; ++p) {
+            const int tiles = ((a.ph[p].outW + TILE_W - 1) / TILE_W) * ((a.ph[p].outH + TILE_H - 1) / TILE_H);
+            if (tiles > maxtiles) maxtiles = tiles;
+        }
         ProfScope ps(R3D_PROF_CONV, st);
-        if (f16) hipLaunchKernelGGL(conv_mfma_f16x3_kernel, dim3(maxtiles, Cout / BLOCK_M, N * 4), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(conv_mfma_kernel, dim3(maxtiles, Cout / BLOCK_M, N * 4), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(conv_mfma_kernel, dim3(maxtiles, Cout / BLOCK_M, N * 4), dim3(256), 0, st, a);
     }
     {
     ProfScope ps(R3D_PROF_FIR, st);
@@ -721,7 +544,7 @@ extern "C" int r3d_sr_block_forward(const void* prepacked, const void* styles, i
                        T, (size_t)Cout * TH * TW, pk + L.b0, L.total, y0, (size_t)Cout * OH * OW, Cout, OH, OW, clamp);
     }
     // ---- conv1: 3x3 pad 1 --------------------------------------------------------------------------------
-    float* xo_cb = (x_out && !x_out_nchw) ? x_out : xo;
+    float* xo_cb = (x_out_format == R3D_FMT_CB8) ? reinterpret_cast<float*>(x_out) : xo;
     {
         ConvArgs a;
         a.x = y0; a.x_stride_n = (size_t)Cout * OH * OW;
@@ -730,14 +553,10 @@ extern "C" int r3d_sr_block_forward(const void* prepacked, const void* styles, i
         a.y = xo_cb; a.y_stride_n = (size_t)Cout * OH * OW;
         a.Cin = Cout; a.Cout = Cout; a.H = OH; a.W = OW; a.OH = OH; a.OW = OW;
         a.nphase = 1; a.act = 1; a.clamp = clamp;
-        ConvPhase& p = a.ph[0];
-        p.outH = OH; p.outW = OW; p.oy_mul = 1; p.oy_add = 0; p.ox_mul = 1; p.ox_add = 0; p.ntaps = 9;
-        for (int ky = 0; ky < 3; ++ky)
-            for (int kx = 0; kx < 3; ++kx) { p.dy[ky * 3 + kx] = ky - 1; p.dx[ky * 3 + kx] = kx - 1; p.widx[ky * 3 + kx] = ky * 3 + kx; }
-        const int tiles = ((OW + TW_ - 1) / TW_) * ((OH + TH_ - 1) / TH_);
+        sr_fill_conv3x3_phase(a.ph, OH, OW);
+        const int tiles = ((OW + TILE_W - 1) / TILE_W) * ((OH + TILE_H - 1) / TILE_H);
         ProfScope ps(R3D_PROF_CONV, st);
-        if (f16) hipLaunchKernelGGL(conv_mfma_f16x3_kernel, dim3(tiles, Cout / BLOCK_M, N), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(conv_mfma_kernel, dim3(tiles, Cout / BLOCK_M, N), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(conv_mfma_kernel, dim3(tiles, Cout / BLOCK_M, N), dim3(256), 0, st, a);
     }
     // ---- toRGB + skip upsample ---------------------------------------------------------------------------
     {
@@ -745,9 +564,10 @@ extern "C" int r3d_sr_block_forward(const void* prepacked, const void* styles, i
     hipLaunchKernelGGL(torgb_upsample_kernel, dim3((OH * OW + 255) / 256, N), dim3(256), 3 * Cout * sizeof(float), st,
                        xo_cb, (size_t)Cout * OH * OW, pk + L.wrgb, pk + L.brgb, L.total, img, img_out, Cout, OH, OW, clamp);
     }
-    if (x_out && x_out_nchw) {
+    if (x_out_format == R3D_FMT_NCHW) {
         ProfScope ps(R3D_PROF_LAYOUT, st);
-        hipLaunchKernelGGL(cb8_to_nchw_kernel, dim3((OH * OW + 255) / 256, Cout / 8, N), dim3(256), 0, st, xo_cb, x_out, Cout, OH * OW);
+        hipLaunchKernelGGL(cb8_to_nchw_kernel, dim3((OH * OW + 255) / 256, Cout / 8, N), dim3(256), 0, st, xo_cb,
+                           reinterpret_cast<float*>(x_out), Cout, OH * OW);
     }
     return check_launch("sr_block_forward");
 }

@@ -88,7 +88,7 @@ class SynthesisBlock(nn.Module):
                                     conv_clamp=conv_clamp, **layer_kwargs)
         self.torgb = ToRGBLayer(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp)
         self.conv_clamp = conv_clamp
-        self.blocked_output = False
+        self.out_format = "nchw"       # 'nchw' (reference layout) | 'cb8' | 'split' (f16x3 hand-off, needs _next)
         self.return_x = True           # False: skip materialising x (last block of SuperresolutionHybrid8XDC)
         # 'f16x3': fp32-accurate 3-term fp16 split on the f16 matrix pipe (default, ~5x faster);
         # 'f32': exact fp32 MFMA.  Override per module or with R3D_SR_PRECISION.
@@ -105,30 +105,23 @@ class SynthesisBlock(nn.Module):
             setattr(self, name, t)
         return t
 
-    def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, noise_mode="random",
-                **layer_kwargs):
+    _FMT = {"none": -1, "nchw": 0, "cb8": 1, "split": 2}
+
+    def prepare(self, ws, dev=None):
+        """Static weight re-layout (cached on parameter versions) + per-forward style/demodulation vectors for
+        `ws` [N,3,w_dim].  Returns (prepacked, styles) device buffers; styles starts with the conv0 style vector
+        (what a producer needs to emit this block's input in SPLIT format)."""
         lib = _lib.load()
-        if noise_mode == "random" or (noise_mode == "const" and
-                                      (float(self.conv0.noise_strength) != 0 or float(self.conv1.noise_strength) != 0)):
-            raise NotImplementedError("noise_mode=%r: the inference path uses 'none' "
-                                      "(img2plane_baseline.py:113)" % noise_mode)
-        if img is None:
-            raise NotImplementedError("img=None (first block of a synthesis network) is not on the SR path")
-        blocked_in = bool(getattr(x, "_r3d_cb8", False))
-        x = _f32c(x)
-        img = _f32c(img)
         ws = _f32c(ws)
-        N = img.shape[0]
-        Hin, Win = img.shape[-2], img.shape[-1]
+        N = ws.shape[0]
+        dev = ws.device if dev is None else dev
         Cin, Cout = self.in_channels, self.out_channels
         assert ws.shape[1] == self.num_conv + self.num_torgb and ws.shape[2] == self.w_dim, ws.shape
-        dev = img.device
         st = _lib.stream_ptr()
         c0, c1, tr = self.conv0, self.conv1, self.torgb
         keep = [_f32c(t) for t in (c0.weight, c0.bias, c0.affine.weight, c0.affine.bias,
                                    c1.weight, c1.bias, c1.affine.weight, c1.affine.bias,
                                    tr.weight, tr.bias, tr.affine.weight, tr.affine.bias)]
-        # static weight re-layout, redone only when the conv parameters change (in-place updates bump _version)
         prec = {"f32": 0, "f16x3": 1}[self.precision]
         key = (keep[0].data_ptr(), c0.weight._version, keep[4].data_ptr(), c1.weight._version, str(dev), prec)
         if self._prepack_key != key:
@@ -136,26 +129,56 @@ class SynthesisBlock(nn.Module):
             _lib.check(lib.r3d_sr_block_prepack(Cin, Cout, _lib.ptr(keep[0]), _lib.ptr(keep[4]), _lib.ptr(pre), prec, st),
                        "sr_block_prepack")
             self._prepack_key = key
-        pre = self._prepacked
         styles = self._buf("_styles", int(lib.r3d_sr_block_styles_bytes(N, Cin, Cout)), dev)
         _lib.check(lib.r3d_sr_block_styles(_lib.ptr(ws), N, self.w_dim, Cin, Cout, *[_lib.ptr(t) for t in keep],
                                            _lib.ptr(styles), st), "sr_block_styles")
+        return self._prepacked, styles
+
+    def styles_stride(self):
+        return int(_lib.load().r3d_sr_block_styles_bytes(1, self.in_channels, self.out_channels)) // 4
+
+    def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, noise_mode="random",
+                _prepared=None, _next=None, **layer_kwargs):
+        lib = _lib.load()
+        if noise_mode == "random" or (noise_mode == "const" and
+                                      (float(self.conv0.noise_strength) != 0 or float(self.conv1.noise_strength) != 0)):
+            raise NotImplementedError("noise_mode=%r: the inference path uses 'none' "
+                                      "(img2plane_baseline.py:113)" % noise_mode)
+        if img is None:
+            raise NotImplementedError("img=None (first block of a synthesis network) is not on the SR path")
+        x_fmt = getattr(x, "_r3d_fmt", "nchw")
+        x = x.contiguous() if x_fmt == "split" else _f32c(x)
+        img = _f32c(img)
+        N = img.shape[0]
+        Hin, Win = img.shape[-2], img.shape[-1]
+        Cin, Cout = self.in_channels, self.out_channels
+        dev = img.device
+        st = _lib.stream_ptr()
+        prec = {"f32": 0, "f16x3": 1}[self.precision]
+        pre, styles = _prepared if _prepared is not None else self.prepare(ws, dev)
         need = int(lib.r3d_sr_block_workspace_bytes(N, Cin, Cout, Hin, Win))
         work = self._buf("_workspace", need, dev)
         OH, OW = 2 * Hin, 2 * Win
         img_out = torch.empty(N, 3, OH, OW, device=dev, dtype=torch.float32)
-        if not self.return_x:
+        out_fmt = self.out_format if self.return_x else "none"
+        next_scale, next_stride = None, 0
+        if out_fmt == "none":
             x_out = None
-        elif self.blocked_output:
+        elif out_fmt == "split":
+            assert _next is not None, "out_format='split' needs the consumer's styles (scaled hand-off)"
+            next_scale, next_stride = _next
+            x_out = torch.empty(N, 2, Cout // 8, OH, OW, 8, device=dev, dtype=torch.float16)
+        elif out_fmt == "cb8":
             x_out = torch.empty(N, Cout // 8, OH, OW, 8, device=dev, dtype=torch.float32)
         else:
             x_out = torch.empty(N, Cout, OH, OW, device=dev, dtype=torch.float32)
         clamp = -1.0 if self.conv_clamp is None else float(self.conv_clamp)
-        _lib.check(lib.r3d_sr_block_forward(_lib.ptr(pre), _lib.ptr(styles), N, Cin, Cout, Hin, Win, _lib.ptr(x), int(blocked_in),
-                                            _lib.ptr(img), clamp, _lib.ptr(x_out), int(not self.blocked_output),
-                                            _lib.ptr(img_out), prec, _lib.ptr(work), need, st), "sr_block_forward")
-        if self.blocked_output and x_out is not None:
-            x_out._r3d_cb8 = True
+        _lib.check(lib.r3d_sr_block_forward(_lib.ptr(pre), _lib.ptr(styles), N, Cin, Cout, Hin, Win, _lib.ptr(x),
+                                            self._FMT[x_fmt], _lib.ptr(img), clamp, _lib.ptr(x_out), self._FMT[out_fmt],
+                                            _lib.ptr(next_scale), next_stride, _lib.ptr(img_out), prec,
+                                            _lib.ptr(work), need, st), "sr_block_forward")
+        if x_out is not None and out_fmt != "nchw":
+            x_out._r3d_fmt = out_fmt
         return x_out, img_out
 
 
@@ -176,7 +199,6 @@ class SuperresolutionHybrid8XDC(nn.Module):
                                      use_fp16=False, conv_clamp=None, **block_kwargs)
         self.block1 = SynthesisBlock(256, 128, w_dim=512, resolution=512, img_channels=3, is_last=True,
                                      use_fp16=False, conv_clamp=None, **block_kwargs)
-        self.block0.blocked_output = True      # block0 -> block1 hand-off stays channel-blocked
         self.block1.return_x = False           # forward() only returns rgb (:359)
 
     def forward(self, rgb, x, ws, **block_kwargs):
@@ -186,6 +208,15 @@ class SuperresolutionHybrid8XDC(nn.Module):
                               align_corners=False, antialias=self.sr_antialias)
             rgb = F.interpolate(rgb, size=(self.input_resolution, self.input_resolution), mode="bilinear",
                                 align_corners=False, antialias=self.sr_antialias)
-        x, rgb = self.block0(x, rgb, ws, **block_kwargs)
-        x, rgb = self.block1(x, rgb, ws, **block_kwargs)
+        # block1's style vectors first: block0's conv1 epilogue emits its output already scaled by block1.conv0's
+        # styles and split into fp16 hi/lo planes (f16x3), so block1 stages its input with plain copies
+        self.block1.precision = self.block0.precision
+        prep1 = self.block1.prepare(ws)
+        if self.block0.precision == "f16x3":
+            self.block0.out_format = "split"
+            nxt = (prep1[1].view(torch.float32), self.block1.styles_stride())
+        else:
+            self.block0.out_format, nxt = "cb8", None
+        x, rgb = self.block0(x, rgb, ws, _next=nxt, **block_kwargs)
+        x, rgb = self.block1(x, rgb, ws, _prepared=prep1, **block_kwargs)
         return rgb

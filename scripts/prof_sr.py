@@ -1,0 +1,18 @@
+"""Run only SuperresolutionHybrid8XDC (128^2 -> 512^2) a few times -- target for rocprofv3 passes."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from real3dportrait_amd import SuperresolutionHybrid8XDC, synth
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+sr = SuperresolutionHybrid8XDC(channels=32, img_resolution=512, sr_num_fp16_res=0, sr_antialias=True).cuda()
+with torch.no_grad():
+    for blk, p in zip((sr.block0, sr.block1), synth.synth_sr_params(7)):
+        for name in ("conv0", "conv1", "torgb"):
+            l = getattr(blk, name); w, b, aw, ab = p[name]
+            l.weight.copy_(T(w)); l.bias.copy_(T(b)); l.affine.weight.copy_(T(aw)); l.affine.bias.copy_(T(ab))
+x = T(synth.hash_unitvar(7, (1, 32, 128, 128), stream=1)); rgb = x[:, :3].contiguous(); ws = torch.ones(1, 14, 512, device="cuda")
+for _ in range(2): sr(rgb, x, ws, noise_mode="none")
+torch.cuda.synchronize(); t = time.perf_counter()
+for _ in range(reps): sr(rgb, x, ws, noise_mode="none")
+torch.cuda.synchronize(); print("SR 128->512: %.3f ms" % ((time.perf_counter() - t) / reps * 1e3))

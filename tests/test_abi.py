@@ -46,8 +46,11 @@ def test_argument_errors_are_reported_not_thrown():
     rc = lib.r3d_render_forward(one, 1, 32, 32, one, one, one, one, one, one, 256, 48, 48, 1.0, 0, None, None, 0,
                                 one, one, one, one, one, 8, None)
     assert rc == -2 and b"workspace" in lib.r3d_last_error()
-    rc = lib.r3d_sr_block_prepack(30, 256, one, one, one, None)
+    rc = lib.r3d_sr_block_prepack(30, 256, one, one, one, 1, None)
     assert rc == -1 and b"multiple of 8" in lib.r3d_last_error()
+    rc2 = lib.r3d_sr_block_forward(one, one, 1, 32, 256, 16, 16, one, 2, one, -1.0, None, -1, None, 0, one, 0, one, 1 << 40, None)
+    assert rc2 == -1 and b"format" in lib.r3d_last_error()      # SPLIT input needs the f16x3 precision
+    rc = lib.r3d_sr_block_prepack(30, 256, one, one, one, 1, None)
     try:
         _lib.check(rc, "prepack")
         assert False
