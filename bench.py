@@ -26,6 +26,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_F16_MFMA_TFLOPS = 2500.0         # dense f16/bf16 MFMA peak (same guide)
 PEAK_HBM_TBPS = 8.0
 
 # algorithmic conv FLOPs of one frame: 2*taps*Cin*Cout*pixels for the four conv launches
@@ -168,14 +169,22 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("conv_mfma_kernel_bytes_per_launch")
+            traffic = json.load(open(tpath)).get("conv_bytes_per_launch_" + os.environ.get("R3D_SR_PRECISION", "f16x3"))
         except Exception:
             traffic = None
-    roofline = {"kernel": "conv_mfma_kernel", "bound": "mfma", "achieved": round(achieved_tf, 2),
-                "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved_tf / PEAK_F32_MFMA_TFLOPS, 4),
+    prec = os.environ.get("R3D_SR_PRECISION", "f16x3")
+    if prec == "f32":       # exact fp32 on v_mfma_f32_32x32x2_f32
+        kname, peak, products = "conv_mfma_kernel", PEAK_F32_MFMA_TFLOPS, 1
+    else:                   # fp32-accurate 3-term fp16 split on v_mfma_f32_32x32x16_f16: 3 MFMA products per algorithmic MAC
+        kname, peak, products = "conv_mfma_f16x3_kernel + tconv_mfma_f16x3_kernel", PEAK_F16_MFMA_TFLOPS, 3
+    roofline = {"kernel": kname, "bound": "mfma", "achieved": round(achieved_tf, 2),
+                "peak": peak, "unit": "TFLOP/s", "frac": round(achieved_tf / peak, 4),
                 "traffic": traffic, "launches_per_frame": 4,
                 "avg_launch_ms": round(ms.value / max(1, cnt.value), 4),
-                "algorithmic_gflop_per_launch": round(sum(flops) / 4 / 1e9, 3)}
+                "algorithmic_gflop_per_launch": round(sum(flops) / 4 / 1e9, 3),
+                "mfma_products_per_mac": products,
+                "executed_tflops": round(achieved_tf * products, 1), "pipe_frac": round(achieved_tf * products / peak, 4),
+                "precision": prec}
 
     out = None
     if rank == 0:

@@ -398,7 +398,7 @@ extern "C" size_t r3d_sr_block_styles_bytes(int N, int Cin, int Cout)
 extern "C" size_t r3d_sr_block_workspace_bytes(int N, int Cin, int Cout, int Hin, int Win)
 {
     const size_t xin = align256((size_t)N * Cin * Hin * Win * 4);
-    const size_t T = align256((size_t)N * Cout * (2 * Hin + 1) * (2 * Win + 1) * 4);
+    const size_t T = align256((size_t)N * Cout * 4 * (Hin + 1) * (Win + 1) * 4);
     const size_t y0 = align256((size_t)N * Cout * 4 * Hin * Win * 4);
     const size_t xo = align256((size_t)N * Cout * 4 * Hin * Win * 4);
     const size_t rgbp = align256((size_t)N * (Cout / BLOCK_M) * 3 * 4 * Hin * Win * 4);
@@ -413,7 +413,7 @@ void sr_fill_tconv_phases(ConvPhase* ph, int Hin, int Win)
         for (int pb = 0; pb < 2; ++pb) {
             ConvPhase& p = ph[pa * 2 + pb];
             p.outH = Hin + (pa == 0); p.outW = Win + (pb == 0);
-            p.oy_mul = 2; p.oy_add = pa; p.ox_mul = 2; p.ox_add = pb;
+            p.oy_mul = 2; p.oy_add = pa; p.ox_mul = 2; p.ox_add = pb; p.out_off = 0;
             p.ntaps = 0;
             for (int ky = pa; ky < 3; ky += 2)
                 for (int kx = pb; kx < 3; kx += 2) {
@@ -425,7 +425,7 @@ void sr_fill_tconv_phases(ConvPhase* ph, int Hin, int Win)
 void sr_fill_conv3x3_phase(ConvPhase* ph, int H, int W)
 {
     ConvPhase& p = ph[0];
-    p.outH = H; p.outW = W; p.oy_mul = 1; p.oy_add = 0; p.ox_mul = 1; p.ox_add = 0; p.ntaps = 9;
+    p.outH = H; p.outW = W; p.oy_mul = 1; p.oy_add = 0; p.ox_mul = 1; p.ox_add = 0; p.ntaps = 9; p.out_off = 0;
     for (int ky = 0; ky < 3; ++ky)
         for (int kx = 0; kx < 3; ++kx) { p.dy[ky * 3 + kx] = ky - 1; p.dx[ky * 3 + kx] = kx - 1; p.widx[ky * 3 + kx] = ky * 3 + kx; }
 }
@@ -510,7 +510,7 @@ extern "C" int r3d_sr_block_forward(const void* prepacked, const void* styles, i
     const int OH = 2 * Hin, OW = 2 * Win, TH = OH + 1, TW = OW + 1;
     char* wsb = reinterpret_cast<char*>(workspace);
     float* xin = reinterpret_cast<float*>(wsb); wsb += align256((size_t)N * Cin * Hin * Win * 4);
-    float* T = reinterpret_cast<float*>(wsb);   wsb += align256((size_t)N * Cout * TH * TW * 4);
+    float* T = reinterpret_cast<float*>(wsb);   wsb += align256((size_t)N * Cout * 4 * (Hin + 1) * (Win + 1) * 4);
     float* y0 = reinterpret_cast<float*>(wsb);  wsb += align256((size_t)N * Cout * OH * OW * 4);
     float* xo = reinterpret_cast<float*>(wsb);
 

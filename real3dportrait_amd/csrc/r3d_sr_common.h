@@ -34,6 +34,7 @@ struct ConvPhase {
     int oy_mul, oy_add, ox_mul, ox_add;   // stored at (i*oy_mul+oy_add, j*ox_mul+ox_add)
     int ntaps;
     int dy[9], dx[9], widx[9];            // input pixel = (i+dy, j+dx); weight tap index
+    size_t out_off;                       // float offset of this phase's output plane (phase-major T layout), else 0
 };
 
 void sr_fill_tconv_phases(ConvPhase* ph, int Hin, int Win);

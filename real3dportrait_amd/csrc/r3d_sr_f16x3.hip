@@ -17,6 +17,8 @@
 // Block = 128 couts x (16x16) pixels, 4 waves of 64 couts x 128 pixels (2x4 MFMA tiles, 128 accumulators).
 // Behaviour restated from modules/eg3ds/models/networks_stylegan2.py:37-94,286-373,429-473 and
 // modules/eg3ds/torch_utils/ops/{conv2d_resample.py:116-133, upfirdn2d.py:171-215,317-354, bias_act.py:93-122}.
+#include <stdlib.h>
+
 #include "r3d_sr_common.h"
 
 namespace r3d {
@@ -90,128 +92,185 @@ struct Conv2Args {
     ConvPhase ph[4];
 };
 
-template <int NTAPS, int CPS, bool FULL_EPI>   // CPS = chunk pairs (K=16 MFMA steps) staged per barrier; FULL_EPI: act/split/toRGB epilogue
-__device__ __forceinline__ void conv2_block(const Conv2Args& a, const ConvPhase& ph, int n, uint4* patch /* [2][2*CPS][324] */)
+// One block: 128 couts x 16x16 pixels, WN x 2 waves; wave (wm, wn) owns couts [64wm, +64) and pixel rows
+// [2*NT*wn, +2*NT) as 2 x NT MFMA tiles (WN=2,NT=4: 4 waves x 128 accumulators; WN=4,NT=2: 8 waves x 64 accumulators
+// = 4 waves/SIMD at 2 blocks/CU).  Per stage = 16 input channels (two 8-channel blocks = one K=16 MFMA step per tap):
+// the halo patch (B operand, hi+lo) sits in LDS for all taps of the stage; the weights (A operand) go through LDS in
+// sub-stages of SUB taps.  All global loads are register-prefetched one (sub-)stage ahead, and the weight loads are
+// issued BEFORE the patch loads, so the compiler's counted s_waitcnt vmcnt(N) at the weight ds_write leaves the slow
+// (MALL/HBM) patch loads in flight under the MFMAs.
+template <int NTAPS, bool FULL_EPI, int WN, int NT>
+__device__ __forceinline__ void conv2_block(const Conv2Args& a, const ConvPhase& ph, int n, uint4* lds)
 {
-    constexpr int NCH = 2 * CPS;                              // channel blocks per stage
-    constexpr int STAGE_ELEMS = 2 * NCH * F_PATCH_PIX;         // uint4 per stage (hi + lo)
-    constexpr int NPF = (STAGE_ELEMS + 255) / 256;
+    static_assert(WN * NT == 8, "16 pixel rows per block");
+    constexpr int NTHR = 128 * WN;
+    constexpr int SUB = NTAPS >= 9 ? 3 : (NTAPS >= 2 ? 2 : 1);        // taps per weight sub-stage
+    constexpr int NSUB = (NTAPS + SUB - 1) / SUB;                     // sub-stages per stage
+    constexpr int B_ELEMS = 2 * 2 * F_PATCH_PIX;                      // uint4: planes x chunks x pixels = 1296
+    constexpr int NPF = (B_ELEMS + NTHR - 1) / NTHR;
+    constexpr int A_ELEMS = SUB * 2 * 256;                            // uint4 per sub-stage: (tap, half-chunk) x (cout, hi|lo)
+    constexpr int A_BUF = 3 * 2 * 256;                                // uint4 per weight buffer (sized for SUB = 3)
+    constexpr int NAR = A_ELEMS / NTHR;
+    uint4* patchB = lds;                                              // [plane][chunk][324]
+    uint4* bufA = lds + B_ELEMS;                                      // 2 x [SUB][2][128 couts][hi|lo], filled by LDS-DMA
     const int tiles_x = (ph.outW + F_TILE_W - 1) / F_TILE_W;
     const int tile = blockIdx.x;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int i0 = ty * F_TILE_H, j0 = tx * F_TILE_W;
     const int m0 = blockIdx.y * BLOCK_M;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave - wm * WN;
     const int li = lane & 31, h = lane >> 5;
     const int nchunks = a.Cin >> 3;
     const size_t plane = (size_t)nchunks * a.H * a.W;
     const uint4* X = a.x + (size_t)n * a.x_stride_n;
     const uint4* WP = a.wp;
 
-    f32x16 acc[2][4];
+    f32x16 acc[2][NT];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    // N-tile pixel of this lane: rows (2nt, 2nt+1) of the wave's 8 rows; the odd row's columns are rotated by 2 so
+    // N-tile pixel of this lane: rows (2nt, 2nt+1) of the wave's rows; the odd row's columns are rotated by 2 so
     // that each ds_read_b128 lane group covers 16 distinct 16-byte LDS slots with the 18-pixel patch row stride
     const int prow = li >> 4, pcol = ((li & 15) - 2 * prow) & 15;
-    int boff[4];
+    const int row0 = wn * 2 * NT;
+    int boff[NT];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) boff[nt] = (wn * 8 + nt * 2 + prow + 1) * F_PATCH_W + (pcol + 1);
+    for (int nt = 0; nt < NT; ++nt) boff[nt] = (row0 + nt * 2 + prow + 1) * F_PATCH_W + (pcol + 1) + h * F_PATCH_PIX;
+    const int aoff = (h * 128 + 64 * wm + li) * 2;                    // + ts*512 + mt*64
 
-    // staging: element e = tid + 256k  ->  (plane, chunk, patch pixel); recomputed per stage to keep VGPRs for the MFMAs
     const int chunk_stride = a.H * a.W;
     uint4 pf[NPF];
-    auto prefetch = [&](int c0) {
+    unsigned pf_off[NPF];                                             // per-thread patch element -> offset within a 2-chunk slab
+    unsigned pf_valid = 0;                                            // bit k: element k is inside the image (else zero fill)
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) {
+        const int e = threadIdx.x + NTHR * k;
+        unsigned off = 0;
+        if (e < B_ELEMS) {
+            const int pl = e / (2 * F_PATCH_PIX);
+            const int rem = e - pl * (2 * F_PATCH_PIX);
+            const int c = rem / F_PATCH_PIX, pp = rem - c * F_PATCH_PIX;
+            const int py = pp / F_PATCH_W, px = pp - py * F_PATCH_W;
+            const int iy = i0 + py - 1, ix = j0 + px - 1;
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+                off = (unsigned)(pl * plane) + (unsigned)(c * chunk_stride + iy * a.W + ix);
+                pf_valid |= 1u << k;
+            }
+        }
+        pf_off[k] = off;
+    }
+    auto load_patch = [&](int c0) {                                   // global -> registers (written to LDS one stage later)
+        const uint4* Xs = X + (size_t)c0 * chunk_stride;              // wave-uniform base + 32-bit per-lane offset
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
-            const int e = threadIdx.x + 256 * k;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (e < STAGE_ELEMS) {
-                const int pl = e / (NCH * F_PATCH_PIX);
-                const int rem = e - pl * (NCH * F_PATCH_PIX);
-                const int c = rem / F_PATCH_PIX, pp = rem - c * F_PATCH_PIX;
-                const int py = pp / F_PATCH_W, px = pp - py * F_PATCH_W;
-                const int iy = i0 + py - 1, ix = j0 + px - 1;
-                if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c0 + c < nchunks)
-                    v = X[(size_t)pl * plane + (size_t)(c0 + c) * chunk_stride + iy * a.W + ix];
-            }
+            // always issue exactly NPF loads (the counted s_waitcnt vmcnt(NPF) below relies on it); halo -> zero
+            uint4 v = Xs[pf_off[k]];
+            if (!(pf_valid & (1u << k))) v = make_uint4(0, 0, 0, 0);
             pf[k] = v;
         }
     };
-    auto load_a = [&](int tapw, int cbase, h8 (&ah)[2], h8 (&al)[2]) {
-        const int cb = cbase + h;
-        const bool dead = cb >= nchunks;
+    // weights: global -> LDS by DMA (global_load_lds_dwordx4: LDS address = wave-uniform base + lane*16; the
+    // sub-stage image is linear in e = tid + NTHR*k, so a wave's 64 lanes fill one contiguous KB); no VGPRs, no ds_write
+    const int tid_hi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);       // 0 for 256-thread blocks
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const unsigned tid_lo = threadIdx.x & 255;
+    auto dma_weights = [&](int c0, int sub, uint4* dstA) {
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const size_t wi = (((size_t)tapw * nchunks + (dead ? 0 : cb)) * a.Cout + (m0 + 64 * wm + 32 * mt + li)) * 2;
-            uint4 q0 = WP[wi], q1 = WP[wi + 1];
-            if (dead) { q0 = make_uint4(0, 0, 0, 0); q1 = q0; }
-            ah[mt] = *reinterpret_cast<h8*>(&q0); al[mt] = *reinterpret_cast<h8*>(&q1);
+        for (int k = 0; k < NAR; ++k) {
+            const int pair = (NTHR >> 8) * k + tid_hi, t = sub * SUB + (pair >> 1), hc = pair & 1;     // wave-uniform
+            if (t < NTAPS) {
+                const uint4* src = WP + (((size_t)ph.widx[t] * nchunks + (c0 + hc)) * a.Cout + m0) * 2;      // uniform
+                // inline asm: hipcc would otherwise put s_waitcnt vmcnt(0) in front of every ds_read while an LDS-DMA it
+                // knows about is in flight (no alias info inside one LDS array); waits for these DMAs are the explicit
+                // counted s_waitcnt vmcnt below (cdna_hip_programming.md section 5.7)
+                const unsigned lds_dst = __builtin_amdgcn_readfirstlane(
+                    (unsigned)(size_t)(__attribute__((address_space(3))) uint4*)(dstA + NTHR * k + 64 * wave_u));
+                const uint4* gsrc = src + tid_lo;
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+            }
         }
     };
 
-    prefetch(0);
-    h8 ah[2], al[2];
-    load_a(ph.widx[0], 0, ah, al);
-    const uint4* patch_hi = patch;
-    const uint4* patch_lo = patch + NCH * F_PATCH_PIX;
-    for (int c0 = 0; c0 < nchunks; c0 += NCH) {
-        __syncthreads();                                   // everyone is done reading the previous stage
+    int g = 0;                                                        // global sub-stage counter (weight buffer parity)
+    dma_weights(0, 0, bufA);
+    load_patch(0);
+    for (int c0 = 0; c0 < nchunks; c0 += 2) {
 #pragma unroll
-        for (int k = 0; k < NPF; ++k) {
-            const int e = threadIdx.x + 256 * k;
-            if (e < STAGE_ELEMS) patch[e] = pf[k];
-        }
-        __syncthreads();
-        if (c0 + NCH < nchunks) prefetch(c0 + NCH);        // next stage's loads fly under this stage's MFMAs
+        for (int sub = 0; sub < NSUB; ++sub, ++g) {
+            if (sub == 0) {
+                __syncthreads();                                       // previous stage's patch reads are done
 #pragma unroll
-        for (int cp = 0; cp < CPS; ++cp) {
-#pragma unroll
-            for (int t = 0; t < NTAPS; ++t) {
-                // A operands one (tap, chunk-pair) ahead
-                h8 nh[2], nl[2];
-                {
-                    int nt_ = t + 1, ncp = cp, nc0 = c0;
-                    if (nt_ == NTAPS) { nt_ = 0; ++ncp; if (ncp == CPS) { ncp = 0; nc0 += NCH; } }
-                    if (nc0 < nchunks) load_a(ph.widx[nt_], nc0 + 2 * ncp, nh, nl);
-                    else { nh[0] = ah[0]; nh[1] = ah[1]; nl[0] = al[0]; nl[1] = al[1]; }
+                for (int k = 0; k < NPF; ++k) {
+                    const int e = threadIdx.x + NTHR * k;
+                    if (e < B_ELEMS) patchB[e] = pf[k];
                 }
-                const int toff = ph.dy[t] * F_PATCH_W + ph.dx[t] + (2 * cp + h) * F_PATCH_PIX;
+            }
+            // weights of this sub-stage have landed (own DMAs) -> barrier -> everybody's have
+            // (the NPF patch loads of the next stage were issued AFTER these DMAs during sub-stage 0: leave them in flight)
+            if (NSUB > 1 && sub == 1 && c0 + 2 < nchunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPF) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const uint4* curA = bufA + (g & 1) * A_BUF;
+            uint4* nxtA = bufA + ((g + 1) & 1) * A_BUF;
+            // next weights first, then (once per stage) the next patch: in-order vmcnt lets the weights be waited for
+            // while the slow patch loads are still in flight
+            {
+            if (sub + 1 < NSUB) dma_weights(c0, sub + 1, nxtA);
+            else if (c0 + 2 < nchunks) dma_weights(c0 + 2, 0, nxtA);
+            if (sub == 0 && c0 + 2 < nchunks) load_patch(c0 + 2);
+            }
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt) {
-                    uint4 r0 = patch_hi[boff[nt] + toff];
-                    uint4 r1 = patch_lo[boff[nt] + toff];
-                    const h8 bh = *reinterpret_cast<h8*>(&r0), bl = *reinterpret_cast<h8*>(&r1);
+            for (int ts = 0; ts < SUB; ++ts) {
+                const int t = sub * SUB + ts;
+                if (t < NTAPS) {
+                    h8 ah[2], al[2];
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
+                        uint4 q0 = curA[ts * 512 + aoff + mt * 64], q1 = curA[ts * 512 + aoff + mt * 64 + 1];
+                        ah[mt] = *reinterpret_cast<h8*>(&q0); al[mt] = *reinterpret_cast<h8*>(&q1);
+                    }
+                    const int toff = ph.dy[t] * F_PATCH_W + ph.dx[t];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        uint4 r0 = patchB[boff[nt] + toff];
+                        uint4 r1 = patchB[boff[nt] + toff + 2 * F_PATCH_PIX];
+                        const h8 bh = *reinterpret_cast<h8*>(&r0), bl = *reinterpret_cast<h8*>(&r1);
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
+                        }
                     }
                 }
-                ah[0] = nh[0]; ah[1] = nh[1]; al[0] = nl[0]; al[1] = nl[1];
             }
         }
     }
+    __syncthreads();
+    uint4* patch = lds;      // LDS is reused by the epilogue's toRGB reduction
 
     // ---- epilogue ------------------------------------------------------------------------------------------------
     const float* B = a.bias ? a.bias + (size_t)n * a.vec_stride_n : nullptr;
     const float* D = a.out_scale + (size_t)n * a.vec_stride_n;
     const float* NS = a.next_scale ? a.next_scale + (size_t)n * a.next_scale_stride_n : nullptr;
     const bool do_rgb = FULL_EPI && a.rgb_partial != nullptr;
-    float rgbp[4][3];
+    float rgbp[NT][3];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) { rgbp[nt][0] = 0.f; rgbp[nt][1] = 0.f; rgbp[nt][2] = 0.f; }
+    for (int nt = 0; nt < NT; ++nt) { rgbp[nt][0] = 0.f; rgbp[nt][1] = 0.f; rgbp[nt][2] = 0.f; }
     const size_t oplane = (size_t)(a.Cout >> 3) * a.OH * a.OW;
+    float* Yf = a.y_f32 ? a.y_f32 + (size_t)n * a.y_f32_stride_n + ph.out_off : nullptr;
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const int i = i0 + wn * 8 + nt * 2 + prow, j = j0 + pcol;
+    for (int nt = 0; nt < NT; ++nt) {
+        const int i = i0 + row0 + nt * 2 + prow, j = j0 + pcol;
         const bool inside = i < ph.outH && j < ph.outW;
         const int oy = i * ph.oy_mul + ph.oy_add, ox = j * ph.ox_mul + ph.ox_add;
 #pragma unroll
@@ -219,12 +278,16 @@ __device__ __forceinline__ void conv2_block(const Conv2Args& a, const ConvPhase&
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int co = m0 + 64 * wm + 32 * mt + 8 * g + 4 * h;
+                const float4 d4 = *reinterpret_cast<const float4*>(D + co);
+                const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
+                float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (FULL_EPI && a.act) { const float4 b4 = *reinterpret_cast<const float4*>(B + co); bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w; }
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float t = acc[mt][nt][4 * g + r] * D[co + r];
+                    float t = acc[mt][nt][4 * g + r] * dv[r];
                     if (FULL_EPI && a.act) {
-                        t += B[co + r];
+                        t += bv[r];
                         t = (t < 0.f ? t * 0.2f : t) * 1.4142135623730951f;
                         if (a.clamp >= 0.f) t = fminf(fmaxf(t, -a.clamp), a.clamp);
                     }
@@ -240,12 +303,13 @@ __device__ __forceinline__ void conv2_block(const Conv2Args& a, const ConvPhase&
                 }
                 if (!inside) continue;
                 const size_t pix = ((size_t)(co >> 3) * a.OH + oy) * a.OW + ox;
-                if (a.y_f32)
-                    *reinterpret_cast<float4*>(a.y_f32 + (size_t)n * a.y_f32_stride_n + pix * 8 + (co & 7)) = make_float4(v[0], v[1], v[2], v[3]);
+                if (Yf) *reinterpret_cast<float4*>(Yf + pix * 8 + (co & 7)) = make_float4(v[0], v[1], v[2], v[3]);
                 if (FULL_EPI && a.y_split) {
+                    const float4 s4 = *reinterpret_cast<const float4*>(NS + co);
+                    const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
                     h4 hi, lo;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { _Float16 x0, x1; split1(v[r] * NS[co + r], x0, x1); hi[r] = x0; lo[r] = x1; }
+                    for (int r = 0; r < 4; ++r) { _Float16 x0, x1; split1(v[r] * sv[r], x0, x1); hi[r] = x0; lo[r] = x1; }
                     uint2* dst = reinterpret_cast<uint2*>(a.y_split + (size_t)n * a.y_split_stride_n + pix) + ((co & 7) >> 2);
                     dst[0] = *reinterpret_cast<uint2*>(&hi);
                     dst[2 * oplane] = *reinterpret_cast<uint2*>(&lo);
@@ -256,101 +320,130 @@ __device__ __forceinline__ void conv2_block(const Conv2Args& a, const ConvPhase&
         // reduce the two lane halves (disjoint couts), then the two cout-waves through LDS (reusing the patch)
         float* red = reinterpret_cast<float*>(patch);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int o = 0; o < 3; ++o) rgbp[nt][o] += __shfl_xor(rgbp[nt][o], 32);
         __syncthreads();
         if (wm == 1 && h == 0) {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int o = 0; o < 3; ++o) red[((wn * 4 + nt) * 3 + o) * 32 + li] = rgbp[nt][o];
+                for (int o = 0; o < 3; ++o) red[((wn * NT + nt) * 3 + o) * 32 + li] = rgbp[nt][o];
         }
         __syncthreads();
         if (wm == 0 && h == 0) {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                const int i = i0 + wn * 8 + nt * 2 + prow, j = j0 + pcol;
+            for (int nt = 0; nt < NT; ++nt) {
+                const int i = i0 + row0 + nt * 2 + prow, j = j0 + pcol;
                 if (i < ph.outH && j < ph.outW) {
                     const int oy = i * ph.oy_mul + ph.oy_add, ox = j * ph.ox_mul + ph.ox_add;
 #pragma unroll
                     for (int o = 0; o < 3; ++o)
                         a.rgb_partial[(size_t)n * a.rgbp_stride_n + ((size_t)blockIdx.y * 3 + o) * a.OH * a.OW + (size_t)oy * a.OW + ox] =
-                            rgbp[nt][o] + red[((wn * 4 + nt) * 3 + o) * 32 + li];
+                            rgbp[nt][o] + red[((wn * NT + nt) * 3 + o) * 32 + li];
                 }
             }
         }
     }
 }
 
-// plain 3x3 conv: 9 taps, 16 input channels per barrier
-__global__ __launch_bounds__(256, 2) void conv_mfma_f16x3_kernel(Conv2Args a)
+static constexpr int F_LDS_UINT4 = 2 * 2 * F_PATCH_PIX + 2 * 3 * 2 * 256;      // patch (20.7 KB) + 2 x 3-tap weight sub-stage (2 x 24.6 KB)
+
+// plain 3x3 conv (9 taps)
+template <int WN, int NT, int OCC>
+__global__ __launch_bounds__(128 * WN, OCC) void conv_mfma_f16x3_kernel(Conv2Args a)
 {
-    __shared__ uint4 patch[2 * 2 * 1 * F_PATCH_PIX];
-    const int n = blockIdx.z;
-    conv2_block<9, 1, true>(a, a.ph[0], n, patch);
+    __shared__ uint4 lds[F_LDS_UINT4];
+    conv2_block<9, true, WN, NT>(a, a.ph[0], blockIdx.z, lds);
 }
 
 // stride-2 transposed conv phases (4/2/2/1 taps)
-__global__ __launch_bounds__(256, 2) void tconv_mfma_f16x3_kernel(Conv2Args a)
+template <int WN, int NT, int OCC>
+__global__ __launch_bounds__(128 * WN, OCC) void tconv_mfma_f16x3_kernel(Conv2Args a)
 {
-    __shared__ uint4 patch[2 * 2 * 1 * F_PATCH_PIX];
+    __shared__ uint4 lds[F_LDS_UINT4];
     const int n = blockIdx.z / a.nphase, p = blockIdx.z - n * a.nphase;
     const ConvPhase& ph = a.ph[p];
     const int tiles = ((ph.outW + F_TILE_W - 1) / F_TILE_W) * ((ph.outH + F_TILE_H - 1) / F_TILE_H);
     if ((int)blockIdx.x >= tiles) return;
     switch (ph.ntaps) {
-        case 4: conv2_block<4, 1, false>(a, ph, n, patch); break;
-        case 2: conv2_block<2, 1, false>(a, ph, n, patch); break;
-        default: conv2_block<1, 1, false>(a, ph, n, patch); break;
+        case 4: conv2_block<4, false, WN, NT>(a, ph, n, lds); break;
+        case 2: conv2_block<2, false, WN, NT>(a, ph, n, lds); break;
+        default: conv2_block<1, false, WN, NT>(a, ph, n, lds); break;
     }
 }
 
 // ---- FIR 4x4 (gain 4, pad 1) + bias + lrelu*sqrt2 on the transposed-conv output; writes SPLIT scaled by the next
-// conv's styles.  T fp32 [C/8][2H+1][2W+1][8] -> SPLIT [C/8][2H][2W].  One thread: one output pixel x 8 channels.
+// conv's styles.  T is PHASE-MAJOR: T[p=(r&1)*2+(c&1)][C/8][Hin+1][Win+1][8] holds row r, col c of the (2Hin+1)x(2Win+1)
+// transposed-conv result (the conv epilogue's stores are then contiguous).  One thread = a 2x2 output quad x 8
+// channels from the 5x5 T window rows 2Y-1..2Y+3, cols 2X-1..2X+3 (25 loads for 4 outputs instead of 64).
 __global__ void fir_bias_act_split_kernel(const float* __restrict__ T, size_t t_stride_n, const float* __restrict__ bias,
                                           const float* __restrict__ next_scale, size_t vec_stride_n,
-                                          uint4* __restrict__ y, size_t y_stride_n, int C, int OH, int OW, float clamp)
+                                          uint4* __restrict__ y, size_t y_stride_n, int C, int Hin, int Win, float clamp)
 {
     const int n = blockIdx.z, cb = blockIdx.y;
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= OH * OW) return;
-    const int oy = p / OW, ox = p - oy * OW;
-    const int TH = OH + 1, TW = OW + 1;
-    const float* Tn = T + (size_t)n * t_stride_n + (size_t)cb * TH * TW * 8;
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= Hin * Win) return;
+    const int Y = q / Win, X = q - Y * Win;
+    const int PH = Hin + 1, PW = Win + 1, OH = 2 * Hin, OW = 2 * Win;
+    const size_t pplane = (size_t)(C / 8) * PH * PW * 8;
+    const float* Tn = T + (size_t)n * t_stride_n + (size_t)cb * PH * PW * 8;
     const float f1[4] = {0.25f, 0.75f, 0.75f, 0.25f};
-    float acc[8];
+    float acc[2][2][8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    for (int a_ = 0; a_ < 2; ++a_)
 #pragma unroll
-    for (int aa = 0; aa < 4; ++aa) {
-        const int ty = oy + aa - 1;
-        if (ty < 0 || ty >= TH) continue;
+        for (int b_ = 0; b_ < 2; ++b_)
 #pragma unroll
-        for (int bb = 0; bb < 4; ++bb) {
-            const int tx = ox + bb - 1;
-            if (tx < 0 || tx >= TW) continue;
-            const float4* s4 = reinterpret_cast<const float4*>(Tn + ((size_t)ty * TW + tx) * 8);
+            for (int c = 0; c < 8; ++c) acc[a_][b_][c] = 0.f;
+#pragma unroll
+    for (int rr = 0; rr < 5; ++rr) {
+        const int r = 2 * Y - 1 + rr;
+        if (r < 0 || r > 2 * Hin) continue;
+#pragma unroll
+        for (int cc = 0; cc < 5; ++cc) {
+            const int c = 2 * X - 1 + cc;
+            if (c < 0 || c > 2 * Win) continue;
+            const float4* s4 = reinterpret_cast<const float4*>(Tn + (size_t)((r & 1) * 2 + (c & 1)) * pplane + ((size_t)(r >> 1) * PW + (c >> 1)) * 8);
             const float4 u = s4[0], v = s4[1];
-            const float w = f1[aa] * f1[bb];
-            acc[0] += u.x * w; acc[1] += u.y * w; acc[2] += u.z * w; acc[3] += u.w * w;
-            acc[4] += v.x * w; acc[5] += v.y * w; acc[6] += v.z * w; acc[7] += v.w * w;
+            const float tv[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy) {
+                const int a_ = rr - dy;                 // tap index: r - (2Y+dy) + 1
+                if (a_ < 0 || a_ > 3) continue;
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    const int b_ = cc - dx;
+                    if (b_ < 0 || b_ > 3) continue;
+                    const float w = f1[a_] * f1[b_];
+#pragma unroll
+                    for (int ch = 0; ch < 8; ++ch) acc[dy][dx][ch] += tv[ch] * w;
+                }
+            }
         }
     }
-    const float* b = bias + (size_t)n * vec_stride_n + cb * 8;
-    const float* ns = next_scale + (size_t)n * vec_stride_n + cb * 8;
-    h8 hi, lo;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        float t = acc[c] + b[c];
-        t = (t < 0.f ? t * 0.2f : t) * 1.4142135623730951f;
-        if (clamp >= 0.f) t = fminf(fmaxf(t, -clamp), clamp);
-        _Float16 x0, x1; split1(t * ns[c], x0, x1); hi[c] = x0; lo[c] = x1;
-    }
+    const float4* b4 = reinterpret_cast<const float4*>(bias + (size_t)n * vec_stride_n + cb * 8);
+    const float4* n4 = reinterpret_cast<const float4*>(next_scale + (size_t)n * vec_stride_n + cb * 8);
+    const float4 b0 = b4[0], b1 = b4[1], n0 = n4[0], n1 = n4[1];
+    const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w}, nv[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
     const size_t plane = (size_t)(C / 8) * OH * OW;
-    uint4* d = y + (size_t)n * y_stride_n + (size_t)cb * OH * OW + p;
-    d[0] = *reinterpret_cast<uint4*>(&hi);
-    d[plane] = *reinterpret_cast<uint4*>(&lo);
+    uint4* d = y + (size_t)n * y_stride_n + (size_t)cb * OH * OW;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            h8 hi, lo;
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) {
+                float t = acc[dy][dx][ch] + bv[ch];
+                t = (t < 0.f ? t * 0.2f : t) * 1.4142135623730951f;
+                if (clamp >= 0.f) t = fminf(fmaxf(t, -clamp), clamp);
+                _Float16 x0, x1; split1(t * nv[ch], x0, x1); hi[ch] = x0; lo[ch] = x1;
+            }
+            const size_t p = (size_t)(2 * Y + dy) * OW + (2 * X + dx);
+            d[p] = *reinterpret_cast<uint4*>(&hi);
+            d[plane + p] = *reinterpret_cast<uint4*>(&lo);
+        }
 }
 
 // ---- image finalize: img_out = upsample2d(img_in) + bias + sum_m partial[m]  (networks_stylegan2.py:463-469) ----
@@ -407,11 +500,17 @@ int sr_prepack_f16x3(int Cin, int Cout, const float* c0_w, const float* c1_w, vo
     return check_launch("sr_block_prepack");
 }
 
-static void launch_conv2(const Conv2Args& a, int tiles, int N, hipStream_t st)
+static void launch_conv2(Conv2Args& a, int tiles, int N, hipStream_t st)
 {
     dim3 grid(tiles, a.Cout / BLOCK_M, N * a.nphase);
-    if (a.nphase == 1) hipLaunchKernelGGL(conv_mfma_f16x3_kernel, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(tconv_mfma_f16x3_kernel, grid, dim3(256), 0, st, a);
+    static const int shape = getenv("R3D_CONV_SHAPE") ? atoi(getenv("R3D_CONV_SHAPE")) : 0;   // tuning switch, default 0
+    if (shape == 1) {           // 4 waves x (64 couts x 128 px), 2 blocks/CU
+        if (a.nphase == 1) hipLaunchKernelGGL((conv_mfma_f16x3_kernel<2, 4, 2>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((tconv_mfma_f16x3_kernel<2, 4, 2>), grid, dim3(256), 0, st, a);
+    } else {                    // 8 waves x (64 couts x 64 px): 4 waves/SIMD at 2 blocks/CU
+        if (a.nphase == 1) hipLaunchKernelGGL((conv_mfma_f16x3_kernel<4, 2, 4>), grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL((tconv_mfma_f16x3_kernel<4, 2, 4>), grid, dim3(512), 0, st, a);
+    }
 }
 
 int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int Cin, int Cout, int Hin, int Win,
@@ -423,10 +522,12 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
     const SrStyleLayout L = sr_style_layout(Cin, Cout);
     const float* pk = reinterpret_cast<const float*>(styles);
     const float* wpk = reinterpret_cast<const float*>(prepacked);
-    const int OH = 2 * Hin, OW = 2 * Win, TH = OH + 1, TW = OW + 1;
+    const int OH = 2 * Hin, OW = 2 * Win;
     char* wsb = reinterpret_cast<char*>(workspace);
     uint4* xin = reinterpret_cast<uint4*>(wsb); wsb += align256((size_t)N * Cin * Hin * Win * 4);
-    float* T = reinterpret_cast<float*>(wsb);   wsb += align256((size_t)N * Cout * TH * TW * 4);
+    const int PH = Hin + 1, PW = Win + 1;
+    const size_t pplane = (size_t)Cout * PH * PW;                 // floats per phase plane
+    float* T = reinterpret_cast<float*>(wsb);   wsb += align256((size_t)N * 4 * pplane * 4);
     uint4* y0 = reinterpret_cast<uint4*>(wsb);  wsb += align256((size_t)N * Cout * OH * OW * 4);
     float* xo = reinterpret_cast<float*>(wsb);                    // fp32 CB8 x (only when an fp32 x_out is requested)
     float* rgbp = reinterpret_cast<float*>(wsb + align256((size_t)N * Cout * OH * OW * 4));
@@ -444,9 +545,12 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
         a.x = xs; a.x_stride_n = (size_t)Cin / 8 * Hin * Win * 2;
         a.wp = reinterpret_cast<const uint4*>(wpk);
         a.out_scale = pk + L.d0; a.bias = nullptr; a.vec_stride_n = L.total;
-        a.y_f32 = T; a.y_f32_stride_n = (size_t)Cout * TH * TW; a.OH = TH; a.OW = TW;
+        a.y_f32 = T; a.y_f32_stride_n = 4 * pplane; a.OH = PH; a.OW = PW;
         a.Cin = Cin; a.Cout = Cout; a.H = Hin; a.W = Win; a.nphase = 4; a.act = 0; a.clamp = -1.f;
         sr_fill_tconv_phases(a.ph, Hin, Win);
+        for (int p = 0; p < 4; ++p) {                               // phase-major T: contiguous stores per phase
+            a.ph[p].oy_mul = 1; a.ph[p].oy_add = 0; a.ph[p].ox_mul = 1; a.ph[p].ox_add = 0; a.ph[p].out_off = p * pplane;
+        }
         int maxtiles = 0;
         for (int p = 0; p < 4; ++p) {
             const int tiles = ((a.ph[p].outW + F_TILE_W - 1) / F_TILE_W) * ((a.ph[p].outH + F_TILE_H - 1) / F_TILE_H);
@@ -457,8 +561,8 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
     }
     {
         ProfScope ps(R3D_PROF_FIR, st);
-        hipLaunchKernelGGL(fir_bias_act_split_kernel, dim3((OH * OW + 255) / 256, Cout / 8, N), dim3(256), 0, st,
-                           T, (size_t)Cout * TH * TW, pk + L.b0, pk + L.s1, L.total, y0, (size_t)Cout / 8 * OH * OW * 2, Cout, OH, OW, clamp);
+        hipLaunchKernelGGL(fir_bias_act_split_kernel, dim3((Hin * Win + 255) / 256, Cout / 8, N), dim3(256), 0, st,
+                           T, 4 * pplane, pk + L.b0, pk + L.s1, L.total, y0, (size_t)Cout / 8 * OH * OW * 2, Cout, Hin, Win, clamp);
     }
     // ---- conv1 (3x3) + bias/lrelu + toRGB partials (+ optional x outputs) ------------------------------------------
     const bool want_f32 = x_out && (x_out_format == R3D_FMT_NCHW || x_out_format == R3D_FMT_CB8);

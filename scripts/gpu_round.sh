@@ -1,4 +1,7 @@
 mkdir -p gpurun_out; export R=$PWD
-timeout 600 python -m pytest tests -m gpu -x -q -s 2>&1 | grep -E "passed|failed|error|sr_full|Error" | tail -8
-python bench.py --steps 30 --warmup 5 > gpurun_out/bench.log 2> gpurun_out/bench.err; tail -2 gpurun_out/bench.err; cat gpurun_out/bench.log
-R3D_SR_PRECISION=f32 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > gpurun_out/bench_f32.log 2>&1; tail -1 gpurun_out/bench_f32.log | cut -c1-400
+timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
+python bench.py --steps 40 --warmup 5 > gpurun_out/bench.log 2> gpurun_out/bench.err; tail -2 gpurun_out/bench.err; cat gpurun_out/bench.log
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof -o r01 -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $R/gpurun_out/prof.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/pmc_fetch -o r01 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $R/gpurun_out/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/pmc_write -o r01 -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $R/gpurun_out/pmc_write.log 2>&1

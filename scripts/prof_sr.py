@@ -15,4 +15,10 @@ x = T(synth.hash_unitvar(7, (1, 32, 128, 128), stream=1)); rgb = x[:, :3].contig
 for _ in range(2): sr(rgb, x, ws, noise_mode="none")
 torch.cuda.synchronize(); t = time.perf_counter()
 for _ in range(reps): sr(rgb, x, ws, noise_mode="none")
-torch.cuda.synchronize(); print("SR 128->512: %.3f ms" % ((time.perf_counter() - t) / reps * 1e3))
+torch.cuda.synchronize(); total = (time.perf_counter() - t) / reps * 1e3
+import ctypes
+from real3dportrait_amd import _lib
+lib = _lib.load(); lib.r3d_profile_configure(2); lib.r3d_profile_reset()
+for _ in range(reps): sr(rgb, x, ws, noise_mode="none")
+torch.cuda.synchronize(); ms, cnt = ctypes.c_double(0), ctypes.c_int(0); lib.r3d_profile_read(1, ctypes.byref(ms), ctypes.byref(cnt))
+print("SR 128->512: %.3f ms   conv kernels: %.3f ms/frame (%d launches)  dbg=%s" % (total, ms.value / reps, cnt.value, os.environ.get("R3D_DBG", "0")))
