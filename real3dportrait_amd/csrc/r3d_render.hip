@@ -163,9 +163,14 @@ __device__ __forceinline__ void stage_decoder(DecoderLds& L, const float* __rest
                                               const float* __restrict__ b1, const float* __restrict__ w2,
                                               const float* __restrict__ b2)
 {
-    // FullyConnectedLayer: w * (1/sqrt(in_features))  (networks_stylegan2.py:115,119)
-    const float g1 = 0.17677669529663687f;  // 1/sqrt(32)
-    const float g2 = 0.125f;                // 1/sqrt(64)
+    // FullyConnectedLayer: w * (1/sqrt(in_features))  (networks_stylegan2.py:115,119).
+    // The hidden layer is evaluated in the log2 domain: h' = log2(e) * (W1 x + b1), softplus(h) = ln2 * sp2(h') with
+    // sp2(h') = max(h',0) + log2(1 + 2^-|h'|)  (5 instructions on v_exp_f32 / v_log_f32).  ln2 folds into layer 2:
+    // for the colour rows, which feed sigmoid(y) = 1/(1 + 2^(-log2(e) y)), ln2 * log2(e) = 1 leaves W2 unchanged and
+    // only b2 picks up log2(e); the density row (natural units) picks up ln2.
+    const float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+    const float g1 = 0.17677669529663687f * kLog2e;  // 1/sqrt(32) * log2(e)
+    const float g2 = 0.125f;                         // 1/sqrt(64)
     for (int i = threadIdx.x; i < 4 * 8 * 64; i += blockDim.x) {
         const int l = i & 63, kk = (i >> 6) & 7, mt = i >> 9;
         L.w1f[i] = w1[(16 * mt + (l & 15)) * kC + 8 * (l >> 4) + kk] * g1;
@@ -175,8 +180,8 @@ __device__ __forceinline__ void stage_decoder(DecoderLds& L, const float* __rest
         const int mt = ks >> 2, reg = ks & 3;
         L.w2f[i] = w2[(1 + 16 * ot + (l & 15)) * kHid + 16 * mt + 4 * (l >> 4) + reg] * g2;
     }
-    for (int i = threadIdx.x; i < kHid; i += blockDim.x) { L.w2s[i] = w2[i] * g2; L.b1[i] = b1[i]; }
-    for (int i = threadIdx.x; i < kOut; i += blockDim.x) L.b2[i] = b2[i];
+    for (int i = threadIdx.x; i < kHid; i += blockDim.x) { L.w2s[i] = w2[i] * (g2 * kLn2); L.b1[i] = b1[i] * kLog2e; }
+    for (int i = threadIdx.x; i < kOut; i += blockDim.x) L.b2[i] = i == 0 ? b2[i] : b2[i] * kLog2e;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -283,7 +288,8 @@ __device__ __forceinline__ void decode_tiles(const DecoderLds& L, int lane, cons
         for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                h[nt][r] = softplus20(h[nt][r]);
+                const float x = h[nt][r];         // log2 domain
+                h[nt][r] = fmaxf(x, 0.0f) + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(x)));
                 sig[nt] += h[nt][r] * ws[r];
             }
         }
@@ -314,7 +320,8 @@ __device__ __forceinline__ void decode_tiles(const DecoderLds& L, int lane, cons
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) col[ot][nt][r] = sigmoidf(col[ot][nt][r]) * 1.002f - 0.001f;
+            for (int r = 0; r < 4; ++r)       // col holds log2(e) * y
+                col[ot][nt][r] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-col[ot][nt][r])) * 1.002f - 0.001f;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -350,6 +357,7 @@ struct RayLds {
     float wv[kRayArr];     // interval weights (coarse order first, later sorted order)
     float om[kRayArr];     // omega per ORIGINAL sample index
     float cdf[104];
+    int cnt[kRayArr];      // merge histogram / rank-collision check
 };
 
 // A6 on n samples T/S (LDS, in the order to march): writes interval weights to wv[0..n-2],
@@ -554,19 +562,95 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderArgs a, int R)
                 }
             }
             wave_lds_sync();
-            // ---- A8 merge: rank of every sample in depth order (stable), scatter (t, sigma) ----------------
+            // ---- A8 merge (renderer.py:197-207): rank of every sample in depth order, scatter (t, sigma).
+            // The coarse samples are generated in increasing order (checked), so instead of an O(S^2) counting sort:
+            //   fine j   -> rank = #{coarse <= t_j} (binary search) + #{fine k < t_j} (Nf compares)
+            //   coarse i -> rank = i + #{fine < t_i} = i + prefix-sum of the histogram of the fine samples' coarse counts
+            // Exact ties between fine samples collide in rank; collisions (and a non-monotone coarse list, e.g. the
+            // no-valid-ray case where depths run backwards) fall back to the exact stable counting sort.
             int rank[SLOTS];
+            bool fast = true;
+#pragma unroll
+            for (int sl = 0; sl < CSLOTS; ++sl) {
+                const int i = sl * 64 + lane;
+                const bool act = i < Nc - 1;
+                fast = fast && (!act || L.t[act ? i : 0] <= L.t[act ? i + 1 : 0]);
+            }
+            fast = __all(fast);
+            if (fast) {
+#pragma unroll
+                for (int sl = 0; sl < CSLOTS + 1; ++sl) { const int i = sl * 64 + lane; if (i <= Nc) L.cnt[i] = 0; }
+                wave_lds_sync();
+                int rf[FSLOTS];
+#pragma unroll
+                for (int sl = 0; sl < FSLOTS; ++sl) {
+                    const int j = sl * 64 + lane;
+                    const bool act = j < Nf;
+                    const float tj = L.t[Nc + (act ? j : 0)];
+                    int lo = 0, hi = Nc;                         // c = #{i < Nc : t_c[i] <= tj}
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (L.t[mid] <= tj) lo = mid + 1; else hi = mid; }
+                    int f = 0;
+                    for (int k = 0; k < Nf; ++k) f += (L.t[Nc + k] < tj) ? 1 : 0;
+                    rf[sl] = lo + f;
+                    if (act) atomicAdd(&L.cnt[lo], 1);
+                }
+                wave_lds_sync();
+                // inclusive prefix over the histogram: pre[i] = #{fine with coarse-count <= i} = #{fine < t_c[i]}
+                int carry = 0;
+                int rc[CSLOTS];
+#pragma unroll
+                for (int sl = 0; sl < CSLOTS; ++sl) {
+                    const int i = sl * 64 + lane;
+                    int v = i < Nc ? L.cnt[i] : 0;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(v, d); if (lane >= d) v += o; }
+                    rc[sl] = i + carry + v;
+                    carry += __shfl(v, 63);
+                }
+                wave_lds_sync();
+                // collision check: every rank slot must be claimed exactly once
+#pragma unroll
+                for (int sl = 0; sl < CSLOTS; ++sl) { const int i = sl * 64 + lane; if (i < Nc) L.cnt[rc[sl]] = i; }
+#pragma unroll
+                for (int sl = 0; sl < FSLOTS; ++sl) { const int j = sl * 64 + lane; if (j < Nf) L.cnt[rf[sl]] = Nc + j; }
+                wave_lds_sync();
+                bool ok = true;
+#pragma unroll
+                for (int sl = 0; sl < CSLOTS; ++sl) { const int i = sl * 64 + lane; if (i < Nc) ok = ok && L.cnt[rc[sl]] == i; }
+#pragma unroll
+                for (int sl = 0; sl < FSLOTS; ++sl) { const int j = sl * 64 + lane; if (j < Nf) ok = ok && L.cnt[rf[sl]] == Nc + j; }
+                fast = __all(ok);
+                if (fast) {
+                    // per-element ranks in the (i = sl*64 + lane) indexing used below: coarse i < Nc, fine Nc + j
+#pragma unroll
+                    for (int sl = 0; sl < CSLOTS; ++sl) { const int i = sl * 64 + lane; if (i < Nc) L.cnt[i] = rc[sl]; }
+#pragma unroll
+                    for (int sl = 0; sl < FSLOTS; ++sl) { const int j = sl * 64 + lane; if (j < Nf) L.cnt[Nc + j] = rf[sl]; }
+                    wave_lds_sync();
+#pragma unroll
+                    for (int sl = 0; sl < SLOTS; ++sl) {
+                        const int i = sl * 64 + lane;
+                        rank[sl] = L.cnt[i < S ? i : 0];
+                    }
+                }
+            }
+            if (!fast) {
+#pragma unroll
+                for (int sl = 0; sl < SLOTS; ++sl) {
+                    const int i = sl * 64 + lane;
+                    const float ti = L.t[i < S ? i : 0];
+                    int cnt = 0;
+                    for (int j = 0; j < S; ++j) {
+                        const float tj = L.t[j];
+                        cnt += (tj < ti || (tj == ti && j < i)) ? 1 : 0;
+                    }
+                    rank[sl] = cnt;
+                }
+            }
 #pragma unroll
             for (int sl = 0; sl < SLOTS; ++sl) {
                 const int i = sl * 64 + lane;
-                const float ti = L.t[i < S ? i : 0];
-                int cnt = 0;
-                for (int j = 0; j < S; ++j) {
-                    const float tj = L.t[j];
-                    cnt += (tj < ti || (tj == ti && j < i)) ? 1 : 0;
-                }
-                rank[sl] = cnt;
-                if (i < S) { L.ts[cnt] = ti; L.ss[cnt] = L.sg[i]; }
+                if (i < S) { L.ts[rank[sl]] = L.t[i]; L.ss[rank[sl]] = L.sg[i]; }
             }
             wave_lds_sync();
             march<SLOTS>(L.ts, L.ss, L.wv, S, lane, wsum, dsum);
