@@ -106,36 +106,35 @@ __global__ void sr_styles_kernel(const float* __restrict__ ws3, int WD, int Cin,
     if (lane == 0) out[c] = (acc + ab[c]) * post;
 }
 
-// grid (Cout/4, N, 2): one WAVE per output channel: d = rsqrt(sum_{ci,k} (W*s)^2 + 1e-8)
+// grid (Cout + 1, N, 2): blocks [0, Cout) of layer z: one BLOCK per output channel: d = rsqrt(sum_{ci,k} (W*s)^2 + 1e-8)
+// (networks_stylegan2.py:65-70); block Cout of layer 0: modulated toRGB weights (:366-368) + bias copies.
 __global__ void sr_demod_kernel(int Cin, int Cout, const float* __restrict__ w0, const float* __restrict__ w1,
-                                float* __restrict__ styles, size_t stride_n)
+                                const float* __restrict__ wrgb, const float* __restrict__ b0, const float* __restrict__ b1,
+                                const float* __restrict__ brgb, float* __restrict__ styles, size_t stride_n)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int co = blockIdx.x * 4 + wave, n = blockIdx.y, layer = blockIdx.z;
-    if (co >= Cout) return;
+    const int co = blockIdx.x, n = blockIdx.y, layer = blockIdx.z;
     const SrStyleLayout L = sr_style_layout(Cin, Cout);
+    float* base = styles + n * stride_n;
+    if (co == Cout) {
+        if (layer == 0)
+            for (int i = threadIdx.x; i < 3 * Cout; i += blockDim.x) {
+                base[L.wrgb + i] = wrgb[i] * base[L.s2 + (i % Cout)];
+                if (i < Cout) { base[L.b0 + i] = b0[i]; base[L.b1 + i] = b1[i]; }
+                if (i < 3) base[L.brgb + i] = brgb[i];
+            }
+        return;
+    }
     const int Ci = layer == 0 ? Cin : Cout;
     const float* W = (layer == 0 ? w0 : w1) + (size_t)co * Ci * 9;
-    float* base = styles + n * stride_n;
     const float* st = base + (layer == 0 ? L.s0 : L.s1);
     float ss = 0.f;
-    for (int i = lane; i < Ci * 9; i += 64) { const float v = W[i] * st[i / 9]; ss += v * v; }
+    for (int i = threadIdx.x; i < Ci * 9; i += blockDim.x) { const float v = W[i] * st[i / 9]; ss += v * v; }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) ss += __shfl_xor(ss, d);
-    if (lane == 0) base[(layer == 0 ? L.d0 : L.d1) + co] = rsqrtf(ss + 1e-8f);
-}
-
-__global__ void sr_style_misc_kernel(int Cin, int Cout, const float* __restrict__ wrgb, const float* __restrict__ b0,
-                                     const float* __restrict__ b1, const float* __restrict__ brgb,
-                                     float* __restrict__ styles, size_t stride_n)
-{
-    const int n = blockIdx.y;
-    const SrStyleLayout L = sr_style_layout(Cin, Cout);
-    float* base = styles + n * stride_n;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < 3 * Cout) base[L.wrgb + i] = wrgb[i] * base[L.s2 + (i % Cout)];
-    if (i < Cout) { base[L.b0 + i] = b0[i]; base[L.b1 + i] = b1[i]; }
-    if (i < 3) base[L.brgb + i] = brgb[i];
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) base[(layer == 0 ? L.d0 : L.d1) + co] = rsqrtf(red[0] + red[1] + red[2] + red[3] + 1e-8f);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -473,8 +472,7 @@ extern "C" int r3d_sr_block_styles(const float* ws3, int N, int WD, int Cin, int
     const size_t stride = sr_style_layout(Cin, Cout).total;
     ProfScope ps(R3D_PROF_PACK, st);
     hipLaunchKernelGGL(sr_styles_kernel, dim3(((Cin > Cout ? Cin : Cout) + 3) / 4, 3, N), dim3(256), 0, st, ws3, WD, Cin, Cout, c0_aw, c0_ab, c1_aw, c1_ab, rgb_aw, rgb_ab, sv, stride);
-    hipLaunchKernelGGL(sr_demod_kernel, dim3((Cout + 3) / 4, N, 2), dim3(256), 0, st, Cin, Cout, c0_w, c1_w, sv, stride);
-    hipLaunchKernelGGL(sr_style_misc_kernel, dim3((3 * Cout + 255) / 256, N), dim3(256), 0, st, Cin, Cout, rgb_w, c0_b, c1_b, rgb_b, sv, stride);
+    hipLaunchKernelGGL(sr_demod_kernel, dim3(Cout + 1, N, 2), dim3(256), 0, st, Cin, Cout, c0_w, c1_w, rgb_w, c0_b, c1_b, rgb_b, sv, stride);
     return check_launch("sr_block_styles");
 }
 
