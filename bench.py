@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("R3D_BENCH_STREAMS", "2")),
+                    help="HIP streams that consecutive frames are issued on (frames are independent)")
     return ap.parse_args()
 
 
@@ -128,38 +130,53 @@ def main():
     G, clip, dec, scene = build_scene(torch, dev, n_frames=max(64, K * world))
     ring = torch.zeros(K, 512, 512, 3, dtype=torch.uint8, device=dev)
 
+    pipe = None
+    if args.streams > 1:
+        from real3dportrait_amd.frames import PipelinedClipRenderer
+        cano, residuals, cams = scene
+        pipe = PipelinedClipRenderer(G, cano, residuals, cams, clip.ws, base_seed=clip.base_seed, n_streams=args.streams)
+
     def step(i):
         t = rank * K + i
-        clip.render_u8(t, out=ring[i:i + 1])
+        (pipe or clip).render_u8(t, out=ring[i:i + 1])
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(W):
+    for i in range(max(W, args.streams)):
         step(i % K)
+    if pipe is not None:
+        pipe.sync()
     if world > 1:                                        # warm the gather path too
         clip_out = __import__("real3dportrait_amd.frames", fromlist=["gather_frames"]).gather_frames(ring, K * world)
     barrier()
-    lib.r3d_profile_configure(1 << 1)                    # bracket conv_mfma_kernel launches only (4 per frame)
-    lib.r3d_profile_reset()
     t0 = time.perf_counter()
     for i in range(K):
         step(i)
+    if pipe is not None:
+        pipe.sync()
     if world > 1:
         from real3dportrait_amd.frames import gather_frames
         clip_out = gather_frames(ring, K * world)
     barrier()
     elapsed = time.perf_counter() - t0
-    lib.r3d_profile_configure(0)
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
-    # ---- roofline of the dominant kernel: conv_mfma_kernel (4 launches/frame), MFMA-bound ---------------------
+    # ---- roofline of the dominant kernel family (the 4 conv launches of a frame), MFMA-bound -------------------
+    # HIP event pairs recorded on the launch stream around every conv launch.  With frames pipelined over several
+    # streams a bracket would also contain other frames' kernels, so the kernel's own duration is measured over the
+    # same K frames issued on ONE stream right after the timed region (what rocprofv3 --stats sees with --streams 1).
     import ctypes
+    lib.r3d_profile_configure(1 << 1); lib.r3d_profile_reset()
+    for i in range(K):
+        clip.render_u8(rank * K + i, out=ring[i:i + 1])
+    torch.cuda.synchronize()
+    lib.r3d_profile_configure(0)
     ms, cnt = ctypes.c_double(0), ctypes.c_int(0)
     _lib.check(lib.r3d_profile_read(1, ctypes.byref(ms), ctypes.byref(cnt)), "profile_read")
     flops = conv_flops_per_frame(128)
@@ -196,7 +213,7 @@ def main():
                                       "planes cano+residual [1,3,32,256,256] -> 128^2 rays x (48 coarse + 48 importance) "
                                       "-> SuperresolutionHybrid8XDC -> 512^2 uint8; clip gathered to rank 0",
                           "neural_rendering_resolution": 128, "depth_samples": "48+48", "final_resolution": 512,
-                          "frames_total": K * world, "parallelism": "frame-sharded dp%d + gather" % world},
+                          "frames_total": K * world, "streams_per_gpu": args.streams, "parallelism": "frame-sharded dp%d + gather" % world},
                "roofline": roofline}
 
     # ---- per-family breakdown + the literal 512^2 neural render (untimed extras, rank 0 of a 1-GPU run) -------
@@ -204,7 +221,7 @@ def main():
         lib.r3d_profile_configure(0x7F); lib.r3d_profile_reset()
         nb = 10
         for i in range(nb):
-            step(i % K)
+            clip.render_u8(i % K, out=ring[(i % K):(i % K) + 1])
         torch.cuda.synchronize()
         names = ["render", "conv_mfma", "fir", "torgb", "sr_pack", "layout", "misc"]
         bd = {}

@@ -56,6 +56,25 @@ def render_clip_sharded(render_frame, num_frames, frame_hw=(512, 512), device="c
     return gather_frames(ring, num_frames, group)
 
 
+def clone_generator_shell(G):
+    """A second generator shell that SHARES G's parameters (decoder, SR layers) but owns its own operator objects,
+    i.e. its own workspaces / style buffers -- what a second HIP stream needs to render another frame concurrently."""
+    from .superresolution import SuperresolutionHybrid8XDC
+    from .triplane import TriPlaneGenerator
+    dev = next(G.parameters()).device
+    G2 = TriPlaneGenerator(hp=G.hparams, backbone=G.backbone)
+    G2.decoder = G.decoder
+    sr = SuperresolutionHybrid8XDC(channels=32, img_resolution=512, sr_num_fp16_res=0, sr_antialias=True)
+    for name in ("block0", "block1"):
+        src, dst = getattr(G.superresolution, name), getattr(sr, name)
+        dst.conv0, dst.conv1, dst.torgb = src.conv0, src.conv1, src.torgb
+        dst.precision = src.precision
+    G2.superresolution = sr
+    G2.rendering_kwargs = dict(G.rendering_kwargs)
+    G2.neural_rendering_resolution = G.neural_rendering_resolution
+    return G2.to(dev).eval()
+
+
 class ClipRenderer:
     """Per-frame driver around a (HIP) TriPlaneGenerator: planes_t = cano + residual_t (the reference's
     secc2plane residual add, modules/real3d/secc_img2plane.py:73-81, fused into the layout kernel),
@@ -97,3 +116,29 @@ class ClipRenderer:
         self._lib.check(lib.r3d_frames_to_u8(self._lib.ptr(img), N, H, W, self._lib.ptr(out), self._lib.stream_ptr()),
                         "frames_to_u8")
         return out[0] if out.dim() == 4 else out
+
+
+class PipelinedClipRenderer:
+    """Frames are independent, so consecutive frames are issued round-robin on `n_streams` HIP streams, each with its
+    own operator workspaces (clone_generator_shell): the latency-bound ray kernel of frame t+1 overlaps the MFMA-bound
+    SR convolutions of frame t.  `sync()` joins the side streams back into the caller's stream."""
+
+    def __init__(self, generator, cano_planes, residuals, cameras, ws, base_seed=0, n_streams=2):
+        self.streams = [torch.cuda.Stream() for _ in range(n_streams)]
+        shells = [generator] + [clone_generator_shell(generator) for _ in range(n_streams - 1)]
+        self.clips = [ClipRenderer(g, cano_planes, residuals, cameras, ws, base_seed) for g in shells]
+        self._k = 0
+
+    def render_u8(self, t, out=None):
+        i = self._k % len(self.streams)
+        self._k += 1
+        st = self.streams[i]
+        if self._k <= len(self.streams):
+            st.wait_stream(torch.cuda.current_stream())       # inputs prepared on the caller's stream
+        with torch.cuda.stream(st):
+            return self.clips[i].render_u8(t, out=out)
+
+    def sync(self):
+        cur = torch.cuda.current_stream()
+        for st in self.streams:
+            cur.wait_stream(st)
