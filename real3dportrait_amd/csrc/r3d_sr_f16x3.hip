@@ -35,7 +35,7 @@ __device__ __forceinline__ void split1(float v, _Float16& hi, _Float16& lo)
     lo = (_Float16)(v - (float)hi);
 }
 
-// ---- weights: [tap][ci/8][cout][8 hi | 8 lo] -------------------------------------------------------------------
+// ---- weights: [tap][ci/8][hi|lo][cout] x 8 halfs (hi and lo in separate 16-byte planes: conflict-free ds_read_b128) ----
 __global__ void sr_prepack_f16_kernel(const float* __restrict__ w, int Ci, int Cout, uint4* __restrict__ out)
 {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // (tap, chunk, cout)
@@ -48,8 +48,9 @@ __global__ void sr_prepack_f16_kernel(const float* __restrict__ w, int Ci, int C
     h8 hi, lo;
 #pragma unroll
     for (int j = 0; j < 8; ++j) { _Float16 a, b; split1(src[9 * j], a, b); hi[j] = a; lo[j] = b; }
-    out[2 * e] = *reinterpret_cast<uint4*>(&hi);
-    out[2 * e + 1] = *reinterpret_cast<uint4*>(&lo);
+    const size_t base = ((size_t)tap * (Ci / 8) + chunk) * 2 * Cout + co;
+    out[base] = *reinterpret_cast<uint4*>(&hi);
+    out[base + Cout] = *reinterpret_cast<uint4*>(&lo);
 }
 
 // ---- input conversion: fp32 (NCHW or CB8) * style -> SPLIT ------------------------------------------------------
@@ -112,7 +113,7 @@ __device__ __forceinline__ void conv2_block(const Conv2Args& a, const ConvPhase&
     constexpr int A_BUF = 3 * 2 * 256;                                // uint4 per weight buffer (sized for SUB = 3)
     constexpr int NAR = A_ELEMS / NTHR;
     uint4* patchB = lds;                                              // [plane][chunk][324]
-    uint4* bufA = lds + B_ELEMS;                                      // 2 x [SUB][2][128 couts][hi|lo], filled by LDS-DMA
+    uint4* bufA = lds + B_ELEMS;                                      // 2 x [SUB][2 chunks][hi|lo][128 couts], filled by LDS-DMA
     const int tiles_x = (ph.outW + F_TILE_W - 1) / F_TILE_W;
     const int tile = blockIdx.x;
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
@@ -141,7 +142,7 @@ __device__ __forceinline__ void conv2_block(const Conv2Args& a, const ConvPhase&
     int boff[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) boff[nt] = (row0 + nt * 2 + prow + 1) * F_PATCH_W + (pcol + 1) + h * F_PATCH_PIX;
-    const int aoff = (h * 128 + 64 * wm + li) * 2;                    // + ts*512 + mt*64
+    const int aoff = h * 256 + 64 * wm + li;                          // [ts][hc = h][hi|lo][128 couts]: + ts*512 + mt*32 (+128 for lo)
 
     const int chunk_stride = a.H * a.W;
     uint4 pf[NPF];
@@ -176,15 +177,15 @@ __device__ __forceinline__ void conv2_block(const Conv2Args& a, const ConvPhase&
     };
     // weights: global -> LDS by DMA (global_load_lds_dwordx4: LDS address = wave-uniform base + lane*16; the
     // sub-stage image is linear in e = tid + NTHR*k, so a wave's 64 lanes fill one contiguous KB); no VGPRs, no ds_write
-    const int tid_hi = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8);       // 0 for 256-thread blocks
+    const int tid_seg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);      // 128-cout segment of this wave
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const unsigned tid_lo = threadIdx.x & 255;
+    const unsigned tid_lo = threadIdx.x & 127;
     auto dma_weights = [&](int c0, int sub, uint4* dstA) {
 #pragma unroll
         for (int k = 0; k < NAR; ++k) {
-            const int pair = (NTHR >> 8) * k + tid_hi, t = sub * SUB + (pair >> 1), hc = pair & 1;     // wave-uniform
+            const int seg = (NTHR >> 7) * k + tid_seg, t = sub * SUB + (seg >> 2), hc = (seg >> 1) & 1, hl = seg & 1;   // wave-uniform
             if (t < NTAPS) {
-                const uint4* src = WP + (((size_t)ph.widx[t] * nchunks + (c0 + hc)) * a.Cout + m0) * 2;      // uniform
+                const uint4* src = WP + (((size_t)ph.widx[t] * nchunks + (c0 + hc)) * 2 + hl) * a.Cout + m0;     // uniform
                 // inline asm: hipcc would otherwise put s_waitcnt vmcnt(0) in front of every ds_read while an LDS-DMA it
                 // knows about is in flight (no alias info inside one LDS array); waits for these DMAs are the explicit
                 // counted s_waitcnt vmcnt below (cdna_hip_programming.md section 5.7)
@@ -235,7 +236,7 @@ __device__ __forceinline__ void conv2_block(const Conv2Args& a, const ConvPhase&
                     h8 ah[2], al[2];
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
-                        uint4 q0 = curA[ts * 512 + aoff + mt * 64], q1 = curA[ts * 512 + aoff + mt * 64 + 1];
+                        uint4 q0 = curA[ts * 512 + aoff + mt * 32], q1 = curA[ts * 512 + aoff + mt * 32 + 128];
                         ah[mt] = *reinterpret_cast<h8*>(&q0); al[mt] = *reinterpret_cast<h8*>(&q1);
                     }
                     const int toff = ph.dy[t] * F_PATCH_W + ph.dx[t];
