@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("R3D_BENCH_STREAMS", "2")),
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("R3D_BENCH_STREAMS", "3")),
                     help="HIP streams that consecutive frames are issued on (frames are independent)")
     return ap.parse_args()
 
