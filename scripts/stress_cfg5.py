@@ -1,0 +1,59 @@
+"""BASELINE.json configs[4] (stress): 1024x1024 SR output, 96 depth samples (96 coarse + 96 importance), batch of 8
+novel-view cameras per GPU.  The reference SR hard-asserts a 512 output (superresolution.py:334), so -- as SURVEY 8(d)
+defines it -- the same two SynthesisBlocks are applied at 2x spatial size (256^2 -> 512^2 -> 1024^2).
+Checks item 0 against the CPU oracle (render) and reports throughput."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from real3dportrait_amd import ImportanceRenderer, OSGDecoder, RaySampler, SynthesisBlock, synth
+N, R, Nc, Nf = 8, 256, 96, 96
+check = "--check" in sys.argv
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+planes1 = synth.synth_planes(7, N=1); dn = synth.synth_decoder(7, sigma_bias=4.0)
+planes = T(planes1).repeat(N, 1, 1, 1, 1)
+dec = OSGDecoder().cuda()
+with torch.no_grad():
+    dec.net[0].weight.copy_(T(dn[0])); dec.net[0].bias.copy_(T(dn[1])); dec.net[2].weight.copy_(T(dn[2])); dec.net[2].bias.copy_(T(dn[3]))
+cams_np = synth.camera_sweep(N, -0.4, 0.4); cams = T(cams_np)
+params = synth.synth_sr_params(7)
+b0 = SynthesisBlock(32, 256, w_dim=512, resolution=512, img_channels=3, is_last=False, conv_clamp=None).cuda()
+b1 = SynthesisBlock(256, 128, w_dim=512, resolution=1024, img_channels=3, is_last=True, conv_clamp=None).cuda()
+with torch.no_grad():
+    for blk, p in zip((b0, b1), params):
+        for name in ("conv0", "conv1", "torgb"):
+            l = getattr(blk, name); w, b, aw, ab = p[name]
+            l.weight.copy_(T(w)); l.bias.copy_(T(b)); l.affine.weight.copy_(T(aw)); l.affine.bias.copy_(T(ab))
+b0.out_format = "split"; b1.return_x = False
+ren = ImportanceRenderer(hp={}); ren.noise_mode = "hash"; ren.seed = 5
+opts = {"ray_start": "auto", "ray_end": "auto", "box_warp": 1.0, "depth_resolution": Nc, "depth_resolution_importance": Nf,
+        "disparity_space_sampling": False, "clamp_mode": "softplus", "white_back": False}
+ws = torch.ones(N, 3, 512, device="cuda")
+rs = RaySampler()
+
+def frame_batch():
+    o, d = rs(cams[:, :16].view(-1, 4, 4), cams[:, 16:].view(-1, 3, 3), R)
+    feat, depth, wsum, valid = ren(planes, dec, o, d, opts)
+    fimg = feat.permute(0, 2, 1).reshape(N, 32, R, R).contiguous()
+    prep1 = b1.prepare(ws)
+    x, rgb = b0(fimg, fimg[:, :3].contiguous(), ws, noise_mode="none", _next=(prep1[1].view(torch.float32), b1.styles_stride()))
+    x, rgb = b1(x, rgb, ws, noise_mode="none", _prepared=prep1)
+    return feat, depth, rgb
+
+for _ in range(2): out = frame_batch()
+torch.cuda.synchronize(); t = time.perf_counter()
+reps = 5
+for _ in range(reps): out = frame_batch()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t) / reps
+print("cfg5 stress: N=%d R=%d %d+%d, SR -> %s: %.2f ms per batch = %.1f frames/s (1024^2 frames)" % (N, R, Nc, Nf, tuple(out[2].shape), dt * 1e3, N / dt))
+assert out[2].shape == (N, 3, 1024, 1024) and torch.isfinite(out[2]).all()
+if check:
+    from oracle import Oracle
+    orc = Oracle()
+    o, d = orc.raygen(cams_np[:1, :16], cams_np[:1, 16:], R)
+    ren2 = ImportanceRenderer(hp={})
+    nc = synth.synth_noise(1, (1, R * R, Nc, 1)); uf = synth.synth_noise(2, (R * R, Nf))
+    ren2.noise_override = (T(nc), T(uf))
+    got = ren2(planes[:1], dec, T(o), T(d), opts)
+    ref = orc.render(planes1, dn, o, d, Nc, Nf, nc, uf)
+    print("render item 0 vs oracle: rgb %.2e depth %.2e" % (np.abs(got[0].cpu().numpy() - ref[0]).max(), np.abs(got[1].cpu().numpy() - ref[1]).max()))
+    assert np.abs(got[0].cpu().numpy() - ref[0]).max() <= 2e-4 and np.abs(got[1].cpu().numpy() - ref[1]).max() <= 1e-4

@@ -99,3 +99,32 @@ def test_frame_sharding_arithmetic():
     assert shard_frames(125, 8, 0) == (0, 16) and shard_frames(125, 8, 7) == (112, 125)
     seeds = {frame_seed(7, t) for t in range(1000)}
     assert len(seeds) == 1000 and frame_seed(7, 3) == frame_seed(7, 3) != frame_seed(8, 3)
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/modules/eg3ds"), reason="reference tree not present")
+def test_patch_model_swaps_operators_of_the_reference_generator():
+    """In the build container the reference's TriPlaneGenerator is importable: patch_model must replace its
+    ray_sampler / renderer / superresolution with the HIP operators and copy the SR parameters strict=True."""
+    import os, sys
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, "/root/reference")
+    try:
+        from utils.commons.hparams import set_hparams, hparams
+        from modules.eg3ds.models.triplane import TriPlaneGenerator as RefG
+    finally:
+        sys.path.remove("/root/reference")
+    set_hparams("/root/reference/egs/egs_bases/eg3d/base.yaml", print_hparams=False)
+    hparams.update(ray_near="auto", ray_far="auto", ones_ws_for_sr=True, enable_rescale_plane_regulation=False)
+    G = RefG().eval()
+    ref_sr_state = {k: v.clone() for k, v in G.superresolution.state_dict().items()}
+    import real3dportrait_amd as r3d
+    r3d.patch_model(G)
+    assert type(G.renderer).__module__.startswith("real3dportrait_amd")
+    assert type(G.ray_sampler).__module__.startswith("real3dportrait_amd")
+    assert type(G.superresolution).__module__.startswith("real3dportrait_amd")
+    new_state = G.superresolution.state_dict()
+    assert set(new_state) == set(ref_sr_state)
+    for k, v in ref_sr_state.items():
+        assert torch.equal(new_state[k], v), k
+    # the generator's own state_dict keys are unchanged (checkpoints keep loading strict=True)
+    assert "decoder.net.0.weight" in G.state_dict() and "superresolution.block0.conv0.affine.weight" in G.state_dict()
