@@ -121,7 +121,8 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback exists)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ          # under torchrun even a 1-rank job exercises the RCCL path
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)
     lib = _lib.load()
@@ -141,7 +142,7 @@ def main():
         (pipe or clip).render_u8(t, out=ring[i:i + 1])
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -149,21 +150,23 @@ def main():
         step(i % K)
     if pipe is not None:
         pipe.sync()
-    if world > 1:                                        # warm the gather path too
-        clip_out = __import__("real3dportrait_amd.frames", fromlist=["gather_frames"]).gather_frames(ring, K * world)
+    from real3dportrait_amd.frames import gather_frames
+    if use_dist:                                         # warm the gather path too
+        clip_out = gather_frames(ring, K * world)
     barrier()
     t0 = time.perf_counter()
     for i in range(K):
         step(i)
     if pipe is not None:
         pipe.sync()
-    if world > 1:
-        from real3dportrait_amd.frames import gather_frames
+    if use_dist:
         clip_out = gather_frames(ring, K * world)
+        if rank == 0:
+            assert clip_out.shape == (K * world, 512, 512, 3)
     barrier()
     elapsed = time.perf_counter() - t0
     el = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
@@ -256,7 +259,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

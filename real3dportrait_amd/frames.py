@@ -27,7 +27,7 @@ def frame_seed(base_seed, frame_index):
 def gather_frames(local, num_frames, group=None):
     """local: uint8 [per, H, W, 3] on every rank (per = ceil(T/W), tail rows unused).
     Returns uint8 [T, H, W, 3] on rank 0 and None elsewhere."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local[:num_frames]
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     bufs = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
