@@ -107,6 +107,9 @@ int r3d_run_model(const float* planes_nhwc, int N, int H, int W,
  * r3d_sr_block_forward:
  *   x [N,Cin,Hin,Win] in x_format, img [N,3,Hin,Win] NCHW fp32
  *   -> x_out in x_out_format (may be NULL / R3D_FMT_NONE), img_out [N,3,2Hin,2Win] NCHW fp32.
+ *   up = 1: SynthesisBlock (conv0 up=2, RGB skip through upsample2d).  up = 0: SynthesisBlockNoUp
+ *   (modules/eg3ds/models/superresolution.py:159-258: conv0 is a plain modulated 3x3 conv and img_out = img + toRGB(x)
+ *   at the input resolution; img and img_out are [N,3,Hin,Win]); R3D_SR_F16X3 only.  Cin % 16 == 0, Cout % 128 == 0.
  *   Activation formats: R3D_FMT_NCHW fp32 (the reference layout); R3D_FMT_CB8 fp32 channel-blocked [N,C/8,H,W,8];
  *   R3D_FMT_SPLIT (f16x3 only): two fp16 planes [N][hi|lo][C/8][H][W][8] holding the activation ALREADY MULTIPLIED
  *   by the consumer conv's style vector -- as input it must have been scaled with this block's conv0 styles; as
@@ -131,11 +134,33 @@ int r3d_sr_block_styles(const float* ws3, int N, int WD, int Cin, int Cout,
                         const float* c1_w, const float* c1_b, const float* c1_aw, const float* c1_ab,
                         const float* rgb_w, const float* rgb_b, const float* rgb_aw, const float* rgb_ab,
                         void* styles, r3d_stream_t stream);
-int r3d_sr_block_forward(const void* prepacked, const void* styles, int N, int Cin, int Cout, int Hin, int Win,
+int r3d_sr_block_forward(const void* prepacked, const void* styles, int N, int Cin, int Cout, int Hin, int Win, int up,
                          const void* x, int x_format, const float* img, float clamp,
                          void* x_out, int x_out_format, const float* next_scale, size_t next_scale_stride,
                          float* img_out, int precision,
                          void* workspace, size_t workspace_bytes, r3d_stream_t stream);
+
+/* --- plain convolution layers around the SR blocks --------------------------------------
+ * replaces torch.nn.Conv2d(Cin, Cout, k, 1, padding=k//2) [+ torch.nn.LeakyReLU] as used by the torso / background
+ * fusion stacks of SuperresolutionHybrid8XDC_Warp (modules/real3d/super_resolution/sr_with_ref.py:24-63:
+ * torso_encoder, bg_encoder, fuse_head_torso_convs, fuse_fg_bg_convs), on the f16x3 convolution kernel of the SR
+ * blocks (fp32-accurate, see r3d_sr_precision).
+ *   y = act(out_scale[co] * conv_k(in_scale[ci] * x, W) + bias[co]),  act(t) = (t < 0 ? act_slope * t : t) * act_gain
+ *   when act != 0, then clamp to +-clamp when clamp >= 0.  in_scale / out_scale / bias may be NULL (1, 1, 0); each
+ *   is [N][C] floats with the given per-sample stride (stride 0 = shared by the batch), 16-byte aligned.
+ *   ksize 1 | 3.  weight [Cout,Cin,k,k] fp32 (torch layout).  Cout % 4 == 0.
+ *   x / y formats as for the SR blocks; blocked formats (CB8, SPLIT) need Cin % 16 == 0 / Cout % 8 == 0, NCHW takes
+ *   any Cin (zero padded to 16 inside).  A SPLIT y is scaled by next_scale (NULL = 1) for the consumer.
+ *   workspace (r3d_conv_workspace_bytes) is only used for non-SPLIT inputs. */
+size_t r3d_conv_prepacked_bytes(int Cin, int Cout, int ksize);
+size_t r3d_conv_workspace_bytes(int N, int Cin, int H, int W);
+int r3d_conv_prepack(const float* weight, int Cin, int Cout, int ksize, void* prepacked, r3d_stream_t stream);
+int r3d_conv_forward(const void* prepacked, int N, int Cin, int Cout, int H, int W, int ksize,
+                     const void* x, int x_format, const float* in_scale, size_t in_scale_stride,
+                     const float* out_scale, size_t out_scale_stride, const float* bias, size_t bias_stride,
+                     int act, float act_slope, float act_gain, float clamp,
+                     void* y, int y_format, const float* next_scale, size_t next_scale_stride,
+                     void* workspace, size_t workspace_bytes, r3d_stream_t stream);
 
 /* --- output side --------------------------------------------------------------------------------
  * clamp(-1,1) -> (x+1)*127.5 -> uint8 HWC, the conversion real3d_infer.py:495-521 does on the host

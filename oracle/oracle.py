@@ -94,19 +94,40 @@ class Oracle:
             return out + ({"depths_coarse": dc, "depths_fine": df[..., :Nf], "sigma_coarse": sc},)
         return out
 
-    def sr_block(self, x, img, params, ws3, clamp=None):
-        """params: dict with conv0/conv1/torgb -> (weight, bias, affine_w, affine_b)."""
+    def conv2d(self, x, w, b=None, slope=None):
+        """torch.nn.Conv2d(k in {1,3}, stride 1, padding k//2) [+ LeakyReLU(slope)] for one image [Ci,H,W]."""
+        x, w = _f(x), _f(w)
+        b = None if b is None else _f(b)
+        Ci, H, W = x.shape
+        Co, k = w.shape[0], w.shape[-1]
+        y = np.empty((Co, H, W), np.float32)
+        rc = self.lib.r3d_oracle_conv2d(_p(x), Ci, H, W, _p(w), _p(b) if b is not None else None, Co, k,
+                                        ctypes.c_float(-1.0 if slope is None else slope), _p(y))
+        if rc != 0:
+            raise RuntimeError("r3d_oracle_conv2d failed")
+        return y
+
+    def conv_stack(self, x, plan, params):
+        """A FUSION_STACKS plan [(ci, co, k, lrelu)] with params [(w, b)]; torch.nn.LeakyReLU() default slope 0.01."""
+        for (ci, co, k, lrelu), (w, b) in zip(plan, params):
+            x = self.conv2d(x, w, b, 0.01 if lrelu else None)
+        return x
+
+    def sr_block(self, x, img, params, ws3, clamp=None, up=True):
+        """params: dict with conv0/conv1/torgb -> (weight, bias, affine_w, affine_b).  up=False: SynthesisBlockNoUp."""
         x, img, ws3 = _f(x), _f(img), _f(ws3)
         Ci, H, W = x.shape
         Co = params["conv1"][0].shape[0]
         WD = ws3.shape[-1]
-        xo = np.empty((Co, 2 * H, 2 * W), np.float32)
-        io = np.empty((3, 2 * H, 2 * W), np.float32)
+        m = 2 if up else 1
+        xo = np.empty((Co, m * H, m * W), np.float32)
+        io = np.empty((3, m * H, m * W), np.float32)
         args = []
         for k in ("conv0", "conv1", "torgb"):
             args += [_f(t) for t in params[k]]
         keep = args
-        rc = self.lib.r3d_oracle_sr_block(_p(x), _p(img), Ci, Co, H, W, WD, _p(ws3),
+        fn = self.lib.r3d_oracle_sr_block if up else self.lib.r3d_oracle_sr_block_noup
+        rc = fn(_p(x), _p(img), Ci, Co, H, W, WD, _p(ws3),
                                           *[_p(a) for a in keep],
                                           ctypes.c_float(-1.0 if clamp is None else clamp), _p(xo), _p(io))
         if rc != 0:

@@ -565,6 +565,85 @@ static void upsample2d_rgb(const float* img, int Cc, int Hh, int Ww, float* out 
             }
 }
 
+/* torch.nn.Conv2d(Ci, Co, k, 1, padding=k/2) [+ torch.nn.LeakyReLU(slope)] as the torso / background fusion stacks
+ * of SuperresolutionHybrid8XDC_Warp build them (modules/real3d/super_resolution/sr_with_ref.py:24-63), one image NCHW.
+ * k in {1, 3}; slope < 0 = no activation. */
+R3D_API int r3d_oracle_conv2d(const float* x, int Ci, int Hh, int Ww, const float* w /*[Co][Ci][k][k]*/, const float* b /*[Co] or NULL*/,
+                              int Co, int k, float slope, float* y)
+{
+    const size_t hw = (size_t)Hh * Ww;
+    if (k == 3) conv3x3(x, Ci, Hh, Ww, w, Co, y);
+    else if (k == 1) {
+#pragma omp parallel for schedule(static)
+        for (int o = 0; o < Co; ++o) {
+            float* yo = y + (size_t)o * hw;
+            memset(yo, 0, sizeof(float) * hw);
+            for (int c = 0; c < Ci; ++c) {
+                const float wv = w[(size_t)o * Ci + c];
+                const float* xc = x + (size_t)c * hw;
+                for (size_t i = 0; i < hw; ++i) yo[i] += wv * xc[i];
+            }
+        }
+    } else return -1;
+    for (int o = 0; o < Co; ++o) {
+        float* yo = y + (size_t)o * hw;
+        const float bo = b ? b[o] : 0.0f;
+        for (size_t i = 0; i < hw; ++i) {
+            float v = yo[i] + bo;
+            if (slope >= 0.0f && v < 0.0f) v *= slope;
+            yo[i] = v;
+        }
+    }
+    return 0;
+}
+
+/* One SynthesisBlockNoUp (architecture 'skip', in_channels != 0)  modules/eg3ds/models/superresolution.py:215-250:
+ *   conv0 :233 and conv1 :234 are both up=1 SynthesisLayers, img.add_(torgb(x)) :247 with no upsample (:241-243).
+ * x [Ci][H][W], img [3][H][W] -> x_out [Co][H][W], img_out [3][H][W]. */
+R3D_API int r3d_oracle_sr_block_noup(const float* x, const float* img, int Ci, int Co, int Hh, int Ww, int WD,
+                                     const float* ws3,
+                                     const float* c0_w, const float* c0_b, const float* c0_aw, const float* c0_ab,
+                                     const float* c1_w, const float* c1_b, const float* c1_aw, const float* c1_ab,
+                                     const float* rgb_w, const float* rgb_b, const float* rgb_aw, const float* rgb_ab,
+                                     float clampv, float* x_out, float* img_out)
+{
+    const size_t hw = (size_t)Hh * Ww;
+    float* st = (float*)malloc(sizeof(float) * (Ci > Co ? Ci : Co));
+    float* wm0 = (float*)malloc(sizeof(float) * (size_t)Co * Ci * 9);
+    float* wm1 = (float*)malloc(sizeof(float) * (size_t)Co * Co * 9);
+    float* wm2 = (float*)malloc(sizeof(float) * (size_t)3 * Co);
+    float* t0 = (float*)malloc(sizeof(float) * (size_t)Co * hw);
+    if (!st || !wm0 || !wm1 || !wm2 || !t0) return -1;
+
+    affine_styles(c0_aw, c0_ab, ws3 + 0 * WD, Ci, WD, st);
+    modulate(c0_w, st, Co, Ci, 9, 1, wm0);
+    conv3x3(x, Ci, Hh, Ww, wm0, Co, t0);
+    bias_act_inplace(t0, Co, hw, c0_b, 1, clampv);
+
+    affine_styles(c1_aw, c1_ab, ws3 + 1 * WD, Co, WD, st);
+    modulate(c1_w, st, Co, Co, 9, 1, wm1);
+    conv3x3(t0, Co, Hh, Ww, wm1, Co, x_out);
+    bias_act_inplace(x_out, Co, hw, c1_b, 1, clampv);
+
+    affine_styles(rgb_aw, rgb_ab, ws3 + 2 * WD, Co, WD, st);
+    const float g = (float)(1.0 / sqrt((double)Co));
+    for (int c = 0; c < Co; ++c) st[c] *= g;
+    modulate(rgb_w, st, 3, Co, 1, 0, wm2);
+    for (int o = 0; o < 3; ++o) {
+        float* yo = img_out + (size_t)o * hw;
+        const float* io = img + (size_t)o * hw;
+        for (size_t i = 0; i < hw; ++i) {
+            float acc = 0.0f;
+            for (int c = 0; c < Co; ++c) acc += x_out[(size_t)c * hw + i] * wm2[(size_t)o * Co + c];
+            float v = acc + rgb_b[o];
+            if (clampv >= 0.0f) { if (v > clampv) v = clampv; if (v < -clampv) v = -clampv; }
+            yo[i] = io[i] + v;
+        }
+    }
+    free(st); free(wm0); free(wm1); free(wm2); free(t0);
+    return 0;
+}
+
 /* One SynthesisBlock (architecture 'skip', in_channels != 0)  networks_stylegan2.py:429-473
  *   conv0 (up=2) :459, conv1 :460, upsample2d(img) :463-465, torgb add :466-469.
  * Parameter pointers are the raw module tensors; ws3 = [3][WD] (conv0, conv1, torgb).

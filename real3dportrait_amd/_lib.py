@@ -31,8 +31,13 @@ SIGNATURES = {
     "r3d_sr_block_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "r3d_sr_block_prepack": (c_int, [c_int, c_int, P, P, P, c_int, P]),
     "r3d_sr_block_styles": (c_int, [P, c_int, c_int, c_int, c_int] + [P] * 12 + [P, P]),
-    "r3d_sr_block_forward": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_float, P, c_int, P, c_size_t,
+    "r3d_sr_block_forward": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_float, P, c_int, P, c_size_t,
                                      P, c_int, P, c_size_t, P]),
+    "r3d_conv_prepacked_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "r3d_conv_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "r3d_conv_prepack": (c_int, [P, c_int, c_int, c_int, P, P]),
+    "r3d_conv_forward": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_size_t, P, c_size_t, P, c_size_t,
+                                 c_int, c_float, c_float, c_float, P, c_int, P, c_size_t, P, c_size_t, P]),
     "r3d_frames_to_u8": (c_int, [P, c_int, c_int, c_int, P, P]),
     "r3d_profile_configure": (c_int, [ctypes.c_uint32]),
     "r3d_profile_reset": (c_int, []),

@@ -476,16 +476,17 @@ extern "C" int r3d_sr_block_styles(const float* ws3, int N, int WD, int Cin, int
     return check_launch("sr_block_styles");
 }
 
-extern "C" int r3d_sr_block_forward(const void* prepacked, const void* styles, int N, int Cin, int Cout, int Hin, int Win,
+extern "C" int r3d_sr_block_forward(const void* prepacked, const void* styles, int N, int Cin, int Cout, int Hin, int Win, int up,
                                     const void* x, int x_format, const float* img, float clamp,
                                     void* x_out, int x_out_format, const float* next_scale, size_t next_scale_stride,
                                     float* img_out, int precision,
                                     void* workspace, size_t workspace_bytes, r3d_stream_t stream)
 {
     if (precision != R3D_SR_F32 && precision != R3D_SR_F16X3) { set_error("sr_block_forward: unknown precision %d", precision); return R3D_ERR_INVALID_ARG; }
-    if (!prepacked || !styles || !x || !img || !img_out || N <= 0 || Hin <= 0 || Win <= 0 || (Cin & 7) || (Cout % BLOCK_M)) {
+    if (!prepacked || !styles || !x || !img || !img_out || N <= 0 || Hin <= 0 || Win <= 0 || (Cin & 15) || (Cout % BLOCK_M) || (up != 0 && up != 1)) {
         set_error("sr_block_forward: bad argument"); return R3D_ERR_INVALID_ARG;
     }
+    if (!up && precision != R3D_SR_F16X3) { set_error("sr_block_forward: up=0 (SynthesisBlockNoUp) needs R3D_SR_F16X3"); return R3D_ERR_INVALID_ARG; }
     if (!workspace || workspace_bytes < r3d_sr_block_workspace_bytes(N, Cin, Cout, Hin, Win)) {
         set_error("sr_block_forward: workspace too small"); return R3D_ERR_WORKSPACE;
     }
@@ -499,7 +500,7 @@ extern "C" int r3d_sr_block_forward(const void* prepacked, const void* styles, i
     }
     hipStream_t st = (hipStream_t)stream;
     if (f16)
-        return sr_block_forward_f16x3(prepacked, styles, N, Cin, Cout, Hin, Win, x, x_format, img, clamp, x_out, x_out_format,
+        return sr_block_forward_f16x3(prepacked, styles, N, Cin, Cout, Hin, Win, up, x, x_format, img, clamp, x_out, x_out_format,
                                       next_scale, next_scale_stride, img_out, workspace, workspace_bytes, st);
 
     const SrStyleLayout L = sr_style_layout(Cin, Cout);
@@ -568,4 +569,42 @@ extern "C" int r3d_sr_block_forward(const void* prepacked, const void* styles, i
                            reinterpret_cast<float*>(x_out), Cout, OH * OW);
     }
     return check_launch("sr_block_forward");
+}
+
+// ---- generic convolution layer (see include/r3d_hip.h) -----------------------------------------------------------
+extern "C" size_t r3d_conv_prepacked_bytes(int Cin, int Cout, int ksize) { return r3d::conv_prepacked_bytes_f16x3(Cin, Cout, ksize); }
+extern "C" size_t r3d_conv_workspace_bytes(int N, int Cin, int H, int W) { return r3d::conv_workspace_bytes_f16x3(N, Cin, H, W); }
+
+extern "C" int r3d_conv_prepack(const float* weight, int Cin, int Cout, int ksize, void* prepacked, r3d_stream_t stream)
+{
+    using namespace r3d;
+    if (!weight || !prepacked || Cin <= 0 || Cout <= 0 || (ksize != 1 && ksize != 3)) { set_error("conv_prepack: bad argument"); return R3D_ERR_INVALID_ARG; }
+    return conv_prepack_f16x3(weight, Cin, Cout, ksize, prepacked, (hipStream_t)stream);
+}
+
+extern "C" int r3d_conv_forward(const void* prepacked, int N, int Cin, int Cout, int H, int W, int ksize,
+                                const void* x, int x_format, const float* in_scale, size_t in_scale_stride,
+                                const float* out_scale, size_t out_scale_stride, const float* bias, size_t bias_stride,
+                                int act, float act_slope, float act_gain, float clamp,
+                                void* y, int y_format, const float* next_scale, size_t next_scale_stride,
+                                void* workspace, size_t workspace_bytes, r3d_stream_t stream)
+{
+    using namespace r3d;
+    if (!prepacked || !x || !y || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (ksize != 1 && ksize != 3)) {
+        set_error("conv_forward: bad argument"); return R3D_ERR_INVALID_ARG;
+    }
+    if (x_format < R3D_FMT_NCHW || x_format > R3D_FMT_SPLIT || y_format < R3D_FMT_NCHW || y_format > R3D_FMT_SPLIT) {
+        set_error("conv_forward: unsupported activation format (x %d, y %d)", x_format, y_format); return R3D_ERR_INVALID_ARG;
+    }
+    if (Cout & 3) { set_error("conv_forward: Cout = %d must be a multiple of 4", Cout); return R3D_ERR_INVALID_ARG; }
+    if ((x_format != R3D_FMT_NCHW && (Cin & 15)) || (y_format != R3D_FMT_NCHW && (Cout & 7))) {
+        set_error("conv_forward: blocked formats need Cin %% 16 == 0 and Cout %% 8 == 0 (Cin %d, Cout %d)", Cin, Cout); return R3D_ERR_INVALID_ARG;
+    }
+    if (x_format == R3D_FMT_SPLIT && in_scale) { set_error("conv_forward: a SPLIT input is already scaled (in_scale must be null)"); return R3D_ERR_INVALID_ARG; }
+    if (x_format != R3D_FMT_SPLIT && (!workspace || workspace_bytes < r3d_conv_workspace_bytes(N, Cin, H, W))) {
+        set_error("conv_forward: workspace too small"); return R3D_ERR_WORKSPACE;
+    }
+    return conv_forward_f16x3(prepacked, N, Cin, Cout, H, W, ksize, x, x_format, in_scale, in_scale_stride, out_scale, out_scale_stride,
+                              bias, bias_stride, act, act_slope, act_gain, clamp, y, y_format, next_scale, next_scale_stride,
+                              workspace, (hipStream_t)stream);
 }

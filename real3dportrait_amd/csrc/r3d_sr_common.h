@@ -42,9 +42,19 @@ void sr_fill_conv3x3_phase(ConvPhase* ph, int H, int W);
 
 // f16x3 implementation (r3d_sr_f16x3.hip)
 int sr_prepack_f16x3(int Cin, int Cout, const float* c0_w, const float* c1_w, void* prepacked, hipStream_t st);
-int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int Cin, int Cout, int Hin, int Win,
+int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int Cin, int Cout, int Hin, int Win, int up,
                            const void* x, int x_format, const float* img, float clamp,
                            void* x_out, int x_out_format, const float* next_scale, size_t next_scale_stride,
                            float* img_out, void* workspace, size_t workspace_bytes, hipStream_t st);
+
+size_t conv_prepacked_bytes_f16x3(int Cin, int Cout, int ksize);
+int conv_prepack_f16x3(const float* w, int Cin, int Cout, int ksize, void* prepacked, hipStream_t st);
+size_t conv_workspace_bytes_f16x3(int N, int Cin, int H, int W);
+int conv_forward_f16x3(const void* prepacked, int N, int Cin, int Cout, int H, int W, int ksize,
+                       const void* x, int x_format, const float* in_scale, size_t in_scale_stride,
+                       const float* out_scale, size_t out_scale_stride, const float* bias, size_t bias_stride,
+                       int act, float slope, float gain, float clamp,
+                       void* y, int y_format, const float* next_scale, size_t next_scale_stride,
+                       void* workspace, hipStream_t st);
 
 }  // namespace r3d

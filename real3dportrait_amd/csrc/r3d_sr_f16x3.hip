@@ -36,26 +36,30 @@ __device__ __forceinline__ void split1(float v, _Float16& hi, _Float16& lo)
 }
 
 // ---- weights: [tap][ci/8][hi|lo][cout] x 8 halfs (hi and lo in separate 16-byte planes: conflict-free ds_read_b128) ----
-__global__ void sr_prepack_f16_kernel(const float* __restrict__ w, int Ci, int Cout, uint4* __restrict__ out)
+__global__ void sr_prepack_f16_kernel(const float* __restrict__ w, int CiReal, int CoutReal, int ntaps, int Ci, int Cout,
+                                      uint4* __restrict__ out)
 {
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // (tap, chunk, cout)
-    const size_t total = (size_t)9 * (Ci / 8) * Cout;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // (tap, chunk, cout) in the PADDED index space
+    const size_t total = (size_t)ntaps * (Ci / 8) * Cout;
     if (e >= total) return;
     const int co = e % Cout;
     const int chunk = (e / Cout) % (Ci / 8);
     const int tap = (int)(e / Cout / (Ci / 8));
-    const float* src = w + ((size_t)co * Ci + chunk * 8) * 9 + tap;
     h8 hi, lo;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { _Float16 a, b; split1(src[9 * j], a, b); hi[j] = a; lo[j] = b; }
+    for (int j = 0; j < 8; ++j) {
+        const int ci = chunk * 8 + j;
+        const float v = (co < CoutReal && ci < CiReal) ? w[((size_t)co * CiReal + ci) * ntaps + tap] : 0.f;
+        _Float16 a, b; split1(v, a, b); hi[j] = a; lo[j] = b;
+    }
     const size_t base = ((size_t)tap * (Ci / 8) + chunk) * 2 * Cout + co;
     out[base] = *reinterpret_cast<uint4*>(&hi);
     out[base + Cout] = *reinterpret_cast<uint4*>(&lo);
 }
 
-// ---- input conversion: fp32 (NCHW or CB8) * style -> SPLIT ------------------------------------------------------
+// ---- input conversion: fp32 (NCHW or CB8) * style -> SPLIT; channels >= Creal are zero padding (Cin = 3 -> 8) -------
 __global__ void to_split_kernel(const float* __restrict__ src, int cb8, const float* __restrict__ scale, size_t scale_stride_n,
-                                uint4* __restrict__ dst, int C, int HW)
+                                uint4* __restrict__ dst, int C, int Creal, int HW)
 {
     const int n = blockIdx.z, cb = blockIdx.y;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -66,14 +70,16 @@ __global__ void to_split_kernel(const float* __restrict__ src, int cb8, const fl
         const float4 a = s4[0], b = s4[1];
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
     } else {
-        const float* s = src + ((size_t)n * C + cb * 8) * HW + p;
+        const float* s = src + ((size_t)n * Creal + cb * 8) * HW + p;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] = s[(size_t)c * HW];
+        for (int c = 0; c < 8; ++c) v[c] = (cb * 8 + c < Creal) ? s[(size_t)c * HW] : 0.f;
     }
-    const float* sc = scale + n * scale_stride_n + cb * 8;
     h8 hi, lo;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) { _Float16 a, b; split1(v[c] * sc[c], a, b); hi[c] = a; lo[c] = b; }
+    for (int c = 0; c < 8; ++c) {
+        const float sc = (scale && cb * 8 + c < Creal) ? scale[n * scale_stride_n + cb * 8 + c] : 1.f;
+        _Float16 a, b; split1(v[c] * sc, a, b); hi[c] = a; lo[c] = b;
+    }
     const size_t plane = (size_t)(C / 8) * HW;
     uint4* d = dst + (size_t)n * 2 * plane + (size_t)cb * HW + p;
     d[0] = *reinterpret_cast<uint4*>(&hi);
@@ -83,13 +89,16 @@ __global__ void to_split_kernel(const float* __restrict__ src, int cb8, const fl
 // ---- conv ----------------------------------------------------------------------------------------------------
 struct Conv2Args {
     const uint4* x; size_t x_stride_n;        // SPLIT input (hi plane, lo plane), per-n stride in uint4 units
-    const uint4* wp;                          // split prepacked weights
-    const float* out_scale; const float* bias; size_t vec_stride_n;    // demod d[cout], bias[cout] (styles buffer)
-    float* y_f32; size_t y_f32_stride_n; int OH, OW;                   // fp32 CB8 output (T buffer / x_out) or null
-    uint4* y_split; size_t y_split_stride_n;                           // SPLIT output scaled by next_scale, or null
+    const uint4* wp;                          // split prepacked weights [tap][Cin/8][hi|lo][Cout]
+    const float* out_scale; size_t out_scale_stride_n;     // per-cout multiplier (demodulation) or null (= 1)
+    const float* bias; size_t bias_stride_n;               // per-cout bias or null
+    float* y_f32; size_t y_f32_stride_n; int OH, OW;       // fp32 CB8 output (T buffer / x_out) or null
+    float* y_nchw; size_t y_nchw_stride_n;                 // fp32 NCHW output or null
+    uint4* y_split; size_t y_split_stride_n;               // SPLIT output scaled by next_scale (null = 1), or null
     const float* next_scale; size_t next_scale_stride_n;
-    const float* wrgb; float* rgb_partial; size_t rgbp_stride_n;       // toRGB partials [Cout/128][3][OH*OW] or null
-    int Cin, Cout, H, W, nphase, act; float clamp;
+    const float* wrgb; size_t wrgb_stride_n; float* rgb_partial; size_t rgbp_stride_n;   // toRGB partials [Cout/128][3][OH*OW] or null
+    int Cin, Cout, CoutReal, H, W, nphase;    // Cout: padded to 128 (weight layout); CoutReal: channels that exist in the outputs
+    int act; float act_slope, act_gain, clamp; // act: leaky-relu(slope) * gain after the bias; clamp < 0: off
     ConvPhase ph[4];
 };
 
@@ -260,15 +269,16 @@ __device__ __forceinline__ void conv2_block(const Conv2Args& a, const ConvPhase&
     uint4* patch = lds;      // LDS is reused by the epilogue's toRGB reduction
 
     // ---- epilogue ------------------------------------------------------------------------------------------------
-    const float* B = a.bias ? a.bias + (size_t)n * a.vec_stride_n : nullptr;
-    const float* D = a.out_scale + (size_t)n * a.vec_stride_n;
+    const float* B = a.bias ? a.bias + (size_t)n * a.bias_stride_n : nullptr;
+    const float* D = a.out_scale ? a.out_scale + (size_t)n * a.out_scale_stride_n : nullptr;
     const float* NS = a.next_scale ? a.next_scale + (size_t)n * a.next_scale_stride_n : nullptr;
     const bool do_rgb = FULL_EPI && a.rgb_partial != nullptr;
     float rgbp[NT][3];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { rgbp[nt][0] = 0.f; rgbp[nt][1] = 0.f; rgbp[nt][2] = 0.f; }
-    const size_t oplane = (size_t)(a.Cout >> 3) * a.OH * a.OW;
+    const size_t oplane = (size_t)(a.CoutReal >> 3) * a.OH * a.OW;
     float* Yf = a.y_f32 ? a.y_f32 + (size_t)n * a.y_f32_stride_n + ph.out_off : nullptr;
+    float* Yn = (FULL_EPI && a.y_nchw) ? a.y_nchw + (size_t)n * a.y_nchw_stride_n : nullptr;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int i = i0 + row0 + nt * 2 + prow, j = j0 + pcol;
@@ -279,25 +289,26 @@ __device__ __forceinline__ void conv2_block(const Conv2Args& a, const ConvPhase&
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int co = m0 + 64 * wm + 32 * mt + 8 * g + 4 * h;
-                const float4 d4 = *reinterpret_cast<const float4*>(D + co);
-                const float dv[4] = {d4.x, d4.y, d4.z, d4.w};
-                float bv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (FULL_EPI && a.act) { const float4 b4 = *reinterpret_cast<const float4*>(B + co); bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w; }
+                if (co >= a.CoutReal) continue;                       // channels that only exist as weight padding
+                float dv[4] = {1.f, 1.f, 1.f, 1.f}, bv[4] = {0.f, 0.f, 0.f, 0.f};
+                if (D) { const float4 d4 = *reinterpret_cast<const float4*>(D + co); dv[0] = d4.x; dv[1] = d4.y; dv[2] = d4.z; dv[3] = d4.w; }
+                if (FULL_EPI && B) { const float4 b4 = *reinterpret_cast<const float4*>(B + co); bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w; }
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float t = acc[mt][nt][4 * g + r] * dv[r];
-                    if (FULL_EPI && a.act) {
+                    if (FULL_EPI) {
                         t += bv[r];
-                        t = (t < 0.f ? t * 0.2f : t) * 1.4142135623730951f;
+                        if (a.act) t = (t < 0.f ? t * a.act_slope : t) * a.act_gain;
                         if (a.clamp >= 0.f) t = fminf(fmaxf(t, -a.clamp), a.clamp);
                     }
                     v[r] = t;
                 }
                 if (do_rgb) {
-                    const float4 w0 = *reinterpret_cast<const float4*>(a.wrgb + (size_t)n * a.vec_stride_n + co);
-                    const float4 w1 = *reinterpret_cast<const float4*>(a.wrgb + (size_t)n * a.vec_stride_n + a.Cout + co);
-                    const float4 w2 = *reinterpret_cast<const float4*>(a.wrgb + (size_t)n * a.vec_stride_n + 2 * a.Cout + co);
+                    const float* wr = a.wrgb + (size_t)n * a.wrgb_stride_n;
+                    const float4 w0 = *reinterpret_cast<const float4*>(wr + co);
+                    const float4 w1 = *reinterpret_cast<const float4*>(wr + a.CoutReal + co);
+                    const float4 w2 = *reinterpret_cast<const float4*>(wr + 2 * a.CoutReal + co);
                     rgbp[nt][0] += v[0] * w0.x + v[1] * w0.y + v[2] * w0.z + v[3] * w0.w;
                     rgbp[nt][1] += v[0] * w1.x + v[1] * w1.y + v[2] * w1.z + v[3] * w1.w;
                     rgbp[nt][2] += v[0] * w2.x + v[1] * w2.y + v[2] * w2.z + v[3] * w2.w;
@@ -305,9 +316,14 @@ __device__ __forceinline__ void conv2_block(const Conv2Args& a, const ConvPhase&
                 if (!inside) continue;
                 const size_t pix = ((size_t)(co >> 3) * a.OH + oy) * a.OW + ox;
                 if (Yf) *reinterpret_cast<float4*>(Yf + pix * 8 + (co & 7)) = make_float4(v[0], v[1], v[2], v[3]);
+                if (Yn) {
+                    const size_t hw = (size_t)a.OH * a.OW, p0 = (size_t)oy * a.OW + ox;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Yn[(size_t)(co + r) * hw + p0] = v[r];
+                }
                 if (FULL_EPI && a.y_split) {
-                    const float4 s4 = *reinterpret_cast<const float4*>(NS + co);
-                    const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
+                    float sv[4] = {1.f, 1.f, 1.f, 1.f};
+                    if (NS) { const float4 s4 = *reinterpret_cast<const float4*>(NS + co); sv[0] = s4.x; sv[1] = s4.y; sv[2] = s4.z; sv[3] = s4.w; }
                     h4 hi, lo;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { _Float16 x0, x1; split1(v[r] * sv[r], x0, x1); hi[r] = x0; lo[r] = x1; }
@@ -356,6 +372,14 @@ __global__ __launch_bounds__(128 * WN, OCC) void conv_mfma_f16x3_kernel(Conv2Arg
 {
     __shared__ uint4 lds[F_LDS_UINT4];
     conv2_block<9, true, WN, NT>(a, a.ph[0], blockIdx.z, lds);
+}
+
+// 1x1 conv with the full epilogue (nn.Conv2d(k=1) layers of the torso/background fusion stack)
+template <int WN, int NT, int OCC>
+__global__ __launch_bounds__(128 * WN, OCC) void conv1x1_mfma_f16x3_kernel(Conv2Args a)
+{
+    __shared__ uint4 lds[F_LDS_UINT4];
+    conv2_block<1, true, WN, NT>(a, a.ph[0], blockIdx.z, lds);
 }
 
 // stride-2 transposed conv phases (4/2/2/1 taps)
@@ -453,7 +477,7 @@ __global__ void fir_bias_act_split_kernel(const float* __restrict__ T, size_t t_
 // ---- image finalize: img_out = upsample2d(img_in) + bias + sum_m partial[m]  (networks_stylegan2.py:463-469) ----
 __global__ void rgb_finalize_kernel(const float* __restrict__ img_prev, const float* __restrict__ partial, size_t part_stride_n,
                                     int nparts, const float* __restrict__ brgb, size_t vec_stride_n,
-                                    float* __restrict__ img_out, int H, int W, float clamp)
+                                    float* __restrict__ img_out, int H, int W, float clamp, int up)
 {
     const int n = blockIdx.y;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -470,13 +494,18 @@ __global__ void rgb_finalize_kernel(const float* __restrict__ img_prev, const fl
         float t = brgb[(size_t)n * vec_stride_n + c];
         for (int m = 0; m < nparts; ++m) t += partial[(size_t)n * part_stride_n + ((size_t)m * 3 + c) * H * W + p];
         if (clamp >= 0.f) t = fminf(fmaxf(t, -clamp), clamp);
-        const float* I = img_prev + ((size_t)n * 3 + c) * Hh * Wh;
-        float up = 0.f;
-        if (vr0 && vc0) up += I[(size_t)r0 * Wh + c0] * (wy0 * wx0);
-        if (vr0 && vc1) up += I[(size_t)r0 * Wh + c1] * (wy0 * wx1);
-        if (vr1 && vc0) up += I[(size_t)r1 * Wh + c0] * (wy1 * wx0);
-        if (vr1 && vc1) up += I[(size_t)r1 * Wh + c1] * (wy1 * wx1);
-        img_out[((size_t)n * 3 + c) * H * W + p] = up + t;
+        float upv;
+        if (up) {
+            const float* I = img_prev + ((size_t)n * 3 + c) * Hh * Wh;
+            upv = 0.f;
+            if (vr0 && vc0) upv += I[(size_t)r0 * Wh + c0] * (wy0 * wx0);
+            if (vr0 && vc1) upv += I[(size_t)r0 * Wh + c1] * (wy0 * wx1);
+            if (vr1 && vc0) upv += I[(size_t)r1 * Wh + c0] * (wy1 * wx0);
+            if (vr1 && vc1) upv += I[(size_t)r1 * Wh + c1] * (wy1 * wx1);
+        } else {
+            upv = img_prev[((size_t)n * 3 + c) * H * W + p];        // SynthesisBlockNoUp: img.add_(y) at the same resolution
+        }
+        img_out[((size_t)n * 3 + c) * H * W + p] = upv + t;
     }
 }
 
@@ -497,9 +526,9 @@ int sr_prepack_f16x3(int Cin, int Cout, const float* c0_w, const float* c1_w, vo
 {
     float* out = reinterpret_cast<float*>(prepacked);
     const size_t m0 = (size_t)9 * (Cin / 8) * Cout, m1 = (size_t)9 * (Cout / 8) * Cout;
-    hipLaunchKernelGGL(sr_prepack_f16_kernel, dim3((unsigned)((m0 + 255) / 256)), dim3(256), 0, st, c0_w, Cin, Cout,
+    hipLaunchKernelGGL(sr_prepack_f16_kernel, dim3((unsigned)((m0 + 255) / 256)), dim3(256), 0, st, c0_w, Cin, Cout, 9, Cin, Cout,
                        reinterpret_cast<uint4*>(out));
-    hipLaunchKernelGGL(sr_prepack_f16_kernel, dim3((unsigned)((m1 + 255) / 256)), dim3(256), 0, st, c1_w, Cout, Cout,
+    hipLaunchKernelGGL(sr_prepack_f16_kernel, dim3((unsigned)((m1 + 255) / 256)), dim3(256), 0, st, c1_w, Cout, Cout, 9, Cout, Cout,
                        reinterpret_cast<uint4*>(out + (size_t)9 * Cin * Cout));
     return check_launch("sr_block_prepack");
 }
@@ -508,16 +537,21 @@ static void launch_conv2(Conv2Args& a, int tiles, int N, hipStream_t st)
 {
     dim3 grid(tiles, a.Cout / BLOCK_M, N * a.nphase);
     static const int shape = getenv("R3D_CONV_SHAPE") ? atoi(getenv("R3D_CONV_SHAPE")) : 0;   // tuning switch, default 0
+    const int kind = a.nphase > 1 ? 2 : (a.ph[0].ntaps == 9 ? 0 : 1);      // 0: 3x3 conv, 1: 1x1 conv, 2: transposed-conv phases
     if (shape == 1) {           // 4 waves x (64 couts x 128 px), 2 blocks/CU
-        if (a.nphase == 1) hipLaunchKernelGGL((conv_mfma_f16x3_kernel<2, 4, 2>), grid, dim3(256), 0, st, a);
+        if (kind == 0) hipLaunchKernelGGL((conv_mfma_f16x3_kernel<2, 4, 2>), grid, dim3(256), 0, st, a);
+        else if (kind == 1) hipLaunchKernelGGL((conv1x1_mfma_f16x3_kernel<2, 4, 2>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((tconv_mfma_f16x3_kernel<2, 4, 2>), grid, dim3(256), 0, st, a);
     } else {                    // 8 waves x (64 couts x 64 px): 4 waves/SIMD at 2 blocks/CU
-        if (a.nphase == 1) hipLaunchKernelGGL((conv_mfma_f16x3_kernel<4, 2, 4>), grid, dim3(512), 0, st, a);
+        if (kind == 0) hipLaunchKernelGGL((conv_mfma_f16x3_kernel<4, 2, 4>), grid, dim3(512), 0, st, a);
+        else if (kind == 1) hipLaunchKernelGGL((conv1x1_mfma_f16x3_kernel<4, 2, 4>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((tconv_mfma_f16x3_kernel<4, 2, 4>), grid, dim3(512), 0, st, a);
     }
 }
 
-int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int Cin, int Cout, int Hin, int Win,
+static int tiles_of(int H, int W) { return ((W + F_TILE_W - 1) / F_TILE_W) * ((H + F_TILE_H - 1) / F_TILE_H); }
+
+int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int Cin, int Cout, int Hin, int Win, int up,
                            const void* x, int x_format, const float* img, float clamp,
                            void* x_out, int x_out_format, const float* next_scale, size_t next_scale_stride,
                            float* img_out, void* workspace, size_t workspace_bytes, hipStream_t st)
@@ -526,79 +560,147 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
     const SrStyleLayout L = sr_style_layout(Cin, Cout);
     const float* pk = reinterpret_cast<const float*>(styles);
     const float* wpk = reinterpret_cast<const float*>(prepacked);
-    const int OH = 2 * Hin, OW = 2 * Win;
+    const int OH = up ? 2 * Hin : Hin, OW = up ? 2 * Win : Win;
     char* wsb = reinterpret_cast<char*>(workspace);
     uint4* xin = reinterpret_cast<uint4*>(wsb); wsb += align256((size_t)N * Cin * Hin * Win * 4);
     const int PH = Hin + 1, PW = Win + 1;
     const size_t pplane = (size_t)Cout * PH * PW;                 // floats per phase plane
     float* T = reinterpret_cast<float*>(wsb);   wsb += align256((size_t)N * 4 * pplane * 4);
-    uint4* y0 = reinterpret_cast<uint4*>(wsb);  wsb += align256((size_t)N * Cout * OH * OW * 4);
+    uint4* y0 = reinterpret_cast<uint4*>(wsb);  wsb += align256((size_t)N * Cout * 4 * Hin * Win * 4);
     float* xo = reinterpret_cast<float*>(wsb);                    // fp32 CB8 x (only when an fp32 x_out is requested)
-    float* rgbp = reinterpret_cast<float*>(wsb + align256((size_t)N * Cout * OH * OW * 4));
+    float* rgbp = reinterpret_cast<float*>(wsb + align256((size_t)N * Cout * 4 * Hin * Win * 4));
 
     const uint4* xs = reinterpret_cast<const uint4*>(x);
     if (x_format != R3D_FMT_SPLIT) {
         ProfScope ps(R3D_PROF_LAYOUT, st);
         hipLaunchKernelGGL(to_split_kernel, dim3((Hin * Win + 255) / 256, Cin / 8, N), dim3(256), 0, st,
-                           reinterpret_cast<const float*>(x), x_format == R3D_FMT_CB8 ? 1 : 0, pk + L.s0, L.total, xin, Cin, Hin * Win);
+                           reinterpret_cast<const float*>(x), x_format == R3D_FMT_CB8 ? 1 : 0, pk + L.s0, L.total, xin, Cin, Cin, Hin * Win);
         xs = xin;
     }
-    // ---- conv0: stride-2 transposed conv as 4 phases -> T (demodulated, fp32) ------------------------------------
-    {
-        Conv2Args a = {};
-        a.x = xs; a.x_stride_n = (size_t)Cin / 8 * Hin * Win * 2;
-        a.wp = reinterpret_cast<const uint4*>(wpk);
-        a.out_scale = pk + L.d0; a.bias = nullptr; a.vec_stride_n = L.total;
-        a.y_f32 = T; a.y_f32_stride_n = 4 * pplane; a.OH = PH; a.OW = PW;
-        a.Cin = Cin; a.Cout = Cout; a.H = Hin; a.W = Win; a.nphase = 4; a.act = 0; a.clamp = -1.f;
-        sr_fill_tconv_phases(a.ph, Hin, Win);
-        for (int p = 0; p < 4; ++p) {                               // phase-major T: contiguous stores per phase
-            a.ph[p].oy_mul = 1; a.ph[p].oy_add = 0; a.ph[p].ox_mul = 1; a.ph[p].ox_add = 0; a.ph[p].out_off = p * pplane;
+    if (up) {
+        // ---- conv0: stride-2 transposed conv as 4 phases -> T (demodulated, fp32), then FIR + bias + lrelu -> SPLIT ----
+        {
+            Conv2Args a = {};
+            a.x = xs; a.x_stride_n = (size_t)Cin / 8 * Hin * Win * 2;
+            a.wp = reinterpret_cast<const uint4*>(wpk);
+            a.out_scale = pk + L.d0; a.out_scale_stride_n = L.total;
+            a.y_f32 = T; a.y_f32_stride_n = 4 * pplane; a.OH = PH; a.OW = PW;
+            a.Cin = Cin; a.Cout = Cout; a.CoutReal = Cout; a.H = Hin; a.W = Win; a.nphase = 4; a.act = 0; a.clamp = -1.f;
+            sr_fill_tconv_phases(a.ph, Hin, Win);
+            int maxtiles = 0;
+            for (int p = 0; p < 4; ++p) {                               // phase-major T: contiguous stores per phase
+                a.ph[p].oy_mul = 1; a.ph[p].oy_add = 0; a.ph[p].ox_mul = 1; a.ph[p].ox_add = 0; a.ph[p].out_off = p * pplane;
+                const int tiles = tiles_of(a.ph[p].outH, a.ph[p].outW);
+                if (tiles > maxtiles) maxtiles = tiles;
+            }
+            ProfScope ps(R3D_PROF_CONV, st);
+            launch_conv2(a, maxtiles, N, st);
         }
-        int maxtiles = 0;
-        for (int p = 0; p < 4; ++p) {
-            const int tiles = ((a.ph[p].outW + F_TILE_W - 1) / F_TILE_W) * ((a.ph[p].outH + F_TILE_H - 1) / F_TILE_H);
-            if (tiles > maxtiles) maxtiles = tiles;
-        }
-        ProfScope ps(R3D_PROF_CONV, st);
-        launch_conv2(a, maxtiles, N, st);
-    }
-    {
         ProfScope ps(R3D_PROF_FIR, st);
         hipLaunchKernelGGL(fir_bias_act_split_kernel, dim3((Hin * Win + 255) / 256, Cout / 8, N), dim3(256), 0, st,
                            T, 4 * pplane, pk + L.b0, pk + L.s1, L.total, y0, (size_t)Cout / 8 * OH * OW * 2, Cout, Hin, Win, clamp);
+    } else {
+        // ---- conv0 of SynthesisBlockNoUp (superresolution.py:159-258): plain modulated 3x3 conv -> SPLIT for conv1 ----
+        Conv2Args a = {};
+        a.x = xs; a.x_stride_n = (size_t)Cin / 8 * Hin * Win * 2;
+        a.wp = reinterpret_cast<const uint4*>(wpk);
+        a.out_scale = pk + L.d0; a.out_scale_stride_n = L.total; a.bias = pk + L.b0; a.bias_stride_n = L.total;
+        a.OH = OH; a.OW = OW;
+        a.y_split = y0; a.y_split_stride_n = (size_t)Cout / 8 * OH * OW * 2; a.next_scale = pk + L.s1; a.next_scale_stride_n = L.total;
+        a.Cin = Cin; a.Cout = Cout; a.CoutReal = Cout; a.H = Hin; a.W = Win; a.nphase = 1;
+        a.act = 1; a.act_slope = 0.2f; a.act_gain = 1.4142135623730951f; a.clamp = clamp;
+        sr_fill_conv3x3_phase(a.ph, OH, OW);
+        ProfScope ps(R3D_PROF_CONV, st);
+        launch_conv2(a, tiles_of(OH, OW), N, st);
     }
     // ---- conv1 (3x3) + bias/lrelu + toRGB partials (+ optional x outputs) ------------------------------------------
-    const bool want_f32 = x_out && (x_out_format == R3D_FMT_NCHW || x_out_format == R3D_FMT_CB8);
     {
         Conv2Args a = {};
         a.x = y0; a.x_stride_n = (size_t)Cout / 8 * OH * OW * 2;
         a.wp = reinterpret_cast<const uint4*>(wpk + (size_t)9 * Cin * Cout);
-        a.out_scale = pk + L.d1; a.bias = pk + L.b1; a.vec_stride_n = L.total;
+        a.out_scale = pk + L.d1; a.out_scale_stride_n = L.total; a.bias = pk + L.b1; a.bias_stride_n = L.total;
         a.OH = OH; a.OW = OW;
-        if (want_f32) { a.y_f32 = (x_out_format == R3D_FMT_CB8) ? reinterpret_cast<float*>(x_out) : xo; a.y_f32_stride_n = (size_t)Cout * OH * OW; }
+        if (x_out && x_out_format == R3D_FMT_CB8) { a.y_f32 = reinterpret_cast<float*>(x_out); a.y_f32_stride_n = (size_t)Cout * OH * OW; }
+        if (x_out && x_out_format == R3D_FMT_NCHW) { a.y_nchw = reinterpret_cast<float*>(x_out); a.y_nchw_stride_n = (size_t)Cout * OH * OW; }
         if (x_out && x_out_format == R3D_FMT_SPLIT) {
             a.y_split = reinterpret_cast<uint4*>(x_out); a.y_split_stride_n = (size_t)Cout / 8 * OH * OW * 2;
             a.next_scale = next_scale; a.next_scale_stride_n = next_scale_stride;
         }
-        a.wrgb = pk + L.wrgb; a.rgb_partial = rgbp; a.rgbp_stride_n = (size_t)(Cout / BLOCK_M) * 3 * OH * OW;
-        a.Cin = Cout; a.Cout = Cout; a.H = OH; a.W = OW; a.nphase = 1; a.act = 1; a.clamp = clamp;
+        a.wrgb = pk + L.wrgb; a.wrgb_stride_n = L.total; a.rgb_partial = rgbp; a.rgbp_stride_n = (size_t)(Cout / BLOCK_M) * 3 * OH * OW;
+        a.Cin = Cout; a.Cout = Cout; a.CoutReal = Cout; a.H = OH; a.W = OW; a.nphase = 1;
+        a.act = 1; a.act_slope = 0.2f; a.act_gain = 1.4142135623730951f; a.clamp = clamp;
         sr_fill_conv3x3_phase(a.ph, OH, OW);
-        const int tiles = ((OW + F_TILE_W - 1) / F_TILE_W) * ((OH + F_TILE_H - 1) / F_TILE_H);
         ProfScope ps(R3D_PROF_CONV, st);
-        launch_conv2(a, tiles, N, st);
+        launch_conv2(a, tiles_of(OH, OW), N, st);
     }
+    (void)xo;
     {
         ProfScope ps(R3D_PROF_TORGB, st);
         hipLaunchKernelGGL(rgb_finalize_kernel, dim3((OH * OW + 255) / 256, N), dim3(256), 0, st, img, rgbp,
-                           (size_t)(Cout / BLOCK_M) * 3 * OH * OW, Cout / BLOCK_M, pk + L.brgb, L.total, img_out, OH, OW, clamp);
-    }
-    if (x_out && x_out_format == R3D_FMT_NCHW) {
-        ProfScope ps(R3D_PROF_LAYOUT, st);
-        hipLaunchKernelGGL(cb8_to_nchw2_kernel, dim3((OH * OW + 255) / 256, Cout / 8, N), dim3(256), 0, st, xo,
-                           reinterpret_cast<float*>(x_out), Cout, OH * OW);
+                           (size_t)(Cout / BLOCK_M) * 3 * OH * OW, Cout / BLOCK_M, pk + L.brgb, L.total, img_out, OH, OW, clamp, up);
     }
     return check_launch("sr_block_forward(f16x3)");
+}
+
+// ---- generic convolution layer (nn.Conv2d k = 1 | 3, stride 1, padding k/2, + bias + optional LeakyReLU) on the same kernel:
+// the torso / background fusion stacks of SuperresolutionHybrid8XDC_Warp (modules/real3d/super_resolution/sr_with_ref.py:24-63)
+static inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
+
+size_t conv_prepacked_bytes_f16x3(int Cin, int Cout, int ksize)
+{
+    return (size_t)(ksize * ksize) * pad_to(Cin, 16) * pad_to(Cout, BLOCK_M) * sizeof(float);
+}
+
+int conv_prepack_f16x3(const float* w, int Cin, int Cout, int ksize, void* prepacked, hipStream_t st)
+{
+    const int Ci = pad_to(Cin, 16), Co = pad_to(Cout, BLOCK_M), nt = ksize * ksize;
+    const size_t m = (size_t)nt * (Ci / 8) * Co;
+    ProfScope ps(R3D_PROF_PACK, st);
+    hipLaunchKernelGGL(sr_prepack_f16_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, w, Cin, Cout, nt, Ci, Co,
+                       reinterpret_cast<uint4*>(prepacked));
+    return check_launch("conv_prepack");
+}
+
+size_t conv_workspace_bytes_f16x3(int N, int Cin, int H, int W)
+{
+    return align256((size_t)N * pad_to(Cin, 16) * H * W * 4) + 256;
+}
+
+int conv_forward_f16x3(const void* prepacked, int N, int Cin, int Cout, int H, int W, int ksize,
+                       const void* x, int x_format, const float* in_scale, size_t in_scale_stride,
+                       const float* out_scale, size_t out_scale_stride, const float* bias, size_t bias_stride,
+                       int act, float slope, float gain, float clamp,
+                       void* y, int y_format, const float* next_scale, size_t next_scale_stride,
+                       void* workspace, hipStream_t st)
+{
+    const int Ci = pad_to(Cin, 16), Co = pad_to(Cout, BLOCK_M);
+    const uint4* xs = reinterpret_cast<const uint4*>(x);
+    if (x_format != R3D_FMT_SPLIT) {
+        uint4* xin = reinterpret_cast<uint4*>(workspace);
+        ProfScope ps(R3D_PROF_LAYOUT, st);
+        hipLaunchKernelGGL(to_split_kernel, dim3((H * W + 255) / 256, Ci / 8, N), dim3(256), 0, st,
+                           reinterpret_cast<const float*>(x), x_format == R3D_FMT_CB8 ? 1 : 0, in_scale, in_scale_stride, xin, Ci, Cin, H * W);
+        xs = xin;
+    }
+    Conv2Args a = {};
+    a.x = xs; a.x_stride_n = (size_t)Ci / 8 * H * W * 2;
+    a.wp = reinterpret_cast<const uint4*>(prepacked);
+    a.out_scale = out_scale; a.out_scale_stride_n = out_scale_stride; a.bias = bias; a.bias_stride_n = bias_stride;
+    a.OH = H; a.OW = W;
+    if (y_format == R3D_FMT_CB8) { a.y_f32 = reinterpret_cast<float*>(y); a.y_f32_stride_n = (size_t)Cout * H * W; }
+    else if (y_format == R3D_FMT_NCHW) { a.y_nchw = reinterpret_cast<float*>(y); a.y_nchw_stride_n = (size_t)Cout * H * W; }
+    else { a.y_split = reinterpret_cast<uint4*>(y); a.y_split_stride_n = (size_t)Cout / 8 * H * W * 2; a.next_scale = next_scale; a.next_scale_stride_n = next_scale_stride; }
+    a.Cin = Ci; a.Cout = Co; a.CoutReal = Cout; a.H = H; a.W = W; a.nphase = 1;
+    a.act = act; a.act_slope = slope; a.act_gain = gain; a.clamp = clamp;
+    if (ksize == 3) sr_fill_conv3x3_phase(a.ph, H, W);
+    else {
+        ConvPhase& p = a.ph[0];
+        p.outH = H; p.outW = W; p.oy_mul = 1; p.oy_add = 0; p.ox_mul = 1; p.ox_add = 0; p.out_off = 0;
+        p.ntaps = 1; p.dy[0] = 0; p.dx[0] = 0; p.widx[0] = 0;
+    }
+    ProfScope ps(R3D_PROF_CONV, st);
+    launch_conv2(a, tiles_of(H, W), N, st);
+    return check_launch("conv_forward");
 }
 
 }  // namespace r3d

@@ -66,6 +66,8 @@ class SynthesisBlock(nn.Module):
     channel-blocked by default when `self.blocked_output` (used inside SuperresolutionHybrid8XDC) and
     NCHW otherwise (drop-in use, e.g. sr_with_ref.py:83,124)."""
 
+    _UP = 1        # 1: conv0 up=2 + upsample2d RGB skip; 0: SynthesisBlockNoUp
+
     def __init__(self, in_channels, out_channels, w_dim, resolution, img_channels, is_last, architecture="skip",
                  resample_filter=(1, 3, 3, 1), conv_clamp=256, use_fp16=False, fp16_channels_last=False,
                  fused_modconv_default=True, **layer_kwargs):
@@ -82,7 +84,7 @@ class SynthesisBlock(nn.Module):
         self.fused_modconv_default = fused_modconv_default
         self.register_buffer("resample_filter", _setup_filter())
         self.num_conv, self.num_torgb = 2, 1
-        self.conv0 = SynthesisLayer(in_channels, out_channels, w_dim=w_dim, resolution=resolution, up=2,
+        self.conv0 = SynthesisLayer(in_channels, out_channels, w_dim=w_dim, resolution=resolution, up=2 if self._UP else 1,
                                     conv_clamp=conv_clamp, **layer_kwargs)
         self.conv1 = SynthesisLayer(out_channels, out_channels, w_dim=w_dim, resolution=resolution,
                                     conv_clamp=conv_clamp, **layer_kwargs)
@@ -158,7 +160,7 @@ class SynthesisBlock(nn.Module):
         pre, styles = _prepared if _prepared is not None else self.prepare(ws, dev)
         need = int(lib.r3d_sr_block_workspace_bytes(N, Cin, Cout, Hin, Win))
         work = self._buf("_workspace", need, dev)
-        OH, OW = 2 * Hin, 2 * Win
+        OH, OW = (2 * Hin, 2 * Win) if self._UP else (Hin, Win)
         img_out = torch.empty(N, 3, OH, OW, device=dev, dtype=torch.float32)
         out_fmt = self.out_format if self.return_x else "none"
         next_scale, next_stride = None, 0
@@ -173,13 +175,126 @@ class SynthesisBlock(nn.Module):
         else:
             x_out = torch.empty(N, Cout, OH, OW, device=dev, dtype=torch.float32)
         clamp = -1.0 if self.conv_clamp is None else float(self.conv_clamp)
-        _lib.check(lib.r3d_sr_block_forward(_lib.ptr(pre), _lib.ptr(styles), N, Cin, Cout, Hin, Win, _lib.ptr(x),
-                                            self._FMT[x_fmt], _lib.ptr(img), clamp, _lib.ptr(x_out), self._FMT[out_fmt],
+        _lib.check(lib.r3d_sr_block_forward(_lib.ptr(pre), _lib.ptr(styles), N, Cin, Cout, Hin, Win, self._UP,
+                                            _lib.ptr(x), self._FMT[x_fmt], _lib.ptr(img), clamp, _lib.ptr(x_out), self._FMT[out_fmt],
                                             _lib.ptr(next_scale), next_stride, _lib.ptr(img_out), prec,
                                             _lib.ptr(work), need, st), "sr_block_forward")
         if x_out is not None and out_fmt != "nchw":
             x_out._r3d_fmt = out_fmt
         return x_out, img_out
+
+
+class SynthesisBlockNoUp(SynthesisBlock):
+    """modules/eg3ds/models/superresolution.py:159-258 (architecture 'skip', in_channels != 0, fp32): conv0 and conv1
+    are both plain modulated 3x3 convs and the RGB skip is `img.add_(torgb(x))` at the block's resolution (the
+    upsample2d call is commented out in the reference, :241-243).  Used by SuperresolutionHybrid8XDC_Warp as
+    head_torso_block (modules/real3d/super_resolution/sr_with_ref.py:54).  f16x3 precision only."""
+    _UP = 0
+
+
+class Conv2d(nn.Module):
+    """torch.nn.Conv2d(in_channels, out_channels, k, 1, padding=k//2) on the HIP conv kernel (r3d_conv_forward), with
+    torch's parameter names/shapes so the reference's state_dict loads unchanged.  Covers what the torso / background
+    fusion stacks of sr_with_ref.py:24-63 use: k in {1, 3}, stride 1, 'same' zero padding, bias."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__()
+        k = kernel_size[0] if isinstance(kernel_size, (tuple, list)) else kernel_size
+        s = stride[0] if isinstance(stride, (tuple, list)) else stride
+        pd = padding[0] if isinstance(padding, (tuple, list)) else padding
+        if k not in (1, 3) or s != 1 or pd != k // 2:
+            raise NotImplementedError("HIP Conv2d covers k in {1,3}, stride 1, padding k//2 (got k=%r s=%r p=%r)" % (k, s, pd))
+        if out_channels % 4:
+            raise NotImplementedError("HIP Conv2d needs out_channels %% 4 == 0 (got %d)" % out_channels)
+        self.in_channels, self.out_channels, self.kernel_size, self.stride, self.padding = in_channels, out_channels, (k, k), (1, 1), (pd, pd)
+        ref = nn.Conv2d(in_channels, out_channels, k, 1, pd, bias=bias)       # torch's default init
+        self.weight = nn.Parameter(ref.weight.detach().clone())
+        self.bias = nn.Parameter(ref.bias.detach().clone()) if bias else None
+        self._prepacked = None
+        self._prepack_key = None
+        self._workspace = None
+
+    _buf = SynthesisBlock._buf
+    _FMT = SynthesisBlock._FMT
+
+    def forward(self, x, negative_slope=None, out_format="nchw"):
+        """negative_slope: fuse a following torch.nn.LeakyReLU(negative_slope); out_format 'nchw' | 'cb8' | 'split'."""
+        lib = _lib.load()
+        x_fmt = getattr(x, "_r3d_fmt", "nchw")
+        x = x.contiguous() if x_fmt == "split" else _f32c(x)
+        Cin, Cout, k = self.in_channels, self.out_channels, self.kernel_size[0]
+        if x_fmt == "nchw":
+            N, C, H, W = x.shape
+        elif x_fmt == "cb8":
+            N, C, H, W = x.shape[0], x.shape[1] * 8, x.shape[2], x.shape[3]
+        else:
+            N, C, H, W = x.shape[0], x.shape[2] * 8, x.shape[3], x.shape[4]
+        if C != Cin:
+            raise RuntimeError("Conv2d: expected input with %d channels, got %d" % (Cin, C))
+        dev = x.device
+        st = _lib.stream_ptr()
+        w = _f32c(self.weight)
+        key = (w.data_ptr(), self.weight._version, str(dev))
+        if self._prepack_key != key:
+            pre = self._buf("_prepacked", int(lib.r3d_conv_prepacked_bytes(Cin, Cout, k)), dev)
+            _lib.check(lib.r3d_conv_prepack(_lib.ptr(w), Cin, Cout, k, _lib.ptr(pre), st), "conv_prepack")
+            self._prepack_key = key
+        need = int(lib.r3d_conv_workspace_bytes(N, Cin, H, W))
+        work = self._buf("_workspace", need, dev) if x_fmt != "split" else None
+        if out_format == "split":
+            y = torch.empty(N, 2, Cout // 8, H, W, 8, device=dev, dtype=torch.float16)
+        elif out_format == "cb8":
+            y = torch.empty(N, Cout // 8, H, W, 8, device=dev, dtype=torch.float32)
+        else:
+            y = torch.empty(N, Cout, H, W, device=dev, dtype=torch.float32)
+        b = _f32c(self.bias) if self.bias is not None else None
+        act = 0 if negative_slope is None else 1
+        _lib.check(lib.r3d_conv_forward(_lib.ptr(self._prepacked), N, Cin, Cout, H, W, k, _lib.ptr(x), self._FMT[x_fmt],
+                                        None, 0, None, 0, _lib.ptr(b), 0, act, float(negative_slope or 0.0), 1.0, -1.0,
+                                        _lib.ptr(y), self._FMT[out_format], None, 0, _lib.ptr(work), need if work is not None else 0, st),
+                   "conv_forward")
+        if out_format != "nchw":
+            y._r3d_fmt = out_format
+        return y
+
+
+class ConvStack(nn.Sequential):
+    """An nn.Sequential of Conv2d / LeakyReLU modules (the shape of torso_encoder, bg_encoder, fuse_head_torso_convs and
+    fuse_fg_bg_convs, sr_with_ref.py:24-63) evaluated on the HIP conv kernel: each LeakyReLU is fused into the
+    preceding conv's epilogue and intermediate activations stay in the fp16 hi/lo SPLIT format (no fp32 round trip).
+    state_dict keys are the reference's ('0.weight', '0.bias', '2.weight', ...).
+
+    ConvStack.from_torch(seq) converts a torch nn.Sequential with loaded weights."""
+
+    @classmethod
+    def from_torch(cls, seq):
+        mods = []
+        for m in seq:
+            if isinstance(m, nn.Conv2d):
+                c = Conv2d(m.in_channels, m.out_channels, m.kernel_size, m.stride, m.padding, bias=m.bias is not None)
+                c.load_state_dict(m.state_dict())
+                mods.append(c.to(m.weight.device))
+            elif isinstance(m, nn.LeakyReLU):
+                mods.append(nn.LeakyReLU(m.negative_slope))
+            else:
+                raise NotImplementedError("ConvStack: unsupported module %s" % type(m).__name__)
+        return cls(*mods)
+
+    def forward(self, x):
+        mods = list(self)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if not isinstance(m, Conv2d):
+                raise NotImplementedError("ConvStack: %s without a preceding Conv2d" % type(m).__name__)
+            slope, step = None, 1
+            if i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU):
+                slope, step = mods[i + 1].negative_slope, 2
+            nxt = mods[i + step] if i + step < len(mods) else None
+            fmt = "split" if (nxt is not None and m.out_channels % 16 == 0) else "nchw"
+            x = m(x, negative_slope=slope, out_format=fmt)
+            i += step
+        return x
 
 
 class SuperresolutionHybrid8XDC(nn.Module):

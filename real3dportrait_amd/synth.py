@@ -77,6 +77,26 @@ def synth_sr_params(seed, channels=32, mid=256, last=128, w_dim=512):
     return [synth_sr_block(seed, channels, mid, w_dim, 100), synth_sr_block(seed, mid, last, w_dim, 200)]
 
 
+# channel plans of the torso / background fusion stacks (modules/real3d/super_resolution/sr_with_ref.py:24-63):
+# (in_channels, out_channels, kernel_size, leaky_relu_after)
+FUSION_STACKS = {
+    "torso_encoder": [(64, 256, 1, False)],
+    "bg_encoder": [(3, 64, 3, True), (64, 256, 3, True), (256, 256, 3, False)],
+    "fuse_head_torso_convs": [(512, 256, 3, True), (256, 256, 3, False)],
+    "fuse_fg_bg_convs": [(512, 64, 1, True), (64, 256, 3, True), (256, 256, 3, False)],
+}
+
+
+def synth_conv_stack(seed, plan, stream0=300):
+    """[(weight [co,ci,k,k], bias [co])] for a FUSION_STACKS plan; weights ~ N(0, 1/(ci k k)) so activations stay O(1)."""
+    out = []
+    for i, (ci, co, k, _) in enumerate(plan):
+        w = hash_unitvar(seed, (co, ci, k, k), stream=stream0 + 2 * i) * np.float32(1.0 / math.sqrt(ci * k * k))
+        b = hash_unitvar(seed, (co,), stream=stream0 + 2 * i + 1) * np.float32(0.1)
+        out.append((w.astype(np.float32), b.astype(np.float32)))
+    return out
+
+
 def look_at_camera(yaw=0.0, pitch=0.0, radius=2.7, lookat=(0.0, 0.0, 0.2), focal=4.2647):
     """camera[25] = flattened OpenCV-convention cam2world (4x4) + normalised intrinsics (3x3)."""
     la = np.asarray(lookat, np.float64)

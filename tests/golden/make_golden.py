@@ -213,8 +213,53 @@ def synthesis_case(name):
     print(name, img.shape, float(np.abs(img).mean()))
 
 
+def torch_stack(plan, params):
+    """The reference builds these stacks inline from torch.nn modules (sr_with_ref.py:24-63); same construction."""
+    mods = []
+    for (ci, co, k, lrelu), (w, b) in zip(plan, params):
+        conv = torch.nn.Conv2d(ci, co, k, 1, padding=k // 2)
+        with torch.no_grad():
+            conv.weight.copy_(torch.from_numpy(w))
+            conv.bias.copy_(torch.from_numpy(b))
+        mods.append(conv)
+        if lrelu:
+            mods.append(torch.nn.LeakyReLU())
+    return torch.nn.Sequential(*mods).eval()
+
+
+def fusion_case(name, R=24):
+    """Convolutional part of SuperresolutionHybrid8XDC_Warp.forward, fuse mode 'v2' (sr_with_ref.py:101-123) at
+    R x R instead of 256 x 256: torso_encoder, bg_encoder, alpha-cat, fuse_head_torso_convs, head_torso_block
+    (the reference's SynthesisBlockNoUp), occlusion-cat, fuse_fg_bg_convs.  The warp-based torso model that produces
+    deformed_torso_hid / occlusion is out of scope; its outputs are synthetic inputs here."""
+    from modules.eg3ds.models.superresolution import SynthesisBlockNoUp
+    seed = 57
+    stacks = {k: torch_stack(plan, synth.synth_conv_stack(seed, plan, 300 + 20 * i))
+              for i, (k, plan) in enumerate(synth.FUSION_STACKS.items())}
+    blk = SynthesisBlockNoUp(256, 256, w_dim=512, resolution=R, img_channels=3, is_last=False, use_fp16=False,
+                             conv_clamp=None, channel_base=32768, channel_max=512,
+                             fused_modconv_default="inference_only").eval()
+    load_block(blk, synth.synth_sr_block(seed, 256, 256, 512, 400))
+    t = lambda shape, s, g=1.0: torch.from_numpy(synth.hash_unitvar(seed, shape, stream=s) * np.float32(g))
+    x_head, hid, bg, rgb, rgb_torso = t((1, 256, R, R), 1), t((1, 64, R, R), 2), t((1, 3, R, R), 3, 0.5), t((1, 3, R, R), 4, 0.5), t((1, 3, R, R), 5, 0.5)
+    alpha = torch.from_numpy(synth.synth_noise(seed, (1, 1, R, R), stream=6))
+    occ = torch.from_numpy(synth.synth_noise(seed, (1, 1, R, R), stream=8))
+    ws = torch.from_numpy(np.ones((1, 3, 512), np.float32) + synth.hash_unitvar(seed, (1, 3, 512), stream=9) * np.float32(0.1))
+    with torch.no_grad():
+        x_torso = stacks["torso_encoder"](hid)
+        x_bg = stacks["bg_encoder"](bg)
+        rgb1 = rgb * alpha + rgb_torso * (1 - alpha)
+        x1 = stacks["fuse_head_torso_convs"](torch.cat([x_head * alpha, x_torso * (1 - alpha)], dim=1))
+        x2, rgb2 = blk(x1, rgb1.clone(), ws, noise_mode="none")
+        x3 = stacks["fuse_fg_bg_convs"](torch.cat([x2 * occ, x_bg * (1 - occ)], dim=1))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=seed, R=R,
+                        x_torso=x_torso.numpy()[:, ::4], x_bg=x_bg.numpy()[:, ::4], x1=x1.numpy()[:, ::4],
+                        x2=x2.numpy()[:, ::4], rgb2=rgb2.numpy(), x3=x3.numpy()[:, ::4])
+    print(name, x3.shape, float(x3.abs().mean()), float(rgb2.abs().mean()))
+
+
 def main():
-    which = sys.argv[1:] or ["render", "run_model", "sr_small", "sr_full", "synthesis"]
+    which = sys.argv[1:] or ["render", "run_model", "sr_small", "sr_full", "synthesis", "fusion"]
     if "render" in which:
         small = synth.synth_planes(1, N=1, H=32, W=32)
         render_case("render_a_r16_16p16", small, [synth.look_at_camera(0.0, 0.0)], 16, 16, 16, 2, 3)
@@ -238,6 +283,8 @@ def main():
         sr_full_case("sr_full_a")
     if "synthesis" in which:
         synthesis_case("synthesis_ref_a")
+    if "fusion" in which:
+        fusion_case("fusion_a")
 
 
 if __name__ == "__main__":

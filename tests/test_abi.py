@@ -48,8 +48,19 @@ def test_argument_errors_are_reported_not_thrown():
     assert rc == -2 and b"workspace" in lib.r3d_last_error()
     rc = lib.r3d_sr_block_prepack(30, 256, one, one, one, 1, None)
     assert rc == -1 and b"multiple of 8" in lib.r3d_last_error()
-    rc2 = lib.r3d_sr_block_forward(one, one, 1, 32, 256, 16, 16, one, 2, one, -1.0, None, -1, None, 0, one, 0, one, 1 << 40, None)
+    rc2 = lib.r3d_sr_block_forward(one, one, 1, 32, 256, 16, 16, 1, one, 2, one, -1.0, None, -1, None, 0, one, 0, one, 1 << 40, None)
     assert rc2 == -1 and b"format" in lib.r3d_last_error()      # SPLIT input needs the f16x3 precision
+    rc2 = lib.r3d_sr_block_forward(one, one, 1, 32, 256, 16, 16, 0, one, 0, one, -1.0, None, -1, None, 0, one, 0, one, 1 << 40, None)
+    assert rc2 == -1 and b"up=0" in lib.r3d_last_error()        # SynthesisBlockNoUp is f16x3 only
+    rc2 = lib.r3d_conv_forward(one, 1, 64, 30, 16, 16, 3, one, 0, None, 0, None, 0, None, 0, 0, 0.0, 1.0, -1.0,
+                               one, 0, None, 0, one, 1 << 40, None)
+    assert rc2 == -1 and b"multiple of 4" in lib.r3d_last_error()
+    rc2 = lib.r3d_conv_forward(one, 1, 64, 32, 16, 16, 5, one, 0, None, 0, None, 0, None, 0, 0, 0.0, 1.0, -1.0,
+                               one, 0, None, 0, one, 1 << 40, None)
+    assert rc2 == -1 and b"bad argument" in lib.r3d_last_error()
+    rc2 = lib.r3d_conv_forward(one, 1, 64, 32, 16, 16, 3, one, 0, None, 0, None, 0, None, 0, 0, 0.0, 1.0, -1.0,
+                               one, 0, None, 0, one, 8, None)
+    assert rc2 == -2 and b"workspace" in lib.r3d_last_error()
     rc = lib.r3d_sr_block_prepack(30, 256, one, one, one, 1, None)
     try:
         _lib.check(rc, "prepack")

@@ -117,6 +117,81 @@ def test_sr_blocks_golden(torch_cuda, precision):
         assert np.abs(got.cpu().numpy() - ref).max() <= SR_TOL * max(1.0, np.abs(ref).max())
 
 
+def _fusion_modules(torch, seed, R):
+    from real3dportrait_amd import synth
+    from real3dportrait_amd.superresolution import Conv2d, ConvStack, SynthesisBlockNoUp
+    stacks = {}
+    for n, (k, plan) in enumerate(synth.FUSION_STACKS.items()):
+        mods = []
+        for (ci, co, ks, lrelu), (w, b) in zip(plan, synth.synth_conv_stack(seed, plan, 300 + 20 * n)):
+            c = Conv2d(ci, co, ks, 1, padding=ks // 2)
+            with torch.no_grad():
+                c.weight.copy_(torch.from_numpy(w)); c.bias.copy_(torch.from_numpy(b))
+            mods.append(c)
+            if lrelu:
+                mods.append(torch.nn.LeakyReLU())
+        stacks[k] = ConvStack(*mods).cuda()
+    blk = SynthesisBlockNoUp(256, 256, w_dim=512, resolution=R, img_channels=3, is_last=False, conv_clamp=None).cuda()
+    load_block(torch, blk, synth.synth_sr_block(seed, 256, 256, 512, 400))
+    return stacks, blk
+
+
+def test_fusion_stacks_golden(torch_cuda):
+    """torso_encoder / bg_encoder / fuse_head_torso_convs / head_torso_block (SynthesisBlockNoUp) /
+    fuse_fg_bg_convs of SuperresolutionHybrid8XDC_Warp (sr_with_ref.py:24-63, :101-123) vs the reference's outputs."""
+    torch = torch_cuda
+    from test_oracle_golden import _fusion_inputs
+    g = load_golden("fusion_a")
+    seed, R = int(g["seed"]), int(g["R"])
+    i = {k: T(torch, v) for k, v in _fusion_inputs(seed, R).items()}
+    stacks, blk = _fusion_modules(torch, seed, R)
+    x_torso = stacks["torso_encoder"](i["hid"])
+    x_bg = stacks["bg_encoder"](i["bg"])
+    a, occ = i["alpha"], i["occ"]
+    rgb1 = i["rgb"] * a + i["rgb_torso"] * (1 - a)
+    x1 = stacks["fuse_head_torso_convs"](torch.cat([i["x_head"] * a, x_torso * (1 - a)], dim=1))
+    x2, rgb2 = blk(x1, rgb1, i["ws"], noise_mode="none")
+    x3 = stacks["fuse_fg_bg_convs"](torch.cat([x2 * occ, x_bg * (1 - occ)], dim=1))
+    for got, key in ((x_torso[:, ::4], "x_torso"), (x_bg[:, ::4], "x_bg"), (x1[:, ::4], "x1"), (x2[:, ::4], "x2"),
+                     (rgb2, "rgb2"), (x3[:, ::4], "x3")):
+        ref = g[key]
+        assert got.shape == ref.shape, key
+        assert np.abs(got.cpu().numpy() - ref).max() <= SR_TOL * max(1.0, np.abs(ref).max()), key
+
+
+@pytest.mark.parametrize("N,Cin,Cout,k,H,W,slope", [(2, 3, 64, 3, 37, 21, 0.01), (1, 64, 256, 1, 16, 16, None),
+                                                    (1, 7, 32, 3, 33, 48, 0.2), (3, 512, 64, 1, 20, 20, 0.01),
+                                                    (1, 32, 12, 3, 19, 19, None)])
+def test_conv2d_vs_torch_fp32(torch_cuda, N, Cin, Cout, k, H, W, slope):
+    """r3d_conv_forward vs torch's fp32 conv2d (the same ATen op the reference stacks run) on ragged sizes, channel
+    padding (Cin 3/7 -> 16, Cout 12/32/64 -> 128) and batch > 1."""
+    torch = torch_cuda
+    from real3dportrait_amd import synth
+    from real3dportrait_amd.superresolution import Conv2d
+    x = T(torch, synth.hash_unitvar(5, (N, Cin, H, W), stream=1))
+    c = Conv2d(Cin, Cout, k, 1, padding=k // 2).cuda()
+    with torch.no_grad():
+        c.weight.copy_(T(torch, synth.hash_unitvar(5, (Cout, Cin, k, k), stream=2) / np.float32(np.sqrt(Cin * k * k))))
+        c.bias.copy_(T(torch, synth.hash_unitvar(5, (Cout,), stream=3)))
+    y = c(x, negative_slope=slope)
+    xd, wd, bd = x.double().cpu(), c.weight.detach().double().cpu(), c.bias.detach().double().cpu()
+    ref = torch.nn.functional.conv2d(xd, wd, bd, padding=k // 2)
+    if slope is not None:
+        ref = torch.nn.functional.leaky_relu(ref, slope)
+    assert y.shape == ref.shape
+    assert (y.cpu().double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_conv2d_rejects_unsupported(torch_cuda):
+    from real3dportrait_amd.superresolution import Conv2d
+    with pytest.raises(NotImplementedError):
+        Conv2d(8, 8, 5, 1, padding=2)
+    with pytest.raises(NotImplementedError):
+        Conv2d(8, 8, 3, 2, padding=1)
+    with pytest.raises(NotImplementedError):
+        Conv2d(32, 1, 3, 1, padding=1)
+
+
 @pytest.mark.parametrize("precision", ["f32", "f16x3"])
 def test_sr_full_golden(torch_cuda, precision):
     torch = torch_cuda

@@ -63,6 +63,35 @@ def test_sr_blocks_match_reference(oracle):
     assert np.abs(r1 - g["rgb1"][0]).max() <= 2e-5 * max(1.0, scale)
 
 
+def _fusion_inputs(seed, R):
+    from real3dportrait_amd import synth
+    t = lambda shape, s, g=1.0: synth.hash_unitvar(seed, shape, stream=s) * np.float32(g)
+    return dict(x_head=t((1, 256, R, R), 1), hid=t((1, 64, R, R), 2), bg=t((1, 3, R, R), 3, 0.5),
+                rgb=t((1, 3, R, R), 4, 0.5), rgb_torso=t((1, 3, R, R), 5, 0.5),
+                alpha=synth.synth_noise(seed, (1, 1, R, R), stream=6), occ=synth.synth_noise(seed, (1, 1, R, R), stream=8),
+                ws=np.ones((1, 3, 512), np.float32) + synth.hash_unitvar(seed, (1, 3, 512), stream=9) * np.float32(0.1))
+
+
+def test_fusion_stacks_match_reference(oracle):
+    """Torso / background fusion convs + SynthesisBlockNoUp (sr_with_ref.py:24-63, :101-123) vs the reference."""
+    from real3dportrait_amd import synth
+    g = load_golden("fusion_a")
+    seed, R = int(g["seed"]), int(g["R"])
+    i = _fusion_inputs(seed, R)
+    P = {k: synth.synth_conv_stack(seed, plan, 300 + 20 * n) for n, (k, plan) in enumerate(synth.FUSION_STACKS.items())}
+    S = synth.FUSION_STACKS
+    x_torso = oracle.conv_stack(i["hid"][0], S["torso_encoder"], P["torso_encoder"])
+    x_bg = oracle.conv_stack(i["bg"][0], S["bg_encoder"], P["bg_encoder"])
+    a, occ = i["alpha"][0], i["occ"][0]
+    rgb1 = i["rgb"][0] * a + i["rgb_torso"][0] * (1 - a)
+    x1 = oracle.conv_stack(np.concatenate([i["x_head"][0] * a, x_torso * (1 - a)]), S["fuse_head_torso_convs"], P["fuse_head_torso_convs"])
+    x2, rgb2 = oracle.sr_block(x1, rgb1, synth.synth_sr_block(seed, 256, 256, 512, 400), i["ws"][0], up=False)
+    x3 = oracle.conv_stack(np.concatenate([x2 * occ, x_bg * (1 - occ)]), S["fuse_fg_bg_convs"], P["fuse_fg_bg_convs"])
+    for got, key in ((x_torso[::4], "x_torso"), (x_bg[::4], "x_bg"), (x1[::4], "x1"), (x2[::4], "x2"), (rgb2, "rgb2"), (x3[::4], "x3")):
+        ref = g[key][0]
+        assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), key
+
+
 def test_edge_cases_run(oracle):
     """No valid ray at all (camera looks away): fix-up is skipped, depths run backwards, outputs stay finite."""
     from real3dportrait_amd import synth
