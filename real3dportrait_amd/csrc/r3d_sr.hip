@@ -386,7 +386,8 @@ using namespace r3d;
 
 extern "C" size_t r3d_sr_block_prepacked_bytes(int Cin, int Cout)
 {
-    return ((size_t)9 * Cin * Cout + (size_t)9 * Cout * Cout) * sizeof(float);
+    // conv0 (plain layout) + conv1 + conv0 again in the fused up-conv layout (f16x3)
+    return ((size_t)2 * 9 * Cin * Cout + (size_t)9 * Cout * Cout) * sizeof(float);
 }
 
 extern "C" size_t r3d_sr_block_styles_bytes(int N, int Cin, int Cout)

@@ -398,6 +398,289 @@ __global__ __launch_bounds__(128 * WN, OCC) void tconv_mfma_f16x3_kernel(Conv2Ar
     }
 }
 
+// ---- fused up-sampling conv: conv_transpose2d(stride 2) + FIR 4x4 (gain 4, pad 1) + bias + lrelu*sqrt2 -> SPLIT --------
+// (conv2d_resample.py:116-133 up=2 path + bias_act of SynthesisLayer.forward, networks_stylegan2.py:329-341.)
+// The transposed conv is evaluated as its four output phases T_p(i,j) = sum_{taps (ky,kx) = p mod 2} x(i - ky/2, j - kx/2) W[ky][kx]
+// (row 2i+pa, col 2j+pb of the (2H+1)x(2W+1) result).  One block owns ALL FOUR phases of a 16x16 grid of (i,j) for 32
+// couts, so the input patch is read once for the 9 taps (the per-phase kernel re-read it four times: that launch was
+// memory-bound at 28 % of the MFMA pipe) and the fp32 T never leaves the CU: it is FIR-filtered out of LDS into the
+// 28x28 outputs the grid fully determines (halo recompute (16/14)^2 = 1.31x MFMA work), biased, activated, scaled by
+// the next conv's styles, split and stored.  Out-of-image inputs are zero-filled, which makes the rows r = -1 and
+// r = 2H+1 that the FIR's zero padding touches come out as exact zeros.
+//   4 waves x (32 couts x 64 grid points x 4 phases) = 8 accumulator tiles (128 VGPRs) at 2 waves/SIMD, 2 blocks/CU.
+//   Per 16-channel stage a wave reads the 4 shifted B windows once (16 ds_read_b128) and 9 taps of A (18) for 54 MFMAs.
+static constexpr int U_TILE = 14;                                   // inputs (= output quads) per tile side
+static constexpr int U_WSTAGE = 9 * 2 * 2 * 32;                     // uint4 per weight stage: [tap][chunk][hi|lo][32 couts]
+static constexpr int U_PATCH = 2 * 2 * F_PATCH_PIX;                 // uint4: [plane][chunk][18x18]
+static constexpr int U_LDS_UINT4 = U_PATCH + 2 * U_WSTAGE;          // 3600 uint4 = 57.6 KB (epilogue slice: 2048 uint4)
+
+struct UpArgs {
+    const uint4* x; size_t x_stride_n;          // SPLIT input [hi|lo][Cin/8][H][W]
+    const uint4* wp;                            // [Cout/32][Cin/16][tap][chunk][hi|lo][32] (sr_prepack_up_kernel)
+    const float* out_scale; const float* bias; const float* next_scale; size_t vec_stride_n;
+    uint4* y; size_t y_stride_n;                // SPLIT output [hi|lo][Cout/8][2H][2W], scaled by next_scale
+    int Cin, Cout, H, W, tiles_x, ntiles, tiles_per_xcd;
+    float clamp;
+};
+
+__global__ void sr_prepack_up_kernel(const float* __restrict__ w, int Cin, int Cout, uint4* __restrict__ out)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)9 * (Cin / 8) * Cout * 2;
+    if (e >= total) return;
+    const int co = e & 31, hl = (e >> 5) & 1, hc = (e >> 6) & 1;
+    const int t = (int)((e >> 7) % 9);
+    const size_t r = (e >> 7) / 9;
+    const int nst = Cin / 16;
+    const int st = (int)(r % nst), cg = (int)(r / nst);
+    const int cout = cg * 32 + co;
+    h8 v8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int ci = st * 16 + hc * 8 + j;
+        _Float16 a, b; split1(w[((size_t)cout * Cin + ci) * 9 + t], a, b);
+        v8[j] = hl ? b : a;
+    }
+    out[e] = *reinterpret_cast<uint4*>(&v8);
+}
+
+__global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
+{
+    __shared__ uint4 lds[U_LDS_UINT4];
+    const int G = a.Cout >> 5;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;         // the cout groups of one tile share an XCD (one L2)
+    const int tl = slot / G, cg = slot - tl * G;
+    const int tile = xcd * a.tiles_per_xcd + tl;
+    if (tile >= a.ntiles) return;
+    const int n = blockIdx.y;
+    const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
+    const int i0 = ty * U_TILE, j0 = tx * U_TILE;                   // first input row / col of the tile; grid point g <-> i0 - 1 + g
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int nst = a.Cin >> 4;
+    const int chunk_stride = a.H * a.W;
+    const size_t plane = (size_t)(a.Cin >> 3) * chunk_stride;
+    const uint4* X = a.x + (size_t)n * a.x_stride_n;
+    uint4* patchB = lds;
+    uint4* bufA = lds + U_PATCH;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[p][nt][r] = 0.f;
+
+    // grid point of this lane in N tile nt: row 4*wave + 2*nt + prow, col pcol (odd rows rotated by 2: conflict-free b128 reads)
+    const int prow = li >> 4, pcol = ((li & 15) - 2 * prow) & 15;
+    const int row0 = wave * 4;
+    int boff[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) boff[nt] = (row0 + nt * 2 + prow + 1) * F_PATCH_W + (pcol + 1) + h * F_PATCH_PIX;
+    const int aoff = h * 64 + li;
+
+    // patch element e -> (plane, chunk, 17x17 pixel): patch (py,px) <-> input (i0 - 2 + py, j0 - 2 + px)
+    constexpr int NPF = 5;
+    uint4 pf[NPF];
+    unsigned pf_off[NPF], pf_lds[NPF];
+    unsigned pf_valid = 0;
+#pragma unroll
+    for (int k = 0; k < NPF; ++k) {
+        const int e = tid + 256 * k;
+        unsigned off = 0, l = F_PATCH_PIX - 1;                      // surplus lanes write the never-read corner (17,17)
+        if (e < 4 * 289) {
+            const int pl = e / 578, rem = e - pl * 578;
+            const int c = rem / 289, pp = rem - c * 289;
+            const int py = pp / 17, px = pp - py * 17;
+            const int iy = i0 - 2 + py, ix = j0 - 2 + px;
+            l = pl * (2 * F_PATCH_PIX) + c * F_PATCH_PIX + py * F_PATCH_W + px;
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+                off = (unsigned)(pl * plane) + (unsigned)(c * chunk_stride + iy * a.W + ix);
+                pf_valid |= 1u << k;
+            }
+        }
+        pf_off[k] = off; pf_lds[k] = l;
+    }
+    auto load_patch = [&](int st) {
+        const uint4* Xs = X + (size_t)(2 * st) * chunk_stride;
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) pf[k] = Xs[pf_off[k]];       // halo -> zero at the LDS write (keeps the loads in flight)
+    };
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const uint4* WP = a.wp + (size_t)cg * nst * U_WSTAGE;
+    auto dma_weights = [&](int st, uint4* dstA) {                   // 1152 uint4 per stage, linear: 4.5 rounds of 256 lanes
+        const uint4* src = WP + (size_t)st * U_WSTAGE;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            if (k < 4 || wave_u < 2) {
+                const unsigned lds_dst = __builtin_amdgcn_readfirstlane(
+                    (unsigned)(size_t)(__attribute__((address_space(3))) uint4*)(dstA + 256 * k + 64 * wave_u));
+                const uint4* gsrc = src + 256 * k + tid;
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+            }
+        }
+    };
+
+    dma_weights(0, bufA);
+    load_patch(0);
+    for (int st = 0; st < nst; ++st) {
+        __syncthreads();                                            // the previous stage's patch reads are done
+#pragma unroll
+        for (int k = 0; k < NPF; ++k)
+            patchB[pf_lds[k]] = (pf_valid & (1u << k)) ? pf[k] : make_uint4(0, 0, 0, 0);   // unconditional: no divergent waits
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this stage's weight DMAs (issued one stage ago) have landed
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const uint4* curA = bufA + (st & 1) * U_WSTAGE;
+#if defined(R3D_UP_ABL) && (R3D_UP_ABL & 16)
+        if (st + 1 < nst && st == 0) {
+#else
+        if (st + 1 < nst) {
+#endif
+            dma_weights(st + 1, bufA + ((st + 1) & 1) * U_WSTAGE);
+            load_patch(st + 1);
+        }
+#pragma unroll
+        for (int win = 0; win < 4; ++win) {                         // input shift (sy, sx): x(i - sy, j - sx)
+            const int sy = win >> 1, sx = win & 1;
+            const int toff = -(sy * F_PATCH_W + sx);
+            h8 bh[2], bl[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+#if defined(R3D_UP_ABL) && (R3D_UP_ABL & 8)
+                uint4 r0 = make_uint4(st, win, nt, 1), r1 = make_uint4(st, win, nt, 2);
+#else
+                uint4 r0 = patchB[boff[nt] + toff];
+                uint4 r1 = patchB[boff[nt] + toff + 2 * F_PATCH_PIX];
+#endif
+                bh[nt] = *reinterpret_cast<h8*>(&r0); bl[nt] = *reinterpret_cast<h8*>(&r1);
+            }
+#pragma unroll
+            for (int ky = 2 * sy; ky <= (sy ? 2 : 1); ++ky)
+#pragma unroll
+                for (int kx = 2 * sx; kx <= (sx ? 2 : 1); ++kx) {
+                    const int t = ky * 3 + kx, p = (ky & 1) * 2 + (kx & 1);
+#if defined(R3D_UP_ABL) && (R3D_UP_ABL & 8)
+                    uint4 q0 = make_uint4(st, t, 3, 1), q1 = make_uint4(st, t, 4, 2);
+#else
+                    uint4 q0 = curA[t * 128 + aoff], q1 = curA[t * 128 + aoff + 32];
+#endif
+                    const h8 ah = *reinterpret_cast<h8*>(&q0), al = *reinterpret_cast<h8*>(&q1);
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+#if defined(R3D_UP_ABL) && (R3D_UP_ABL & 4)
+                        acc[p][nt][0] += (float)(al[0] * bh[nt][0] + ah[1] * bl[nt][1]);
+#else
+                        acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[nt], acc[p][nt], 0, 0, 0);
+                        acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[nt], acc[p][nt], 0, 0, 0);
+                        acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[nt], acc[p][nt], 0, 0, 0);
+#endif
+                    }
+                }
+        }
+    }
+
+#ifdef R3D_UP_ABL
+    if (R3D_UP_ABL & 2) {       // ablation: no epilogue (keep the accumulators alive)
+        float sum = 0.f;
+        for (int p = 0; p < 4; ++p) for (int nt = 0; nt < 2; ++nt) for (int r = 0; r < 16; ++r) sum += acc[p][nt][r];
+        if (sum == 12345.678f) a.y[0] = make_uint4(1, 2, 3, 4);
+        return;
+    }
+#endif
+    // ---- epilogue: 4 slices of 8 couts through LDS: T (demodulated, fp32) [phase][cout half][16x16][4] -> FIR -> y -------
+    float4* tls = reinterpret_cast<float4*>(lds);
+    const int co0 = cg * 32;
+    const float* D = a.out_scale + (size_t)n * a.vec_stride_n + co0;
+    const float* Bv = a.bias + (size_t)n * a.vec_stride_n + co0;
+    const float* NS = a.next_scale + (size_t)n * a.vec_stride_n + co0;
+    const int OH = 2 * a.H, OW = 2 * a.W;
+    const size_t oplane = (size_t)(a.Cout >> 3) * OH * OW;
+    const int Y = tid >> 4, Xq = tid & 15;
+    const bool fir_thread = Y < U_TILE && Xq < U_TILE && i0 + Y < a.H && j0 + Xq < a.W;
+    const float f1[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        __syncthreads();                                            // main loop / previous slice's FIR reads are done
+        const float4 d4 = *reinterpret_cast<const float4*>(D + 8 * g + 4 * h);
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int px = (row0 + nt * 2 + prow) * 16 + pcol;
+                tls[(p * 2 + h) * 256 + px] = make_float4(acc[p][nt][4 * g + 0] * d4.x, acc[p][nt][4 * g + 1] * d4.y,
+                                                          acc[p][nt][4 * g + 2] * d4.z, acc[p][nt][4 * g + 3] * d4.w);
+            }
+        __syncthreads();
+#ifdef R3D_UP_ABL
+        if (R3D_UP_ABL & 1) continue;
+#endif
+        if (fir_thread) {
+            float o[2][2][8];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                float4 s[2][2];
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) s[dy][dx] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int rr = 0; rr < 5; ++rr) {                    // T row 2(i0+Y) - 1 + rr = phase row (rr+1)&1 at grid row Y + (rr+1)/2
+                    const int pa = (rr + 1) & 1, gy = Y + ((rr + 1) >> 1);
+#pragma unroll
+                    for (int cc = 0; cc < 5; ++cc) {
+                        const int pb = (cc + 1) & 1, gx = Xq + ((cc + 1) >> 1);
+                        const float4 tv = tls[((pa * 2 + pb) * 2 + hf) * 256 + gy * 16 + gx];
+#pragma unroll
+                        for (int dy = 0; dy < 2; ++dy) {
+                            const int a_ = rr - dy;
+                            if (a_ < 0 || a_ > 3) continue;
+#pragma unroll
+                            for (int dx = 0; dx < 2; ++dx) {
+                                const int b_ = cc - dx;
+                                if (b_ < 0 || b_ > 3) continue;
+                                const float w = f1[a_] * f1[b_];
+                                s[dy][dx].x += tv.x * w; s[dy][dx].y += tv.y * w; s[dy][dx].z += tv.z * w; s[dy][dx].w += tv.w * w;
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) {
+                        o[dy][dx][4 * hf + 0] = s[dy][dx].x; o[dy][dx][4 * hf + 1] = s[dy][dx].y;
+                        o[dy][dx][4 * hf + 2] = s[dy][dx].z; o[dy][dx][4 * hf + 3] = s[dy][dx].w;
+                    }
+            }
+            const float4 b0 = *reinterpret_cast<const float4*>(Bv + 8 * g), b1 = *reinterpret_cast<const float4*>(Bv + 8 * g + 4);
+            const float4 n0 = *reinterpret_cast<const float4*>(NS + 8 * g), n1 = *reinterpret_cast<const float4*>(NS + 8 * g + 4);
+            const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w}, nv[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
+            uint4* d = a.y + (size_t)n * a.y_stride_n + (size_t)((co0 >> 3) + g) * OH * OW;
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    h8 hi, lo;
+#pragma unroll
+                    for (int ch = 0; ch < 8; ++ch) {
+                        float t = o[dy][dx][ch] + bv[ch];
+                        t = (t < 0.f ? t * 0.2f : t) * 1.4142135623730951f;
+                        if (a.clamp >= 0.f) t = fminf(fmaxf(t, -a.clamp), a.clamp);
+                        _Float16 x0, x1; split1(t * nv[ch], x0, x1); hi[ch] = x0; lo[ch] = x1;
+                    }
+                    const size_t pq = (size_t)(2 * (i0 + Y) + dy) * OW + (2 * (j0 + Xq) + dx);
+                    d[pq] = *reinterpret_cast<uint4*>(&hi);
+                    d[oplane + pq] = *reinterpret_cast<uint4*>(&lo);
+                }
+        }
+    }
+}
+
 // ---- FIR 4x4 (gain 4, pad 1) + bias + lrelu*sqrt2 on the transposed-conv output; writes SPLIT scaled by the next
 // conv's styles.  T is PHASE-MAJOR: T[p=(r&1)*2+(c&1)][C/8][Hin+1][Win+1][8] holds row r, col c of the (2Hin+1)x(2Win+1)
 // transposed-conv result (the conv epilogue's stores are then contiguous).  One thread = a 2x2 output quad x 8
@@ -530,6 +813,10 @@ int sr_prepack_f16x3(int Cin, int Cout, const float* c0_w, const float* c1_w, vo
                        reinterpret_cast<uint4*>(out));
     hipLaunchKernelGGL(sr_prepack_f16_kernel, dim3((unsigned)((m1 + 255) / 256)), dim3(256), 0, st, c1_w, Cout, Cout, 9, Cout, Cout,
                        reinterpret_cast<uint4*>(out + (size_t)9 * Cin * Cout));
+    // conv0 again in the fused up-conv layout (SynthesisBlock; the plain layout above serves SynthesisBlockNoUp)
+    const size_t mu = (size_t)9 * (Cin / 8) * Cout * 2;
+    hipLaunchKernelGGL(sr_prepack_up_kernel, dim3((unsigned)((mu + 255) / 256)), dim3(256), 0, st, c0_w, Cin, Cout,
+                       reinterpret_cast<uint4*>(out + (size_t)9 * Cin * Cout + (size_t)9 * Cout * Cout));
     return check_launch("sr_block_prepack");
 }
 
@@ -577,7 +864,22 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
                            reinterpret_cast<const float*>(x), x_format == R3D_FMT_CB8 ? 1 : 0, pk + L.s0, L.total, xin, Cin, Cin, Hin * Win);
         xs = xin;
     }
-    if (up) {
+    static const int fused_up = getenv("R3D_UPCONV") ? atoi(getenv("R3D_UPCONV")) : 1;   // A/B switch: 0 = per-phase T-conv + FIR kernel
+    if (up && fused_up) {
+        // ---- conv0: fused transposed conv + FIR + bias + lrelu -> SPLIT (one kernel, T stays on chip) ----------------
+        UpArgs u = {};
+        u.x = xs; u.x_stride_n = (size_t)Cin / 8 * Hin * Win * 2;
+        u.wp = reinterpret_cast<const uint4*>(wpk + (size_t)9 * Cin * Cout + (size_t)9 * Cout * Cout);
+        u.out_scale = pk + L.d0; u.bias = pk + L.b0; u.next_scale = pk + L.s1; u.vec_stride_n = L.total;
+        u.y = y0; u.y_stride_n = (size_t)Cout / 8 * OH * OW * 2;
+        u.Cin = Cin; u.Cout = Cout; u.H = Hin; u.W = Win;
+        u.tiles_x = (Win + U_TILE - 1) / U_TILE;
+        u.ntiles = u.tiles_x * ((Hin + U_TILE - 1) / U_TILE);
+        u.tiles_per_xcd = (u.ntiles + 7) / 8;
+        u.clamp = clamp;
+        ProfScope ps(R3D_PROF_CONV, st);
+        hipLaunchKernelGGL(upconv_fir_f16x3_kernel, dim3(8 * u.tiles_per_xcd * (Cout / 32), N), dim3(256), 0, st, u);
+    } else if (up) {
         // ---- conv0: stride-2 transposed conv as 4 phases -> T (demodulated, fp32), then FIR + bias + lrelu -> SPLIT ----
         {
             Conv2Args a = {};
