@@ -411,8 +411,12 @@ __global__ __launch_bounds__(128 * WN, OCC) void tconv_mfma_f16x3_kernel(Conv2Ar
 //   Per 16-channel stage a wave reads the 4 shifted B windows once (16 ds_read_b128) and 9 taps of A (18) for 54 MFMAs.
 static constexpr int U_TILE = 14;                                   // inputs (= output quads) per tile side
 static constexpr int U_WSTAGE = 9 * 2 * 2 * 32;                     // uint4 per weight stage: [tap][chunk][hi|lo][32 couts]
-static constexpr int U_PATCH = 2 * 2 * F_PATCH_PIX;                 // uint4: [plane][chunk][18x18]
-static constexpr int U_LDS_UINT4 = U_PATCH + 2 * U_WSTAGE;          // 3600 uint4 = 57.6 KB (epilogue slice: 2048 uint4)
+static constexpr int U_PW = 17, U_PPLANE = 320;                     // patch: 17x17 pixels per (plane, chunk), padded to 5 x 64 slots
+static constexpr int U_PATCH = 4 * U_PPLANE;                        // uint4: [hi|lo][chunk][320]
+static constexpr int U_STAGE = U_PATCH + U_WSTAGE;                  // 2432 uint4 per stage buffer
+static constexpr int U_LDS_UINT4 = 2 * U_STAGE;                     // double-buffered: 77.8 KB (epilogue slice: 2048 uint4)
+
+__device__ uint4 g_zero16[1];                                       // DMA source of zero-filled (out-of-image / padding) patch slots
 
 struct UpArgs {
     const uint4* x; size_t x_stride_n;          // SPLIT input [hi|lo][Cin/8][H][W]
@@ -444,6 +448,16 @@ __global__ void sr_prepack_up_kernel(const float* __restrict__ w, int Cin, int C
     out[e] = *reinterpret_cast<uint4*>(&v8);
 }
 
+// LDS-DMA of one wave-instruction: 64 lanes x 16 B from per-lane global addresses to LDS [dst, dst + 1 KB).  Inline asm so
+// that hipcc does not serialise the ds_reads of the other buffer behind it (waits are the explicit vmcnt(0) per stage).
+__device__ __forceinline__ void dma64(const uint4* gsrc, uint4* lds_dst_uniform)
+{
+    const unsigned d = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) uint4*)lds_dst_uniform);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(d) : "memory");
+}
+
 __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
 {
     __shared__ uint4 lds[U_LDS_UINT4];
@@ -461,8 +475,6 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
     const int chunk_stride = a.H * a.W;
     const size_t plane = (size_t)(a.Cin >> 3) * chunk_stride;
     const uint4* X = a.x + (size_t)n * a.x_stride_n;
-    uint4* patchB = lds;
-    uint4* bufA = lds + U_PATCH;
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -472,90 +484,70 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[p][nt][r] = 0.f;
 
-    // grid point of this lane in N tile nt: row 4*wave + 2*nt + prow, col pcol (odd rows rotated by 2: conflict-free b128 reads)
-    const int prow = li >> 4, pcol = ((li & 15) - 2 * prow) & 15;
+    // grid point of this lane in N tile nt: row 4*wave + 2*nt + prow, col pcol (odd rows rotated by the row stride mod 16:
+    // every ds_read_b128 lane group then covers 16 distinct 16-byte slots)
+    const int prow = li >> 4, pcol = ((li & 15) - prow) & 15;
     const int row0 = wave * 4;
     int boff[2];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) boff[nt] = (row0 + nt * 2 + prow + 1) * F_PATCH_W + (pcol + 1) + h * F_PATCH_PIX;
-    const int aoff = h * 64 + li;
+    for (int nt = 0; nt < 2; ++nt) boff[nt] = (row0 + nt * 2 + prow + 1) * U_PW + (pcol + 1) + h * U_PPLANE;
+    const int aoff = U_PATCH + h * 64 + li;
 
-    // patch element e -> (plane, chunk, 17x17 pixel): patch (py,px) <-> input (i0 - 2 + py, j0 - 2 + px)
-    constexpr int NPF = 5;
-    uint4 pf[NPF];
-    unsigned pf_off[NPF], pf_lds[NPF];
+    // patch DMA: wave w fills segment sg = 4k + w (k = 0..4) of the 20 x 64-slot patch image; slot idx = (sg % 5) * 64 + lane of
+    // (plane, chunk) = sg / 5 holds patch pixel (idx / 17, idx % 17) <-> input (i0 - 2 + py, j0 - 2 + px); slots outside the
+    // image / beyond 289 read the zero block
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    unsigned pf_off[5];
     unsigned pf_valid = 0;
 #pragma unroll
-    for (int k = 0; k < NPF; ++k) {
-        const int e = tid + 256 * k;
-        unsigned off = 0, l = F_PATCH_PIX - 1;                      // surplus lanes write the never-read corner (17,17)
-        if (e < 4 * 289) {
-            const int pl = e / 578, rem = e - pl * 578;
-            const int c = rem / 289, pp = rem - c * 289;
-            const int py = pp / 17, px = pp - py * 17;
-            const int iy = i0 - 2 + py, ix = j0 - 2 + px;
-            l = pl * (2 * F_PATCH_PIX) + c * F_PATCH_PIX + py * F_PATCH_W + px;
-            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-                off = (unsigned)(pl * plane) + (unsigned)(c * chunk_stride + iy * a.W + ix);
-                pf_valid |= 1u << k;
-            }
+    for (int k = 0; k < 5; ++k) {
+        const int sg = 4 * k + wave_u, pc = sg / 5, idx = (sg - pc * 5) * 64 + lane;
+        const int py = idx / U_PW, px = idx - py * U_PW;
+        const int iy = i0 - 2 + py, ix = j0 - 2 + px;
+        unsigned off = 0;
+        if (idx < U_PW * U_PW && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+            off = (unsigned)((pc >> 1) * plane) + (unsigned)((pc & 1) * chunk_stride + iy * a.W + ix);
+            pf_valid |= 1u << k;
         }
-        pf_off[k] = off; pf_lds[k] = l;
+        pf_off[k] = off;
     }
-    auto load_patch = [&](int st) {
+    const uint4* WP = a.wp + (size_t)cg * nst * U_WSTAGE;
+    auto dma_stage = [&](int st, uint4* buf) {
+        const uint4* src = WP + (size_t)st * U_WSTAGE + tid;        // weights: 1152 uint4, linear: 4.5 rounds of 256 lanes
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+            if (k < 4 || wave_u < 2) dma64(src + 256 * k, buf + U_PATCH + 256 * k + 64 * wave_u);
         const uint4* Xs = X + (size_t)(2 * st) * chunk_stride;
 #pragma unroll
-        for (int k = 0; k < NPF; ++k) pf[k] = Xs[pf_off[k]];       // halo -> zero at the LDS write (keeps the loads in flight)
-    };
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const uint4* WP = a.wp + (size_t)cg * nst * U_WSTAGE;
-    auto dma_weights = [&](int st, uint4* dstA) {                   // 1152 uint4 per stage, linear: 4.5 rounds of 256 lanes
-        const uint4* src = WP + (size_t)st * U_WSTAGE;
-#pragma unroll
         for (int k = 0; k < 5; ++k) {
-            if (k < 4 || wave_u < 2) {
-                const unsigned lds_dst = __builtin_amdgcn_readfirstlane(
-                    (unsigned)(size_t)(__attribute__((address_space(3))) uint4*)(dstA + 256 * k + 64 * wave_u));
-                const uint4* gsrc = src + 256 * k + tid;
-                unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-            }
+            const uint4* g = (pf_valid & (1u << k)) ? Xs + pf_off[k] : g_zero16;
+            dma64(g, buf + 64 * (4 * k + wave_u));
         }
     };
 
-    dma_weights(0, bufA);
-    load_patch(0);
+    dma_stage(0, lds);
     for (int st = 0; st < nst; ++st) {
-        __syncthreads();                                            // the previous stage's patch reads are done
-#pragma unroll
-        for (int k = 0; k < NPF; ++k)
-            patchB[pf_lds[k]] = (pf_valid & (1u << k)) ? pf[k] : make_uint4(0, 0, 0, 0);   // unconditional: no divergent waits
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this stage's weight DMAs (issued one stage ago) have landed
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this stage's DMAs (issued one stage ago) have landed
+        __builtin_amdgcn_s_barrier();                               // ... everybody's; and the other buffer's readers are done
         asm volatile("" ::: "memory");
-        const uint4* curA = bufA + (st & 1) * U_WSTAGE;
+        const uint4* cur = lds + (st & 1) * U_STAGE;
 #if defined(R3D_UP_ABL) && (R3D_UP_ABL & 16)
-        if (st + 1 < nst && st == 0) {
+        if (st + 1 < nst && st == 0) dma_stage(st + 1, lds + ((st + 1) & 1) * U_STAGE);
 #else
-        if (st + 1 < nst) {
+        if (st + 1 < nst) dma_stage(st + 1, lds + ((st + 1) & 1) * U_STAGE);
 #endif
-            dma_weights(st + 1, bufA + ((st + 1) & 1) * U_WSTAGE);
-            load_patch(st + 1);
-        }
 #pragma unroll
         for (int win = 0; win < 4; ++win) {                         // input shift (sy, sx): x(i - sy, j - sx)
             const int sy = win >> 1, sx = win & 1;
-            const int toff = -(sy * F_PATCH_W + sx);
+            const int toff = -(sy * U_PW + sx);
             h8 bh[2], bl[2];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
 #if defined(R3D_UP_ABL) && (R3D_UP_ABL & 8)
                 uint4 r0 = make_uint4(st, win, nt, 1), r1 = make_uint4(st, win, nt, 2);
 #else
-                uint4 r0 = patchB[boff[nt] + toff];
-                uint4 r1 = patchB[boff[nt] + toff + 2 * F_PATCH_PIX];
+                uint4 r0 = cur[boff[nt] + toff];
+                uint4 r1 = cur[boff[nt] + toff + 2 * U_PPLANE];
 #endif
                 bh[nt] = *reinterpret_cast<h8*>(&r0); bl[nt] = *reinterpret_cast<h8*>(&r1);
             }
@@ -567,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
 #if defined(R3D_UP_ABL) && (R3D_UP_ABL & 8)
                     uint4 q0 = make_uint4(st, t, 3, 1), q1 = make_uint4(st, t, 4, 2);
 #else
-                    uint4 q0 = curA[t * 128 + aoff], q1 = curA[t * 128 + aoff + 32];
+                    uint4 q0 = cur[t * 128 + aoff], q1 = cur[t * 128 + aoff + 32];
 #endif
                     const h8 ah = *reinterpret_cast<h8*>(&q0), al = *reinterpret_cast<h8*>(&q1);
 #pragma unroll
@@ -634,7 +626,11 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
 #pragma unroll
                     for (int cc = 0; cc < 5; ++cc) {
                         const int pb = (cc + 1) & 1, gx = Xq + ((cc + 1) >> 1);
+#if defined(R3D_UP_ABL) && (R3D_UP_ABL & 64)
+                        const float4 tv = make_float4(gy, gx, pa, pb);
+#else
                         const float4 tv = tls[((pa * 2 + pb) * 2 + hf) * 256 + gy * 16 + gx];
+#endif
 #pragma unroll
                         for (int dy = 0; dy < 2; ++dy) {
                             const int a_ = rr - dy;
@@ -674,8 +670,13 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
                         _Float16 x0, x1; split1(t * nv[ch], x0, x1); hi[ch] = x0; lo[ch] = x1;
                     }
                     const size_t pq = (size_t)(2 * (i0 + Y) + dy) * OW + (2 * (j0 + Xq) + dx);
+#if defined(R3D_UP_ABL) && (R3D_UP_ABL & 32)
+                    if (hi[0] == (_Float16)123.f && lo[3] == (_Float16)77.f)
+#endif
+                    {
                     d[pq] = *reinterpret_cast<uint4*>(&hi);
                     d[oplane + pq] = *reinterpret_cast<uint4*>(&lo);
+                    }
                 }
         }
     }

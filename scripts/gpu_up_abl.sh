@@ -13,7 +13,8 @@ for k,v in d.items():
         m=sum(v[-5:])/5/1e3; print(sys.argv[1], "%-44s %8s %8.1f us" % (k[0],k[1],m))
 PY
 }
+timeout 300 python -m pytest $R/tests/test_gpu_parity.py -m gpu -x -q -k "sr_ or synthesis" 2>&1 | tail -2
 run full
 cp $R/real3dportrait_amd/lib/libr3d_hip.so /tmp/keep.so
-for v in 2 6 10 18; do cp $R/scripts/probes/bin/libr3d_abl$v.so $R/real3dportrait_amd/lib/libr3d_hip.so; run abl$v; done
+for v in 32 64; do cp $R/scripts/probes/bin/libr3d_abl$v.so $R/real3dportrait_amd/lib/libr3d_hip.so; run abl$v; done
 cp /tmp/keep.so $R/real3dportrait_amd/lib/libr3d_hip.so
