@@ -170,12 +170,12 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
-    # ---- roofline of the dominant kernel family (the 4 conv launches of a frame), MFMA-bound -------------------
+    # ---- roofline of the dominant kernel (conv_mfma_f16x3_kernel: the two plain 3x3 convs of a frame), MFMA-bound ----
     # HIP event pairs recorded on the launch stream around every conv launch.  With frames pipelined over several
     # streams a bracket would also contain other frames' kernels, so the kernel's own duration is measured over the
     # same K frames issued on ONE stream right after the timed region (what rocprofv3 --stats sees with --streams 1).
     import ctypes
-    lib.r3d_profile_configure(1 << 1); lib.r3d_profile_reset()
+    lib.r3d_profile_configure((1 << 1) | (1 << 2)); lib.r3d_profile_reset()
     for i in range(K):
         clip.render_u8(rank * K + i, out=ring[i:i + 1])
     torch.cuda.synchronize()
@@ -183,8 +183,17 @@ def main():
     ms, cnt = ctypes.c_double(0), ctypes.c_int(0)
     _lib.check(lib.r3d_profile_read(1, ctypes.byref(ms), ctypes.byref(cnt)), "profile_read")
     flops = conv_flops_per_frame(128)
-    conv_ms_per_frame = ms.value / max(1, cnt.value) * 4
-    achieved_tf = sum(flops) / (conv_ms_per_frame * 1e-3) / 1e12 if cnt.value else 0.0
+    prec = os.environ.get("R3D_SR_PRECISION", "f16x3")
+    ums, ucnt = ctypes.c_double(0), ctypes.c_int(0)
+    _lib.check(lib.r3d_profile_read(2, ctypes.byref(ums), ctypes.byref(ucnt)), "profile_read")
+    if prec == "f32":       # the exact-f32 path runs all four convs on one kernel (per-phase transposed conv + FIR kernel)
+        dom_flops, launches = sum(flops), 4
+    else:                   # f16x3: plain convs (block0.conv1, block1.conv1) on the dominant kernel; the up-sampling convs
+        dom_flops, launches = flops[1] + flops[3], 2     # (block0/1.conv0 + FIR + activation) are fused into upconv_fir_f16x3_kernel
+    conv_ms_per_frame = ms.value / max(1, cnt.value) * launches
+    achieved_tf = dom_flops / (conv_ms_per_frame * 1e-3) / 1e12 if cnt.value else 0.0
+    up_ms_per_frame = ums.value / max(1, ucnt.value) * 2
+    up_tf = (flops[0] + flops[2]) / (up_ms_per_frame * 1e-3) / 1e12 if (ucnt.value and prec != "f32") else None
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -192,19 +201,22 @@ def main():
             traffic = json.load(open(tpath)).get("conv_bytes_per_launch_" + os.environ.get("R3D_SR_PRECISION", "f16x3"))
         except Exception:
             traffic = None
-    prec = os.environ.get("R3D_SR_PRECISION", "f16x3")
     if prec == "f32":       # exact fp32 on v_mfma_f32_32x32x2_f32
         kname, peak, products = "conv_mfma_kernel", PEAK_F32_MFMA_TFLOPS, 1
     else:                   # fp32-accurate 3-term fp16 split on v_mfma_f32_32x32x16_f16: 3 MFMA products per algorithmic MAC
-        kname, peak, products = "conv_mfma_f16x3_kernel + tconv_mfma_f16x3_kernel", PEAK_F16_MFMA_TFLOPS, 3
+        kname, peak, products = "conv_mfma_f16x3_kernel", PEAK_F16_MFMA_TFLOPS, 3
     roofline = {"kernel": kname, "bound": "mfma", "achieved": round(achieved_tf, 2),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(achieved_tf / peak, 4),
-                "traffic": traffic, "launches_per_frame": 4,
+                "traffic": traffic, "launches_per_frame": launches,
                 "avg_launch_ms": round(ms.value / max(1, cnt.value), 4),
-                "algorithmic_gflop_per_launch": round(sum(flops) / 4 / 1e9, 3),
+                "algorithmic_gflop_per_launch": round(dom_flops / launches / 1e9, 3),
                 "mfma_products_per_mac": products,
                 "executed_tflops": round(achieved_tf * products, 1), "pipe_frac": round(achieved_tf * products / peak, 4),
                 "precision": prec}
+    if up_tf is not None:   # second kernel family, reported beside the dominant one (its time includes the fused FIR/activation)
+        roofline["upconv_fir_f16x3_kernel"] = {"launches_per_frame": 2, "avg_launch_ms": round(ums.value / max(1, ucnt.value), 4),
+                                               "achieved": round(up_tf, 2), "frac": round(up_tf / peak, 4),
+                                               "pipe_frac": round(up_tf * products / peak, 4)}
 
     out = None
     if rank == 0:
@@ -226,7 +238,7 @@ def main():
         for i in range(nb):
             clip.render_u8(i % K, out=ring[(i % K):(i % K) + 1])
         torch.cuda.synchronize()
-        names = ["render", "conv_mfma", "fir", "torgb", "sr_pack", "layout", "misc"]
+        names = ["render", "conv_mfma", "upconv_fir", "torgb", "sr_pack", "layout", "misc"]
         bd = {}
         for j, nme in enumerate(names):
             _lib.check(lib.r3d_profile_read(j, ctypes.byref(ms), ctypes.byref(cnt)), "profile_read")

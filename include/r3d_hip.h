@@ -182,7 +182,7 @@ int r3d_event_destroy(void* ev);
 enum r3d_prof_id {
     R3D_PROF_RENDER = 0,     /* render_kernel<..> (fused ray kernel)                       */
     R3D_PROF_CONV = 1,       /* conv_mfma_kernel (3x3 / transposed-conv implicit GEMM)     */
-    R3D_PROF_FIR = 2,        /* fir_bias_act_kernel                                        */
+    R3D_PROF_UPCONV = 2,     /* up-sampling conv: fused transposed conv + FIR (f16x3); FIR (f32)  */
     R3D_PROF_TORGB = 3,      /* torgb_upsample_kernel                                      */
     R3D_PROF_PACK = 4,       /* SR weight modulation / packing kernels                     */
     R3D_PROF_LAYOUT = 5,     /* layout kernels (planes_to_nhwc, nchw<->cb8, frames_to_u8)  */

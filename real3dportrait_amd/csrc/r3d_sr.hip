@@ -539,7 +539,7 @@ extern "C" int r3d_sr_block_forward(const void* prepacked, const void* styles, i
         hipLaunchKernelGGL(conv_mfma_kernel, dim3(maxtiles, Cout / BLOCK_M, N * 4), dim3(256), 0, st, a);
     }
     {
-    ProfScope ps(R3D_PROF_FIR, st);
+    ProfScope ps(R3D_PROF_UPCONV, st);
     hipLaunchKernelGGL(fir_bias_act_kernel, dim3((OH * OW * 2 + 255) / 256, Cout / 8, N), dim3(256), 0, st,
                        T, (size_t)Cout * TH * TW, pk + L.b0, L.total, y0, (size_t)Cout * OH * OW, Cout, OH, OW, clamp);
     }

@@ -416,7 +416,8 @@ static constexpr int U_PATCH = 4 * U_PPLANE;                        // uint4: [h
 static constexpr int U_STAGE = U_PATCH + U_WSTAGE;                  // 2432 uint4 per stage buffer
 static constexpr int U_LDS_UINT4 = 2 * U_STAGE;                     // double-buffered: 77.8 KB (epilogue slice: 2048 uint4)
 
-__device__ uint4 g_zero16[1];                                       // DMA source of zero-filled (out-of-image / padding) patch slots
+__device__ uint4 g_zero16[1];
+                                       // DMA source of zero-filled (out-of-image / padding) patch slots
 
 struct UpArgs {
     const uint4* x; size_t x_stride_n;          // SPLIT input [hi|lo][Cin/8][H][W]
@@ -524,18 +525,13 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
             dma64(g, buf + 64 * (4 * k + wave_u));
         }
     };
-
     dma_stage(0, lds);
     for (int st = 0; st < nst; ++st) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this stage's DMAs (issued one stage ago) have landed
         __builtin_amdgcn_s_barrier();                               // ... everybody's; and the other buffer's readers are done
         asm volatile("" ::: "memory");
         const uint4* cur = lds + (st & 1) * U_STAGE;
-#if defined(R3D_UP_ABL) && (R3D_UP_ABL & 16)
-        if (st + 1 < nst && st == 0) dma_stage(st + 1, lds + ((st + 1) & 1) * U_STAGE);
-#else
         if (st + 1 < nst) dma_stage(st + 1, lds + ((st + 1) & 1) * U_STAGE);
-#endif
 #pragma unroll
         for (int win = 0; win < 4; ++win) {                         // input shift (sy, sx): x(i - sy, j - sx)
             const int sy = win >> 1, sx = win & 1;
@@ -543,12 +539,8 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
             h8 bh[2], bl[2];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-#if defined(R3D_UP_ABL) && (R3D_UP_ABL & 8)
-                uint4 r0 = make_uint4(st, win, nt, 1), r1 = make_uint4(st, win, nt, 2);
-#else
                 uint4 r0 = cur[boff[nt] + toff];
                 uint4 r1 = cur[boff[nt] + toff + 2 * U_PPLANE];
-#endif
                 bh[nt] = *reinterpret_cast<h8*>(&r0); bl[nt] = *reinterpret_cast<h8*>(&r1);
             }
 #pragma unroll
@@ -556,48 +548,36 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
 #pragma unroll
                 for (int kx = 2 * sx; kx <= (sx ? 2 : 1); ++kx) {
                     const int t = ky * 3 + kx, p = (ky & 1) * 2 + (kx & 1);
-#if defined(R3D_UP_ABL) && (R3D_UP_ABL & 8)
-                    uint4 q0 = make_uint4(st, t, 3, 1), q1 = make_uint4(st, t, 4, 2);
-#else
                     uint4 q0 = cur[t * 128 + aoff], q1 = cur[t * 128 + aoff + 32];
-#endif
                     const h8 ah = *reinterpret_cast<h8*>(&q0), al = *reinterpret_cast<h8*>(&q1);
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
-#if defined(R3D_UP_ABL) && (R3D_UP_ABL & 4)
-                        acc[p][nt][0] += (float)(al[0] * bh[nt][0] + ah[1] * bl[nt][1]);
-#else
                         acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[nt], acc[p][nt], 0, 0, 0);
                         acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[nt], acc[p][nt], 0, 0, 0);
                         acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[nt], acc[p][nt], 0, 0, 0);
-#endif
                     }
                 }
         }
     }
 
-#ifdef R3D_UP_ABL
-    if (R3D_UP_ABL & 2) {       // ablation: no epilogue (keep the accumulators alive)
-        float sum = 0.f;
-        for (int p = 0; p < 4; ++p) for (int nt = 0; nt < 2; ++nt) for (int r = 0; r < 16; ++r) sum += acc[p][nt][r];
-        if (sum == 12345.678f) a.y[0] = make_uint4(1, 2, 3, 4);
-        return;
-    }
-#endif
-    // ---- epilogue: 4 slices of 8 couts through LDS: T (demodulated, fp32) [phase][cout half][16x16][4] -> FIR -> y -------
-    float4* tls = reinterpret_cast<float4*>(lds);
+    // ---- epilogue: 4 slices of 8 couts through LDS.  T (demodulated, fp32) [pa][pb][cout half][16x16] float4 -> horizontal
+    // 4-tap pass -> H [pa][half][16 rows][28 cols] -> vertical 4-tap pass + bias + lrelu*sqrt2 (+clamp) -> * next styles ->
+    // fp16 hi/lo -> y.  Separable (8 instead of 16 FMAs per output), every pass conflict-free in LDS, arithmetic on float
+    // pairs (v_pk_fma_f32 / v_cvt_pk_f16_f32).
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
+    float4* tls = reinterpret_cast<float4*>(lds);                   // T: 2048 float4
+    float4* hls = tls + 2048;                                       // H: [pa][half][gy][32] (28 used), column swizzled by 8*half
     const int co0 = cg * 32;
     const float* D = a.out_scale + (size_t)n * a.vec_stride_n + co0;
     const float* Bv = a.bias + (size_t)n * a.vec_stride_n + co0;
     const float* NS = a.next_scale + (size_t)n * a.vec_stride_n + co0;
     const int OH = 2 * a.H, OW = 2 * a.W;
     const size_t oplane = (size_t)(a.Cout >> 3) * OH * OW;
-    const int Y = tid >> 4, Xq = tid & 15;
-    const bool fir_thread = Y < U_TILE && Xq < U_TILE && i0 + Y < a.H && j0 + Xq < a.W;
-    const float f1[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+    const float c0 = 0.25f, c1 = 0.75f;                             // [1,3,3,1]/8 * 2 per axis (gain 4 in 2-D)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        __syncthreads();                                            // main loop / previous slice's FIR reads are done
+        if (g == 0) __syncthreads();                                // the main loop's LDS reads are done
         const float4 d4 = *reinterpret_cast<const float4*>(D + 8 * g + 4 * h);
 #pragma unroll
         for (int p = 0; p < 4; ++p)
@@ -608,76 +588,75 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
                                                           acc[p][nt][4 * g + 2] * d4.z, acc[p][nt][4 * g + 3] * d4.w);
             }
         __syncthreads();
-#ifdef R3D_UP_ABL
-        if (R3D_UP_ABL & 1) continue;
-#endif
-        if (fir_thread) {
-            float o[2][2][8];
+        {   // horizontal: thread (X = tid & 15, gy = tid >> 4) x (pa, half): T columns 2X+1 .. 2X+5 -> H columns 2X, 2X+1
+            const int X = tid & 15, gy = tid >> 4;
+            if (X < U_TILE) {
 #pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                float4 s[2][2];
+                for (int k = 0; k < 4; ++k) {
+                    const int half = k & 1, pa = k >> 1;
+                    f2 ta[5], tb[5];
 #pragma unroll
-                for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                    for (int dx = 0; dx < 2; ++dx) s[dy][dx] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int rr = 0; rr < 5; ++rr) {                    // T row 2(i0+Y) - 1 + rr = phase row (rr+1)&1 at grid row Y + (rr+1)/2
-                    const int pa = (rr + 1) & 1, gy = Y + ((rr + 1) >> 1);
-#pragma unroll
-                    for (int cc = 0; cc < 5; ++cc) {
-                        const int pb = (cc + 1) & 1, gx = Xq + ((cc + 1) >> 1);
-#if defined(R3D_UP_ABL) && (R3D_UP_ABL & 64)
-                        const float4 tv = make_float4(gy, gx, pa, pb);
-#else
-                        const float4 tv = tls[((pa * 2 + pb) * 2 + hf) * 256 + gy * 16 + gx];
-#endif
-#pragma unroll
-                        for (int dy = 0; dy < 2; ++dy) {
-                            const int a_ = rr - dy;
-                            if (a_ < 0 || a_ > 3) continue;
-#pragma unroll
-                            for (int dx = 0; dx < 2; ++dx) {
-                                const int b_ = cc - dx;
-                                if (b_ < 0 || b_ > 3) continue;
-                                const float w = f1[a_] * f1[b_];
-                                s[dy][dx].x += tv.x * w; s[dy][dx].y += tv.y * w; s[dy][dx].z += tv.z * w; s[dy][dx].w += tv.w * w;
-                            }
-                        }
+                    for (int cc = 0; cc < 5; ++cc) {                // T column 2X+1+cc = phase (cc+1)&1 at grid column X + (cc+1)/2
+                        const float4 t4 = tls[(((pa * 2 + ((cc + 1) & 1)) * 2 + half) * 16 + gy) * 16 + X + ((cc + 1) >> 1)];
+                        ta[cc] = f2{t4.x, t4.y}; tb[cc] = f2{t4.z, t4.w};
                     }
-                }
-#pragma unroll
-                for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
                     for (int dx = 0; dx < 2; ++dx) {
-                        o[dy][dx][4 * hf + 0] = s[dy][dx].x; o[dy][dx][4 * hf + 1] = s[dy][dx].y;
-                        o[dy][dx][4 * hf + 2] = s[dy][dx].z; o[dy][dx][4 * hf + 3] = s[dy][dx].w;
-                    }
-            }
-            const float4 b0 = *reinterpret_cast<const float4*>(Bv + 8 * g), b1 = *reinterpret_cast<const float4*>(Bv + 8 * g + 4);
-            const float4 n0 = *reinterpret_cast<const float4*>(NS + 8 * g), n1 = *reinterpret_cast<const float4*>(NS + 8 * g + 4);
-            const float bv[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w}, nv[8] = {n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w};
-            uint4* d = a.y + (size_t)n * a.y_stride_n + (size_t)((co0 >> 3) + g) * OH * OW;
-#pragma unroll
-            for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 2; ++dx) {
-                    h8 hi, lo;
-#pragma unroll
-                    for (int ch = 0; ch < 8; ++ch) {
-                        float t = o[dy][dx][ch] + bv[ch];
-                        t = (t < 0.f ? t * 0.2f : t) * 1.4142135623730951f;
-                        if (a.clamp >= 0.f) t = fminf(fmaxf(t, -a.clamp), a.clamp);
-                        _Float16 x0, x1; split1(t * nv[ch], x0, x1); hi[ch] = x0; lo[ch] = x1;
-                    }
-                    const size_t pq = (size_t)(2 * (i0 + Y) + dy) * OW + (2 * (j0 + Xq) + dx);
-#if defined(R3D_UP_ABL) && (R3D_UP_ABL & 32)
-                    if (hi[0] == (_Float16)123.f && lo[3] == (_Float16)77.f)
-#endif
-                    {
-                    d[pq] = *reinterpret_cast<uint4*>(&hi);
-                    d[oplane + pq] = *reinterpret_cast<uint4*>(&lo);
+                        const f2 ha = (ta[dx] + ta[dx + 3]) * c0 + (ta[dx + 1] + ta[dx + 2]) * c1;
+                        const f2 hb = (tb[dx] + tb[dx + 3]) * c0 + (tb[dx + 1] + tb[dx + 2]) * c1;
+                        hls[((pa * 2 + half) * 16 + gy) * 32 + ((2 * X + dx + 8 * half) & 31)] = make_float4(ha.x, ha.y, hb.x, hb.y);
                     }
                 }
+            }
+        }
+        __syncthreads();
+        {   // vertical: item (row pair rp, column oc, half): H rows 2rp+1 .. 2rp+5 -> y rows 2rp, 2rp+1 (4 couts each)
+            const float4 b4 = *reinterpret_cast<const float4*>(Bv + 8 * g + 4 * (tid & 1));
+            const float4 n4 = *reinterpret_cast<const float4*>(NS + 8 * g + 4 * (tid & 1));
+            const f2 ba = f2{b4.x, b4.y}, bb = f2{b4.z, b4.w};
+            const float m = 1.4142135623730951f;
+            const f2 ma = f2{n4.x, n4.y} * m, mb = f2{n4.z, n4.w} * m;
+            uint4* d = a.y + (size_t)n * a.y_stride_n + (size_t)((co0 >> 3) + g) * OH * OW;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int q = tid + 256 * k;
+                const int half = q & 1, oc = (q >> 1) & 31, rp = q >> 6;
+                const bool live = rp < U_TILE && oc < 2 * U_TILE;
+                f2 ha[5], hb[5];
+#pragma unroll
+                for (int rr = 0; rr < 5; ++rr) {                    // H row 2rp+1+rr = phase (rr+1)&1 at grid row rp + (rr+1)/2
+                    const int gyy = live ? rp + ((rr + 1) >> 1) : 0;
+                    const float4 t4 = hls[((((rr + 1) & 1) * 2 + half) * 16 + gyy) * 32 + ((oc + 8 * half) & 31)];
+                    ha[rr] = f2{t4.x, t4.y}; hb[rr] = f2{t4.z, t4.w};
+                }
+#pragma unroll
+                for (int dy = 0; dy < 2; ++dy) {
+                    f2 va = ba + (ha[dy] + ha[dy + 3]) * c0 + (ha[dy + 1] + ha[dy + 2]) * c1;
+                    f2 vb = bb + (hb[dy] + hb[dy + 3]) * c0 + (hb[dy + 1] + hb[dy + 2]) * c1;
+                    va = __builtin_elementwise_max(va, va * 0.2f);  // leaky relu (slope 0.2); sqrt(2) gain is inside ma/mb
+                    vb = __builtin_elementwise_max(vb, vb * 0.2f);
+                    if (a.clamp >= 0.f) {                           // conv_clamp acts on the gained activation
+                        const f2 lim = f2{a.clamp, a.clamp} * 0.7071067811865476f;
+                        va = __builtin_elementwise_min(__builtin_elementwise_max(va, -lim), lim);
+                        vb = __builtin_elementwise_min(__builtin_elementwise_max(vb, -lim), lim);
+                    }
+                    const f2 big = f2{65504.f, 65504.f};
+                    va = __builtin_elementwise_min(__builtin_elementwise_max(va * ma, -big), big);
+                    vb = __builtin_elementwise_min(__builtin_elementwise_max(vb * mb, -big), big);
+                    const hh2 hia = __builtin_convertvector(va, hh2), hib = __builtin_convertvector(vb, hh2);
+                    const hh2 loa = __builtin_convertvector(va - __builtin_convertvector(hia, f2), hh2);
+                    const hh2 lob = __builtin_convertvector(vb - __builtin_convertvector(hib, f2), hh2);
+                    const unsigned h0 = *reinterpret_cast<const unsigned*>(&hia), h1 = *reinterpret_cast<const unsigned*>(&hib);
+                    const unsigned l0 = *reinterpret_cast<const unsigned*>(&loa), l1 = *reinterpret_cast<const unsigned*>(&lob);
+                    // lanes 2j (couts 0-3) and 2j+1 (couts 4-7) hold the same pixel: the even lane stores the 16-byte hi word,
+                    // the odd lane the lo word
+                    const unsigned s0 = half ? h0 : l0, s1 = half ? h1 : l1;
+                    const unsigned r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+                    const uint4 w = half ? make_uint4(r0, r1, l0, l1) : make_uint4(h0, h1, r0, r1);
+                    const int oy = 2 * (i0 + rp) + dy, ox = 2 * j0 + oc;
+                    if (live && oy < OH && ox < OW) d[(half ? oplane : 0) + (size_t)oy * OW + ox] = w;
+                }
+            }
         }
     }
 }
@@ -878,7 +857,7 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
         u.ntiles = u.tiles_x * ((Hin + U_TILE - 1) / U_TILE);
         u.tiles_per_xcd = (u.ntiles + 7) / 8;
         u.clamp = clamp;
-        ProfScope ps(R3D_PROF_CONV, st);
+        ProfScope ps(R3D_PROF_UPCONV, st);
         hipLaunchKernelGGL(upconv_fir_f16x3_kernel, dim3(8 * u.tiles_per_xcd * (Cout / 32), N), dim3(256), 0, st, u);
     } else if (up) {
         // ---- conv0: stride-2 transposed conv as 4 phases -> T (demodulated, fp32), then FIR + bias + lrelu -> SPLIT ----
@@ -899,7 +878,7 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
             ProfScope ps(R3D_PROF_CONV, st);
             launch_conv2(a, maxtiles, N, st);
         }
-        ProfScope ps(R3D_PROF_FIR, st);
+        ProfScope ps(R3D_PROF_UPCONV, st);
         hipLaunchKernelGGL(fir_bias_act_split_kernel, dim3((Hin * Win + 255) / 256, Cout / 8, N), dim3(256), 0, st,
                            T, 4 * pplane, pk + L.b0, pk + L.s1, L.total, y0, (size_t)Cout / 8 * OH * OW * 2, Cout, Hin, Win, clamp);
     } else {

@@ -6,3 +6,13 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA S
   rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/pmcr_$tag -o p -- python $R/scripts/prof_render.py 128 48 48 3 > $R/gpurun_out/pmcr_$tag.log 2>&1
 done
 ls $R/gpurun_out
+python - <<'PY'
+import csv, glob, os, collections
+R=os.environ["R"]
+for f in sorted(glob.glob(R+"/gpurun_out/pmcr_*/p_counter_collection.csv")):
+    acc=collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if "render_kernel" in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k,v in acc.items(): print("%-34s %16.0f  (n=%d)" % (k, sum(v)/len(v), len(v)))
+PY

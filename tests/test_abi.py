@@ -29,7 +29,7 @@ def test_version_and_sizes():
     lib = _lib.load()
     assert lib.r3d_version() >= 10
     assert lib.r3d_render_workspace_bytes(1, 16384, 48, 48) >= 2 * 16384 * 4
-    assert lib.r3d_sr_block_prepacked_bytes(32, 256) == (9 * 32 * 256 + 9 * 256 * 256) * 4
+    assert lib.r3d_sr_block_prepacked_bytes(32, 256) == (2 * 9 * 32 * 256 + 9 * 256 * 256) * 4   # conv0 in two layouts + conv1
     assert lib.r3d_sr_block_styles_bytes(2, 32, 256) > 2 * (32 + 4 * 256) * 4
     assert lib.r3d_sr_block_workspace_bytes(1, 32, 256, 128, 128) > 256 * 257 * 257 * 4
 
