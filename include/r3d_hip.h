@@ -43,9 +43,12 @@ const char* r3d_last_error(void);
  * bilinear tap is one contiguous 128-byte read, optionally fusing the per-frame `cano + secc` add.
  * Replaces: the plane add in OSAvatarSECC_Img2plane.cal_plane_given_cano (modules/real3d/
  * secc_img2plane.py:73-81) + the reshape at modules/eg3ds/volumetric_rendering/renderer.py:68.
- * `add` may be NULL. */
+ * `add` may be NULL.  add_flip: bit 2k flips plane k of `add` along H, bit 2k+1 along W, while it is read -- the
+ * torch.flip calls SegFormerSECC2PlaneBackbone.forward applies to its conv output (modules/real3d/segformer.py:722-728:
+ * planes 0,1 along H, plane 2 along H and W = 0b110101 = 53) when `add` is the raw to_plane_cnn output; 0 = none. */
+#define R3D_SECC_PLANE_FLIPS 53
 int r3d_planes_to_nhwc(const float* planes_nchw, const float* add_nchw, float* planes_nhwc,
-                       int N, int C, int H, int W, r3d_stream_t stream);
+                       int N, int C, int H, int W, int add_flip, r3d_stream_t stream);
 
 /* --- A1 ray generation --------------------------------------------------------------------------
  * Replaces RaySampler.forward(cam2world[N,4,4], intrinsics[N,3,3], resolution)
@@ -161,6 +164,12 @@ int r3d_conv_forward(const void* prepacked, int N, int Cin, int Cout, int H, int
                      int act, float act_slope, float act_gain, float clamp,
                      void* y, int y_format, const float* next_scale, size_t next_scale_stride,
                      void* workspace, size_t workspace_bytes, r3d_stream_t stream);
+
+/* torch.nn.UpsamplingBilinear2d(scale_factor=2) (align_corners=True), the resampling step inside to_plane_cnn
+ * (modules/real3d/segformer.py:691-700), between two r3d_conv_forward layers: x fp32 channel-blocked [N,C/8,H,W,8] ->
+ * y at 2H x 2W in R3D_FMT_CB8 or R3D_FMT_SPLIT (scaled by next_scale, NULL = 1).  C % 8 == 0. */
+int r3d_upsample2x_bilinear(const float* x_cb8, int N, int C, int H, int W, void* y, int y_format,
+                            const float* next_scale, size_t next_scale_stride, r3d_stream_t stream);
 
 /* --- output side --------------------------------------------------------------------------------
  * clamp(-1,1) -> (x+1)*127.5 -> uint8 HWC, the conversion real3d_infer.py:495-521 does on the host

@@ -107,6 +107,23 @@ class Oracle:
             raise RuntimeError("r3d_oracle_conv2d failed")
         return y
 
+    def upsample2x_bilinear(self, x):
+        x = _f(x)
+        C, H, W = x.shape
+        y = np.empty((C, 2 * H, 2 * W), np.float32)
+        self.lib.r3d_oracle_upsample2x_bilinear(_p(x), C, H, W, _p(y))
+        return y
+
+    def to_plane_cnn(self, x, plan, params, up_before):
+        """SegFormerSECC2PlaneBackbone.to_plane_cnn + the view/flip/stack of forward (segformer.py:691-700,721-729):
+        x [256,h,w] -> secc planes [3,32,2h,2w]."""
+        for i, ((ci, co, k, lrelu), (w, b)) in enumerate(zip(plan, params)):
+            if i == up_before:
+                x = self.upsample2x_bilinear(x)
+            x = self.conv2d(x, w, b, 0.01 if lrelu else None)
+        p = x.reshape(3, -1, x.shape[-2], x.shape[-1])
+        return np.stack([p[0][:, ::-1, :], p[1][:, ::-1, :], p[2][:, ::-1, ::-1]]).astype(np.float32)
+
     def conv_stack(self, x, plan, params):
         """A FUSION_STACKS plan [(ci, co, k, lrelu)] with params [(w, b)]; torch.nn.LeakyReLU() default slope 0.01."""
         for (ci, co, k, lrelu), (w, b) in zip(plan, params):

@@ -597,6 +597,30 @@ R3D_API int r3d_oracle_conv2d(const float* x, int Ci, int Hh, int Ww, const floa
     return 0;
 }
 
+/* torch.nn.UpsamplingBilinear2d(scale_factor=2): F.interpolate(mode='bilinear', align_corners=True), as used inside
+ * SegFormerSECC2PlaneBackbone.to_plane_cnn (modules/real3d/segformer.py:698).  ATen upsample_bilinear2d: source index =
+ * dst * (in-1)/(out-1), neighbours clamped at the last row/col.  x [C][H][W] -> y [C][2H][2W]. */
+R3D_API int r3d_oracle_upsample2x_bilinear(const float* x, int Cc, int Hh, int Ww, float* y)
+{
+    const int Oh = 2 * Hh, Ow = 2 * Ww;
+    const float sh = Oh > 1 ? (float)(Hh - 1) / (float)(Oh - 1) : 0.0f, sw = Ow > 1 ? (float)(Ww - 1) / (float)(Ow - 1) : 0.0f;
+    for (int c = 0; c < Cc; ++c)
+        for (int oy = 0; oy < Oh; ++oy) {
+            const float fy = sh * oy;
+            const int y0 = (int)fy, y1 = y0 + (y0 < Hh - 1 ? 1 : 0);
+            const float ly = fy - y0, hy = 1.0f - ly;
+            for (int ox = 0; ox < Ow; ++ox) {
+                const float fx = sw * ox;
+                const int x0 = (int)fx, x1 = x0 + (x0 < Ww - 1 ? 1 : 0);
+                const float lx = fx - x0, hx = 1.0f - lx;
+                const float* xc = x + (size_t)c * Hh * Ww;
+                y[((size_t)c * Oh + oy) * Ow + ox] = hy * (hx * xc[y0 * Ww + x0] + lx * xc[y0 * Ww + x1]) +
+                                                     ly * (hx * xc[y1 * Ww + x0] + lx * xc[y1 * Ww + x1]);
+            }
+        }
+    return 0;
+}
+
 /* One SynthesisBlockNoUp (architecture 'skip', in_channels != 0)  modules/eg3ds/models/superresolution.py:215-250:
  *   conv0 :233 and conv1 :234 are both up=1 SynthesisLayers, img.add_(torgb(x)) :247 with no upsample (:241-243).
  * x [Ci][H][W], img [3][H][W] -> x_out [Co][H][W], img_out [3][H][W]. */

@@ -31,13 +31,16 @@ static constexpr int kMaxSamples = 192;      // Nc + Nf
 static constexpr int kRayArr = kMaxSamples + 8;
 
 // -------------------------------------------------------------------------------------------------
-// layout kernel: NCHW [N*3][C][H*W] (+ optional add) -> [N*3][H*W][C]
+// layout kernel: NCHW [N*3][C][H*W] (+ optional add, optionally flipped along H / W per plane) -> [N*3][H*W][C]
+// add_flip: bit 2k = flip H, bit 2k+1 = flip W of plane k of `add` (the flips SegFormerSECC2PlaneBackbone.forward applies to
+// its conv output, modules/real3d/segformer.py:722-728, fused with the cano + secc add of secc_img2plane.py:76-77)
 // -------------------------------------------------------------------------------------------------
 __global__ void planes_to_nhwc_kernel(const float* __restrict__ src, const float* __restrict__ add,
-                                      float* __restrict__ dst, int C, int HW)
+                                      float* __restrict__ dst, int C, int HW, int W, int add_flip)
 {
     __shared__ float tile[32][33];
     const int p = blockIdx.z;
+    const int fl = (add_flip >> (2 * (p % 3))) & 3;
     const int hw0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
     const int tx = threadIdx.x, ty = threadIdx.y;   // 32 x 8
     const float* s = src + (size_t)p * C * HW;
@@ -45,7 +48,17 @@ __global__ void planes_to_nhwc_kernel(const float* __restrict__ src, const float
     for (int j = ty; j < 32; j += 8) {
         const int c = c0 + j, hw = hw0 + tx;
         float v = 0.f;
-        if (c < C && hw < HW) { v = s[(size_t)c * HW + hw]; if (a) v += a[(size_t)c * HW + hw]; }
+        if (c < C && hw < HW) {
+            v = s[(size_t)c * HW + hw];
+            if (a) {
+                int hwa = hw;
+                if (fl) {
+                    const int H = HW / W, h = hw / W, w = hw - h * W;
+                    hwa = ((fl & 1) ? H - 1 - h : h) * W + ((fl & 2) ? W - 1 - w : w);
+                }
+                v += a[(size_t)c * HW + hwa];
+            }
+        }
         tile[j][tx] = v;
     }
     __syncthreads();
@@ -838,13 +851,13 @@ static void launch_render(const RenderArgs& a, int R, int grid, hipStream_t st)
 using namespace r3d;
 
 extern "C" int r3d_planes_to_nhwc(const float* planes_nchw, const float* add_nchw, float* planes_nhwc,
-                                  int N, int C, int H, int W, r3d_stream_t stream)
+                                  int N, int C, int H, int W, int add_flip, r3d_stream_t stream)
 {
-    if (!planes_nchw || !planes_nhwc || N <= 0 || C <= 0 || H <= 0 || W <= 0) { set_error("planes_to_nhwc: bad argument"); return R3D_ERR_INVALID_ARG; }
+    if (!planes_nchw || !planes_nhwc || N <= 0 || C <= 0 || H <= 0 || W <= 0 || add_flip < 0 || add_flip > 63) { set_error("planes_to_nhwc: bad argument"); return R3D_ERR_INVALID_ARG; }
     const int HW = H * W;
     dim3 grid((HW + 31) / 32, (C + 31) / 32, N * 3), block(32, 8);
     ProfScope ps(R3D_PROF_LAYOUT, (hipStream_t)stream);
-    hipLaunchKernelGGL(planes_to_nhwc_kernel, grid, block, 0, (hipStream_t)stream, planes_nchw, add_nchw, planes_nhwc, C, HW);
+    hipLaunchKernelGGL(planes_to_nhwc_kernel, grid, block, 0, (hipStream_t)stream, planes_nchw, add_nchw, planes_nhwc, C, HW, W, add_flip);
     return check_launch("planes_to_nhwc");
 }
 

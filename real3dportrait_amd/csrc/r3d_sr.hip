@@ -609,3 +609,12 @@ extern "C" int r3d_conv_forward(const void* prepacked, int N, int Cin, int Cout,
                               bias, bias_stride, act, act_slope, act_gain, clamp, y, y_format, next_scale, next_scale_stride,
                               workspace, (hipStream_t)stream);
 }
+
+extern "C" int r3d_upsample2x_bilinear(const float* x_cb8, int N, int C, int H, int W, void* y, int y_format,
+                                       const float* next_scale, size_t next_scale_stride, r3d_stream_t stream)
+{
+    using namespace r3d;
+    if (!x_cb8 || !y || N <= 0 || C <= 0 || (C & 7) || H <= 0 || W <= 0) { set_error("upsample2x_bilinear: bad argument (C %d must be a multiple of 8)", C); return R3D_ERR_INVALID_ARG; }
+    if (y_format != R3D_FMT_CB8 && y_format != R3D_FMT_SPLIT) { set_error("upsample2x_bilinear: y_format %d must be CB8 or SPLIT", y_format); return R3D_ERR_INVALID_ARG; }
+    return upsample2x_bilinear_f16x3(x_cb8, N, C, H, W, y, y_format, next_scale, next_scale_stride, (hipStream_t)stream);
+}

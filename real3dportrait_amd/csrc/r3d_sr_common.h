@@ -57,4 +57,7 @@ int conv_forward_f16x3(const void* prepacked, int N, int Cin, int Cout, int H, i
                        void* y, int y_format, const float* next_scale, size_t next_scale_stride,
                        void* workspace, hipStream_t st);
 
+int upsample2x_bilinear_f16x3(const float* x_cb8, int N, int C, int H, int W, void* y, int y_format,
+                              const float* next_scale, size_t next_scale_stride, hipStream_t st);
+
 }  // namespace r3d

@@ -784,6 +784,63 @@ __global__ void cb8_to_nchw2_kernel(const float* __restrict__ src, float* __rest
     d[(size_t)4 * HW] = b.x; d[(size_t)5 * HW] = b.y; d[(size_t)6 * HW] = b.z; d[(size_t)7 * HW] = b.w;
 }
 
+// ---- torch.nn.UpsamplingBilinear2d(scale_factor=2) (align_corners=True) between two conv layers of to_plane_cnn
+// (modules/real3d/segformer.py:691-700): fp32 channel-blocked in -> SPLIT (or fp32 channel-blocked) out at 2H x 2W.
+// Source index = dst * (in - 1) / (out - 1), lambda in fp32, as ATen's upsample_bilinear2d (area_pixel_compute_scale).
+__global__ void upsample2x_bilinear_kernel(const float* __restrict__ x, uint4* __restrict__ y_split, float* __restrict__ y_cb8,
+                                           const float* __restrict__ next_scale, size_t next_scale_stride_n, int C, int H, int W)
+{
+    const int n = blockIdx.z, cb = blockIdx.y;
+    const int OH = 2 * H, OW = 2 * W;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= OH * OW) return;
+    const int oy = p / OW, ox = p - oy * OW;
+    const float sh = OH > 1 ? (float)(H - 1) / (float)(OH - 1) : 0.f, sw = OW > 1 ? (float)(W - 1) / (float)(OW - 1) : 0.f;
+    const float fy = sh * oy, fx = sw * ox;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly = fy - y0, lx = fx - x0, hy = 1.f - ly, hx = 1.f - lx;
+    const float* X = x + ((size_t)n * (C / 8) + cb) * H * W * 8;
+    float v[8];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const float4 a = *reinterpret_cast<const float4*>(X + ((size_t)y0 * W + x0) * 8 + 4 * half);
+        const float4 b = *reinterpret_cast<const float4*>(X + ((size_t)y0 * W + x1) * 8 + 4 * half);
+        const float4 c = *reinterpret_cast<const float4*>(X + ((size_t)y1 * W + x0) * 8 + 4 * half);
+        const float4 d = *reinterpret_cast<const float4*>(X + ((size_t)y1 * W + x1) * 8 + 4 * half);
+        v[4 * half + 0] = hy * (hx * a.x + lx * b.x) + ly * (hx * c.x + lx * d.x);
+        v[4 * half + 1] = hy * (hx * a.y + lx * b.y) + ly * (hx * c.y + lx * d.y);
+        v[4 * half + 2] = hy * (hx * a.z + lx * b.z) + ly * (hx * c.z + lx * d.z);
+        v[4 * half + 3] = hy * (hx * a.w + lx * b.w) + ly * (hx * c.w + lx * d.w);
+    }
+    if (y_cb8) {
+        float4* d = reinterpret_cast<float4*>(y_cb8 + (((size_t)n * (C / 8) + cb) * OH * OW + p) * 8);
+        d[0] = make_float4(v[0], v[1], v[2], v[3]); d[1] = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    if (y_split) {
+        h8 hi, lo;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float sc = next_scale ? next_scale[n * next_scale_stride_n + cb * 8 + c] : 1.f;
+            _Float16 a, b; split1(v[c] * sc, a, b); hi[c] = a; lo[c] = b;
+        }
+        const size_t plane = (size_t)(C / 8) * OH * OW;
+        uint4* d = y_split + (size_t)n * 2 * plane + (size_t)cb * OH * OW + p;
+        d[0] = *reinterpret_cast<uint4*>(&hi);
+        d[plane] = *reinterpret_cast<uint4*>(&lo);
+    }
+}
+
+int upsample2x_bilinear_f16x3(const float* x_cb8, int N, int C, int H, int W, void* y, int y_format,
+                              const float* next_scale, size_t next_scale_stride, hipStream_t st)
+{
+    ProfScope ps(R3D_PROF_LAYOUT, st);
+    hipLaunchKernelGGL(upsample2x_bilinear_kernel, dim3((4 * H * W + 255) / 256, C / 8, N), dim3(256), 0, st, x_cb8,
+                       y_format == R3D_FMT_SPLIT ? reinterpret_cast<uint4*>(y) : nullptr,
+                       y_format == R3D_FMT_CB8 ? reinterpret_cast<float*>(y) : nullptr, next_scale, next_scale_stride, C, H, W);
+    return check_launch("upsample2x_bilinear");
+}
+
 // ---- host ------------------------------------------------------------------------------------------------------
 int sr_prepack_f16x3(int Cin, int Cout, const float* c0_w, const float* c1_w, void* prepacked, hipStream_t st)
 {

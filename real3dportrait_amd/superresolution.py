@@ -258,9 +258,27 @@ class Conv2d(nn.Module):
         return y
 
 
+def upsample2x_bilinear(x, out_format="split"):
+    """torch.nn.UpsamplingBilinear2d(scale_factor=2.) (align_corners=True) on a channel-blocked fp32 activation
+    (r3d_upsample2x_bilinear); output 'split' (input of the next conv) or 'cb8'."""
+    lib = _lib.load()
+    assert getattr(x, "_r3d_fmt", None) == "cb8", "upsample2x_bilinear takes the 'cb8' output of a Conv2d"
+    x = x.contiguous()
+    N, C8, H, W, _ = x.shape
+    if out_format == "split":
+        y = torch.empty(N, 2, C8, 2 * H, 2 * W, 8, device=x.device, dtype=torch.float16)
+    else:
+        y = torch.empty(N, C8, 2 * H, 2 * W, 8, device=x.device, dtype=torch.float32)
+    _lib.check(lib.r3d_upsample2x_bilinear(_lib.ptr(x), N, C8 * 8, H, W, _lib.ptr(y), SynthesisBlock._FMT[out_format], None, 0,
+                                           _lib.stream_ptr()), "upsample2x_bilinear")
+    y._r3d_fmt = out_format
+    return y
+
+
 class ConvStack(nn.Sequential):
-    """An nn.Sequential of Conv2d / LeakyReLU modules (the shape of torso_encoder, bg_encoder, fuse_head_torso_convs and
-    fuse_fg_bg_convs, sr_with_ref.py:24-63) evaluated on the HIP conv kernel: each LeakyReLU is fused into the
+    """An nn.Sequential of Conv2d / LeakyReLU [/ UpsamplingBilinear2d(2)] modules (the shape of torso_encoder, bg_encoder,
+    fuse_head_torso_convs, fuse_fg_bg_convs, sr_with_ref.py:24-63, and of SegFormerSECC2PlaneBackbone.to_plane_cnn,
+    modules/real3d/segformer.py:691-700) evaluated on the HIP conv kernel: each LeakyReLU is fused into the
     preceding conv's epilogue and intermediate activations stay in the fp16 hi/lo SPLIT format (no fp32 round trip).
     state_dict keys are the reference's ('0.weight', '0.bias', '2.weight', ...).
 
@@ -276,6 +294,8 @@ class ConvStack(nn.Sequential):
                 mods.append(c.to(m.weight.device))
             elif isinstance(m, nn.LeakyReLU):
                 mods.append(nn.LeakyReLU(m.negative_slope))
+            elif isinstance(m, nn.UpsamplingBilinear2d) and float(m.scale_factor) == 2.0:
+                mods.append(nn.UpsamplingBilinear2d(scale_factor=2.0))
             else:
                 raise NotImplementedError("ConvStack: unsupported module %s" % type(m).__name__)
         return cls(*mods)
@@ -291,8 +311,14 @@ class ConvStack(nn.Sequential):
             if i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU):
                 slope, step = mods[i + 1].negative_slope, 2
             nxt = mods[i + step] if i + step < len(mods) else None
-            fmt = "split" if (nxt is not None and m.out_channels % 16 == 0) else "nchw"
-            x = m(x, negative_slope=slope, out_format=fmt)
+            if isinstance(nxt, nn.UpsamplingBilinear2d):
+                if m.out_channels % 16 or i + step + 1 >= len(mods):
+                    raise NotImplementedError("ConvStack: UpsamplingBilinear2d must sit between two convs with C % 16 == 0")
+                x = upsample2x_bilinear(m(x, negative_slope=slope, out_format="cb8"), "split")
+                step += 1
+            else:
+                fmt = "split" if (nxt is not None and m.out_channels % 16 == 0) else "nchw"
+                x = m(x, negative_slope=slope, out_format=fmt)
             i += step
         return x
 

@@ -87,6 +87,11 @@ FUSION_STACKS = {
 }
 
 
+# SegFormerSECC2PlaneBackbone.to_plane_cnn (modules/real3d/segformer.py:691-700); "up" = UpsamplingBilinear2d(2) before the conv
+TO_PLANE_CNN = [(256, 256, 3, True), (256, 256, 3, True), (256, 256, 3, True), (256, 96, 3, False)]
+TO_PLANE_CNN_UP_BEFORE = 3          # the x2 bilinear up-sampling sits in front of layer 3
+
+
 def synth_conv_stack(seed, plan, stream0=300):
     """[(weight [co,ci,k,k], bias [co])] for a FUSION_STACKS plan; weights ~ N(0, 1/(ci k k)) so activations stay O(1)."""
     out = []

@@ -116,8 +116,12 @@ class ImportanceRenderer(nn.Module):
         self._workspace = None
 
     # -- plane layout ---------------------------------------------------------------------------------
-    def prepare_planes(self, planes, add=None):
-        """NCHW [N,3,C,H,W] (+ optional per-frame residual, secc_img2plane.py:76-77) -> channel-last."""
+    SECC_PLANE_FLIPS = 53      # R3D_SECC_PLANE_FLIPS: planes 0,1 flipped along H, plane 2 along H and W (segformer.py:722-728)
+
+    def prepare_planes(self, planes, add=None, add_flip=0):
+        """NCHW [N,3,C,H,W] (+ optional per-frame residual, secc_img2plane.py:76-77) -> channel-last.
+        add_flip = SECC_PLANE_FLIPS when `add` is the raw to_plane_cnn output ([N,96,H,W], before the torch.flip calls of
+        SegFormerSECC2PlaneBackbone.forward): the flips are applied while the residual is read."""
         lib = _lib.load()
         planes = _f32c(planes)
         N, P, C, H, W = planes.shape
@@ -127,7 +131,7 @@ class ImportanceRenderer(nn.Module):
         out = torch.empty(N, 3, H, W, C, device=planes.device, dtype=torch.float32)
         addc = _f32c(add).reshape(planes.shape) if add is not None else None
         _lib.check(lib.r3d_planes_to_nhwc(_lib.ptr(planes), _lib.ptr(addc), _lib.ptr(out), N, C, H, W,
-                                          _lib.stream_ptr()), "planes_to_nhwc")
+                                          int(add_flip), _lib.stream_ptr()), "planes_to_nhwc")
         return out
 
     def _planes_nhwc(self, planes):

@@ -258,8 +258,39 @@ def fusion_case(name, R=24):
     print(name, x3.shape, float(x3.abs().mean()), float(rgb2.abs().mean()))
 
 
+def toplane_case(name, r=24):
+    """Per-frame plane producer tail: SegFormerSECC2PlaneBackbone.to_plane_cnn (segformer.py:691-700) on a
+    synthetic fused feature map, the view / flip / stack of its forward (:721-729) and the cano + secc add
+    (secc_img2plane.py:76-77), at r x r -> 2r x 2r instead of 128 -> 256.  The Sequential is built exactly as the
+    reference builds it (plain torch.nn modules); the MiT encoder in front of it is a cold stage and out of scope."""
+    seed = 71
+    plan = synth.TO_PLANE_CNN
+    params = synth.synth_conv_stack(seed, plan, 500)
+    mods = []
+    for i, ((ci, co, k, lrelu), (w, b)) in enumerate(zip(plan, params)):
+        if i == synth.TO_PLANE_CNN_UP_BEFORE:
+            mods.append(torch.nn.UpsamplingBilinear2d(scale_factor=2.))
+        conv = torch.nn.Conv2d(ci, co, k, 1, padding=1)
+        with torch.no_grad():
+            conv.weight.copy_(torch.from_numpy(w)); conv.bias.copy_(torch.from_numpy(b))
+        mods.append(conv)
+        if lrelu:
+            mods.append(torch.nn.LeakyReLU(negative_slope=0.01, inplace=True))
+    cnn = torch.nn.Sequential(*mods).eval()
+    feat = torch.from_numpy(synth.hash_unitvar(seed, (1, 256, r, r), stream=1))
+    cano = torch.from_numpy(synth.hash_unitvar(seed, (1, 3, 32, 2 * r, 2 * r), stream=2))
+    with torch.no_grad():
+        planes = cnn(feat)
+        planes = planes.view(len(planes), 3, -1, planes.shape[-2], planes.shape[-1])
+        pxy, pxz, pzy = torch.flip(planes[:, 0], [2]), torch.flip(planes[:, 1], [2]), torch.flip(planes[:, 2], [2, 3])
+        secc = torch.stack([pxy, pxz, pzy], dim=1)
+        out = cano + secc
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=seed, r=r, planes=out.numpy())
+    print(name, out.shape, float(secc.abs().mean()))
+
+
 def main():
-    which = sys.argv[1:] or ["render", "run_model", "sr_small", "sr_full", "synthesis", "fusion"]
+    which = sys.argv[1:] or ["render", "run_model", "sr_small", "sr_full", "synthesis", "fusion", "toplane"]
     if "render" in which:
         small = synth.synth_planes(1, N=1, H=32, W=32)
         render_case("render_a_r16_16p16", small, [synth.look_at_camera(0.0, 0.0)], 16, 16, 16, 2, 3)
@@ -285,6 +316,8 @@ def main():
         synthesis_case("synthesis_ref_a")
     if "fusion" in which:
         fusion_case("fusion_a")
+    if "toplane" in which:
+        toplane_case("toplane_a")
 
 
 if __name__ == "__main__":

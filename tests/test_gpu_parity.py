@@ -182,6 +182,38 @@ def test_conv2d_vs_torch_fp32(torch_cuda, N, Cin, Cout, k, H, W, slope):
     assert (y.cpu().double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
 
 
+def test_to_plane_cnn_golden(torch_cuda):
+    """to_plane_cnn (3 convs @r, bilinear x2, conv @2r) -> flips fused with the cano + secc add and the
+    channel-last re-layout, vs the reference's modules (tests/golden/toplane_a.npz)."""
+    torch = torch_cuda
+    from real3dportrait_amd import ImportanceRenderer, synth
+    from real3dportrait_amd.superresolution import Conv2d, ConvStack
+    g = load_golden("toplane_a")
+    seed, r = int(g["seed"]), int(g["r"])
+    mods = []
+    for i, ((ci, co, k, lrelu), (w, b)) in enumerate(zip(synth.TO_PLANE_CNN, synth.synth_conv_stack(seed, synth.TO_PLANE_CNN, 500))):
+        if i == synth.TO_PLANE_CNN_UP_BEFORE:
+            mods.append(torch.nn.UpsamplingBilinear2d(scale_factor=2.))
+        c = Conv2d(ci, co, k, 1, padding=1)
+        with torch.no_grad():
+            c.weight.copy_(torch.from_numpy(w)); c.bias.copy_(torch.from_numpy(b))
+        mods.append(c)
+        if lrelu:
+            mods.append(torch.nn.LeakyReLU(0.01))
+    cnn = ConvStack(*mods).cuda()
+    raw = cnn(T(torch, synth.hash_unitvar(seed, (1, 256, r, r), stream=1)))                 # [1,96,2r,2r], not flipped
+    assert raw.shape == (1, 96, 2 * r, 2 * r)
+    ren = ImportanceRenderer(hp={})
+    cano = T(torch, synth.hash_unitvar(seed, (1, 3, 32, 2 * r, 2 * r), stream=2))
+    nhwc = ren.prepare_planes(cano, add=raw, add_flip=ren.SECC_PLANE_FLIPS)                  # [1,3,2r,2r,32]
+    ref = np.transpose(g["planes"], (0, 1, 3, 4, 2))
+    assert np.abs(nhwc.cpu().numpy() - ref).max() <= SR_TOL * max(1.0, np.abs(ref).max())
+    # the unflipped add must still be the plain sum
+    plain = ren.prepare_planes(cano, add=raw.view(1, 3, 32, 2 * r, 2 * r))
+    want = (cano + raw.view(1, 3, 32, 2 * r, 2 * r)).permute(0, 1, 3, 4, 2)
+    assert (plain - want).abs().max().item() == 0.0
+
+
 def test_conv2d_rejects_unsupported(torch_cuda):
     from real3dportrait_amd.superresolution import Conv2d
     with pytest.raises(NotImplementedError):

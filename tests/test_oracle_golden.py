@@ -92,6 +92,19 @@ def test_fusion_stacks_match_reference(oracle):
         assert np.abs(got - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), key
 
 
+def test_to_plane_cnn_matches_reference(oracle):
+    """Per-frame plane producer tail: to_plane_cnn + flips + cano add (segformer.py:691-700,721-729; secc_img2plane.py:76-77)."""
+    from real3dportrait_amd import synth
+    g = load_golden("toplane_a")
+    seed, r = int(g["seed"]), int(g["r"])
+    feat = synth.hash_unitvar(seed, (1, 256, r, r), stream=1)
+    cano = synth.hash_unitvar(seed, (1, 3, 32, 2 * r, 2 * r), stream=2)
+    secc = oracle.to_plane_cnn(feat[0], synth.TO_PLANE_CNN, synth.synth_conv_stack(seed, synth.TO_PLANE_CNN, 500),
+                               synth.TO_PLANE_CNN_UP_BEFORE)
+    got = cano[0] + secc
+    assert np.abs(got - g["planes"][0]).max() <= 2e-5 * max(1.0, np.abs(g["planes"]).max())
+
+
 def test_edge_cases_run(oracle):
     """No valid ray at all (camera looks away): fix-up is skipped, depths run backwards, outputs stay finite."""
     from real3dportrait_amd import synth
