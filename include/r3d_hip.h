@@ -45,10 +45,12 @@ const char* r3d_last_error(void);
  * secc_img2plane.py:73-81) + the reshape at modules/eg3ds/volumetric_rendering/renderer.py:68.
  * `add` may be NULL.  add_flip: bit 2k flips plane k of `add` along H, bit 2k+1 along W, while it is read -- the
  * torch.flip calls SegFormerSECC2PlaneBackbone.forward applies to its conv output (modules/real3d/segformer.py:722-728:
- * planes 0,1 along H, plane 2 along H and W = 0b110101 = 53) when `add` is the raw to_plane_cnn output; 0 = none. */
+ * planes 0,1 along H, plane 2 along H and W = 0b110101 = 53) when `add` is the raw to_plane_cnn output; 0 = none.
+ * depth > 1: tri-grids (triplane_feature_type 'trigrid' / 'trigrid_v2', renderer.py:78-89): planes_nchw is
+ * [N,3,C*depth,H,W] with channel c*depth + d (the reference's .view(N*3, C, D, H, W)) -> [N,3,depth,H,W,C]. */
 #define R3D_SECC_PLANE_FLIPS 53
 int r3d_planes_to_nhwc(const float* planes_nchw, const float* add_nchw, float* planes_nhwc,
-                       int N, int C, int H, int W, int add_flip, r3d_stream_t stream);
+                       int N, int C, int H, int W, int depth, int add_flip, r3d_stream_t stream);
 
 /* --- A1 ray generation --------------------------------------------------------------------------
  * Replaces RaySampler.forward(cam2world[N,4,4], intrinsics[N,3,3], resolution)
@@ -65,6 +67,8 @@ int r3d_raygen(const float* c2w, const float* intrinsics, int N, int R,
  * importance resampling (:234-297), sort-merge (:197-207) and the final composite.
  *
  *   planes_nhwc  [N,3,H,W,32]      from r3d_planes_to_nhwc
+ *   triplane_depth 1: tri-planes, bilinear (sample_from_planes, renderer.py:65-75);  D > 1: tri-grids [N,3,D,H,W,32],
+ *                tri-linear with zero padding (sample_from_trigrids, renderer.py:78-89; hparams triplane_depth = 3)
  *   w1,b1,w2,b2  RAW decoder parameters decoder.net.0.{weight[64,32],bias[64]}, decoder.net.2.{weight[33,64],
  *                bias[33]}; the FullyConnectedLayer gains 1/sqrt(fan_in) are applied inside
  *   origins,dirs [N,M,3]
@@ -77,7 +81,7 @@ int r3d_raygen(const float* c2w, const float* intrinsics, int N, int R,
  *   workspace    r3d_render_workspace_bytes() bytes of device scratch
  */
 size_t r3d_render_workspace_bytes(int N, int M, int Nc, int Nf);
-int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
+int r3d_render_forward(const float* planes_nhwc, int N, int H, int W, int triplane_depth,
                        const float* w1, const float* b1, const float* w2, const float* b2,
                        const float* origins, const float* dirs, int M,
                        int Nc, int Nf, float box_warp, int white_back,
@@ -88,7 +92,7 @@ int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
 /* Replaces ImportanceRenderer.run_model(planes, decoder, sample_coordinates, sample_directions, options)
  * (renderer.py:169-188; inference branches) -- the point-query used by .sample() (triplane.py:140-148).
  * coords [N,npts,3] -> rgb [N,npts,32], sigma [N,npts]. */
-int r3d_run_model(const float* planes_nhwc, int N, int H, int W,
+int r3d_run_model(const float* planes_nhwc, int N, int H, int W, int triplane_depth,
                   const float* w1, const float* b1, const float* w2, const float* b2,
                   const float* coords, int npts, float box_warp,
                   float* rgb, float* sigma, r3d_stream_t stream);

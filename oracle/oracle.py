@@ -54,9 +54,16 @@ class Oracle:
         shp = o.shape[:-1]
         return rs.reshape(shp), re.reshape(shp), v.reshape(shp).astype(bool)
 
-    def run_model(self, planes, dec, coords, box_warp=1.0):
+    def _set_depth(self, planes, triplane_depth):
+        """planes [N,3,C*D,H,W]; returns the feature count C the C functions take."""
+        self.lib.r3d_oracle_set_triplane_depth(int(triplane_depth))
+        assert planes.shape[2] % triplane_depth == 0
+        return planes.shape[2] // triplane_depth
+
+    def run_model(self, planes, dec, coords, box_warp=1.0, triplane_depth=1):
         planes, coords = _f(planes), _f(coords)
-        N, _, C, H, W = planes.shape
+        N, _, _, H, W = planes.shape
+        C = self._set_depth(planes, triplane_depth)
         npts = coords.shape[1]
         w1, b1, w2, b2 = (_f(x) for x in dec)
         HID, OUT = w1.shape[0], w2.shape[0]
@@ -64,12 +71,14 @@ class Oracle:
         sig = np.empty((N, npts, 1), np.float32)
         self.lib.r3d_oracle_run_model(_p(planes), N, C, H, W, _p(w1), _p(b1), _p(w2), _p(b2), HID, OUT,
                                       ctypes.c_float(box_warp), _p(coords), npts, _p(rgb), _p(sig))
+        self.lib.r3d_oracle_set_triplane_depth(1)
         return rgb, sig
 
     def render(self, planes, dec, origins, dirs, Nc, Nf, noise_c, u_f, box_warp=1.0, white_back=False,
-               debug=False):
+               debug=False, triplane_depth=1):
         planes, o, d = _f(planes), _f(origins), _f(dirs)
-        N, _, C, H, W = planes.shape
+        N, _, _, H, W = planes.shape
+        C = self._set_depth(planes, triplane_depth)
         M = o.shape[1]
         w1, b1, w2, b2 = (_f(x) for x in dec)
         HID, OUT = w1.shape[0], w2.shape[0]
@@ -87,6 +96,7 @@ class Oracle:
                                         _p(o), _p(d), M, Nc, Nf, ctypes.c_float(box_warp), int(white_back),
                                         _p(noise_c), _p(u_f), _p(rgb), _p(depth), _p(wsum), _p(valid),
                                         _p(dc), _p(df), _p(sc))
+        self.lib.r3d_oracle_set_triplane_depth(1)
         if rc != 0:
             raise RuntimeError("r3d_oracle_render failed rc=%d" % rc)
         out = (rgb, depth, wsum, valid.astype(bool))

@@ -137,6 +137,43 @@ R3D_API void r3d_oracle_ray_limits(const float* origins, const float* dirs, int 
  * planes: [3, C, H, W] (one batch item, NCHW as the reference holds them).
  * feat_out[3][C]
  * ---------------------------------------------------------------------------------- */
+/* tri-grid depth (triplane_feature_type 'trigrid' / 'trigrid_v2', hparams triplane_depth): 1 = plain tri-planes.
+ * The reference reads it from a module-global hparams dict (renderer.py:181); so does this restatement. */
+static int g_triplane_depth = 1;
+R3D_API void r3d_oracle_set_triplane_depth(int d) { g_triplane_depth = d < 1 ? 1 : d; }
+
+/* sample_from_trigrids (renderer.py:78-89): planes [3][C*D][H][W] viewed as [3][C][D][H][W] (channel c*D + d), 5-D
+ * F.grid_sample (tri-linear, zeros padding, align_corners=False) at the projected coordinates: (u, v) as for tri-planes,
+ * third coordinate = z, y, y (coordinates . inv(plane_axes), renderer.py:29-45,60-62); grid x -> W, y -> H, z -> D. */
+static void sample_trigrids(const float* planes, int C, int D, int H, int W, const float* us, const float* vs, const float* ws,
+                            float* feat_out)
+{
+    for (int p = 0; p < 3; ++p) {
+        const float ix = ((us[p] + 1.0f) * (float)W - 1.0f) / 2.0f;
+        const float iy = ((vs[p] + 1.0f) * (float)H - 1.0f) / 2.0f;
+        const float iz = ((ws[p] + 1.0f) * (float)D - 1.0f) / 2.0f;
+        const float x0f = floorf(ix), y0f = floorf(iy), z0f = floorf(iz);
+        const int x0 = (x0f >= -2.0f && x0f <= (float)W + 1.0f) ? (int)x0f : -5;
+        const int y0 = (y0f >= -2.0f && y0f <= (float)H + 1.0f) ? (int)y0f : -5;
+        const int z0 = (z0f >= -2.0f && z0f <= (float)D + 1.0f) ? (int)z0f : -5;
+        const float* P = planes + (size_t)p * C * D * H * W;
+        for (int c = 0; c < C; ++c) {
+            float acc = 0.0f;
+            for (int dz = 0; dz < 2; ++dz)
+                for (int dy = 0; dy < 2; ++dy)
+                    for (int dx = 0; dx < 2; ++dx) {
+                        const int x = x0 + dx, y = y0 + dy, z = z0 + dz;
+                        if (x < 0 || x >= W || y < 0 || y >= H || z < 0 || z >= D) continue;
+                        const float wx = dx ? ix - x0f : (x0f + 1.0f) - ix;
+                        const float wy = dy ? iy - y0f : (y0f + 1.0f) - iy;
+                        const float wz = dz ? iz - z0f : (z0f + 1.0f) - iz;
+                        acc += P[(((size_t)c * D + z) * H + y) * W + x] * (wx * wy * wz);
+                    }
+            feat_out[p * C + c] = acc;
+        }
+    }
+}
+
 static void sample_planes(const float* planes, int C, int H, int W, float box_warp,
                           const float* xyz, float* feat_out /* [3*C] */)
 {
@@ -144,6 +181,11 @@ static void sample_planes(const float* planes, int C, int H, int W, float box_wa
     const float q[3] = { xyz[0] * s, xyz[1] * s, xyz[2] * s };
     const float us[3] = { q[0], q[0], q[2] };
     const float vs[3] = { q[1], q[2], q[0] };
+    if (g_triplane_depth > 1) {
+        const float ws[3] = { q[2], q[1], q[1] };
+        sample_trigrids(planes, C, g_triplane_depth, H, W, us, vs, ws, feat_out);
+        return;
+    }
     for (int p = 0; p < 3; ++p) {
         const float ix = ((us[p] + 1.0f) * (float)W - 1.0f) / 2.0f;
         const float iy = ((vs[p] + 1.0f) * (float)H - 1.0f) / 2.0f;
@@ -213,7 +255,7 @@ R3D_API void r3d_oracle_run_model(const float* planes, int N, int C, int H, int 
                                   const float* coords, int npts, float* rgb_out, float* sigma_out)
 {
     for (int n = 0; n < N; ++n) {
-        const float* Pn = planes + (size_t)n * 3 * C * H * W;
+        const float* Pn = planes + (size_t)n * 3 * C * g_triplane_depth * H * W;
 #pragma omp parallel for schedule(static)
         for (int i = 0; i < npts; ++i) {
             float feat[3 * 64];
@@ -356,7 +398,7 @@ R3D_API int r3d_oracle_render(const float* planes, int N, int C, int H, int W,
 #pragma omp for schedule(dynamic, 64)
         for (int r = 0; r < nrays; ++r) {
             const int n = r / M;
-            const float* Pn = planes + (size_t)n * 3 * C * H * W;
+            const float* Pn = planes + (size_t)n * 3 * C * g_triplane_depth * H * W;
             const float* o = origins + 3 * (size_t)r;
             const float* d = dirs + 3 * (size_t)r;
             const float start = rs[r], end = re[r];

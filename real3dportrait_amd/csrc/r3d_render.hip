@@ -35,34 +35,36 @@ static constexpr int kRayArr = kMaxSamples + 8;
 // add_flip: bit 2k = flip H, bit 2k+1 = flip W of plane k of `add` (the flips SegFormerSECC2PlaneBackbone.forward applies to
 // its conv output, modules/real3d/segformer.py:722-728, fused with the cano + secc add of secc_img2plane.py:76-77)
 // -------------------------------------------------------------------------------------------------
+// depth D > 1 (tri-grids, renderer.py:78-89): source channel c*D + d of plane p goes to slice d: [N*3][D][H*W][C]
 __global__ void planes_to_nhwc_kernel(const float* __restrict__ src, const float* __restrict__ add,
-                                      float* __restrict__ dst, int C, int HW, int W, int add_flip)
+                                      float* __restrict__ dst, int C, int HW, int W, int add_flip, int D)
 {
     __shared__ float tile[32][33];
-    const int p = blockIdx.z;
+    const int p = blockIdx.z / D, dsl = blockIdx.z - p * D;
     const int fl = (add_flip >> (2 * (p % 3))) & 3;
     const int hw0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
     const int tx = threadIdx.x, ty = threadIdx.y;   // 32 x 8
-    const float* s = src + (size_t)p * C * HW;
-    const float* a = add ? add + (size_t)p * C * HW : nullptr;
+    const float* s = src + (size_t)p * C * D * HW;
+    const float* a = add ? add + (size_t)p * C * D * HW : nullptr;
     for (int j = ty; j < 32; j += 8) {
         const int c = c0 + j, hw = hw0 + tx;
         float v = 0.f;
         if (c < C && hw < HW) {
-            v = s[(size_t)c * HW + hw];
+            const size_t cs = (size_t)c * D + dsl;
+            v = s[cs * HW + hw];
             if (a) {
                 int hwa = hw;
                 if (fl) {
                     const int H = HW / W, h = hw / W, w = hw - h * W;
                     hwa = ((fl & 1) ? H - 1 - h : h) * W + ((fl & 2) ? W - 1 - w : w);
                 }
-                v += a[(size_t)c * HW + hwa];
+                v += a[cs * HW + hwa];
             }
         }
         tile[j][tx] = v;
     }
     __syncthreads();
-    float* d = dst + (size_t)p * HW * C;
+    float* d = dst + (size_t)blockIdx.z * HW * C;
     for (int j = ty; j < 32; j += 8) {
         const int hw = hw0 + j, c = c0 + tx;
         if (c < C && hw < HW) d[(size_t)hw * C + c] = tile[tx][j];
@@ -254,13 +256,56 @@ __device__ __forceinline__ void plane_taps(float u, float v, int H, int W, int p
     t[3].idx = plane_base4 + (yb * W + xb) * 8; t[3].w = (vx1 && vy1) ? fx1 * fy1 : 0.0f;
 }
 
-template <int PLANES_IN_FLIGHT>
+template <int PLANES_IN_FLIGHT, bool TRI = false>
 __device__ __forceinline__ void gather_sample(const float4* __restrict__ planes4, int H, int W, int q,
-                                              float px, float py, float pz, float scale, float x[8])
+                                              float px, float py, float pz, float scale, float x[8], int D = 1)
 {
     const float qx = px * scale, qy = py * scale, qz = pz * scale;
     const int HW8 = H * W * 8;
     const float us[3] = {qx, qx, qz}, vs[3] = {qy, qz, qx};
+    if constexpr (TRI) {
+        // tri-grid (sample_from_trigrids, renderer.py:78-89): each plane is a [C, D, H, W] volume sampled tri-linearly; the
+        // third projected coordinate (project_onto_planes with the axes of renderer.py:29-45) is z, y, y for the three
+        // planes.  Two passes (depth slice z0, z0+1), each the 3-plane / 24-load gather of the tri-plane path.
+        const float ws[3] = {qz, qy, qy};
+        float accs[3][8];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) accs[p][c] = 0.0f;
+#pragma unroll
+        for (int dz = 0; dz < 2; ++dz) {
+            Tap t[12];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const float iz = ((ws[p] + 1.0f) * (float)D - 1.0f) * 0.5f;
+                const float z0f = floorf(iz);
+                const float zc = fminf(fmaxf(z0f, -2.0f), (float)D + 1.0f);
+                const int z = (int)zc + dz;
+                const bool vz = (zc == z0f) && z >= 0 && z < D;
+                const float wz = vz ? (dz ? iz - z0f : (z0f + 1.0f) - iz) : 0.0f;
+                plane_taps(us[p], vs[p], H, W, (p * D + min(max(z, 0), D - 1)) * HW8 + 2 * q, t + 4 * p);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) t[4 * p + k].w *= wz;
+            }
+            float4 lo[12], hi[12];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) { lo[i] = planes4[t[i].idx]; hi[i] = planes4[t[i].idx + 1]; }
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float w = t[4 * p + k].w;
+                    const float4 a = lo[4 * p + k], b = hi[4 * p + k];
+                    accs[p][0] += a.x * w; accs[p][1] += a.y * w; accs[p][2] += a.z * w; accs[p][3] += a.w * w;
+                    accs[p][4] += b.x * w; accs[p][5] += b.y * w; accs[p][6] += b.z * w; accs[p][7] += b.w * w;
+                }
+            __builtin_amdgcn_sched_barrier(0);          // one slice's loads in flight at a time (VGPR budget)
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) x[c] = (accs[0][c] + accs[1][c] + accs[2][c]) * (1.0f / 3.0f);
+        return;
+    }
     float acc[3][8];
     if (PLANES_IN_FLIGHT == 3) {
         Tap t[12];
@@ -444,7 +489,7 @@ __device__ __forceinline__ void march(const float* T, const float* S, float* wv,
 }
 
 struct RenderArgs {
-    const float4* planes4; int N, H, W, M;
+    const float4* planes4; int N, H, W, M, D;      // D: tri-grid depth (1 = tri-plane)
     const float* w1; const float* b1; const float* w2; const float* b2;
     const float* origins; const float* dirs;
     const float* ray_start; const float* ray_end; const uint8_t* valid;
@@ -478,7 +523,7 @@ __device__ __forceinline__ bool next_ray(const RenderArgs& a, int R, int iter, i
     return true;
 }
 
-template <int NTC, int NTF, int OCC, int GPF>
+template <int NTC, int NTF, int OCC, int GPF, bool TRI = false>
 __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
 {
     constexpr int SLOTS = (16 * (NTC + NTF) + 63) / 64;
@@ -502,7 +547,7 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
         int ray;
         if (!next_ray(a, R, iter, wave, ray)) break;
         const int n = ray / a.M;
-        const float4* P = a.planes4 + (size_t)n * 3 * a.H * a.W * 8;
+        const float4* P = a.planes4 + (size_t)n * 3 * (TRI ? a.D : 1) * a.H * a.W * 8;
         const float ox = a.origins[3 * (size_t)ray], oy = a.origins[3 * (size_t)ray + 1], oz = a.origins[3 * (size_t)ray + 2];
         const float dx = a.dirs[3 * (size_t)ray], dy = a.dirs[3 * (size_t)ray + 1], dz = a.dirs[3 * (size_t)ray + 2];
         float start = a.ray_start[ray], end = a.ray_end[ray];
@@ -528,7 +573,7 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
         for (int nt = 0; nt < NTC; ++nt) {            // per-tile pipeline: gather (24 loads in flight) -> decode
             float X[8];
             f32x4 c2[2];
-            gather_sample<GPF>(P, a.H, a.W, q, ox + tc[nt] * dx, oy + tc[nt] * dy, oz + tc[nt] * dz, a.scale, X);
+            gather_sample<GPF, TRI>(P, a.H, a.W, q, ox + tc[nt] * dx, oy + tc[nt] * dy, oz + tc[nt] * dz, a.scale, X, a.D);
             decode_tile(dec, lane, X, c2, sigc[nt]);
             colc[0][nt] = c2[0]; colc[1][nt] = c2[1];
             __builtin_amdgcn_sched_barrier(0);         // one tile at a time (VGPR budget)
@@ -599,7 +644,7 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
                 const float tf = L.t[Nc + (k < Nf ? k : 0)];
                 float X[8];
                 f32x4 c2[2];
-                gather_sample<GPF>(P, a.H, a.W, q, ox + tf * dx, oy + tf * dy, oz + tf * dz, a.scale, X);
+                gather_sample<GPF, TRI>(P, a.H, a.W, q, ox + tf * dx, oy + tf * dy, oz + tf * dz, a.scale, X, a.D);
                 decode_tile(dec, lane, X, c2, sigf[nt]);
                 colf[0][nt] = c2[0]; colf[1][nt] = c2[1];
                 __builtin_amdgcn_sched_barrier(0);
@@ -792,7 +837,8 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
 // -------------------------------------------------------------------------------------------------
 // run_model (renderer.py:169-188): point queries, 64 points per wave iteration
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void run_model_kernel(const float4* __restrict__ planes4, int N, int H, int W,
+template <bool TRI>
+__global__ __launch_bounds__(256, 2) void run_model_kernel(const float4* __restrict__ planes4, int N, int H, int W, int D,
                                                           const float* w1, const float* b1, const float* w2, const float* b2,
                                                           const float* __restrict__ coords, int npts, float scale,
                                                           float* __restrict__ rgb, float* __restrict__ sigma)
@@ -813,10 +859,10 @@ __global__ __launch_bounds__(256, 2) void run_model_kernel(const float4* __restr
             idx[nt] = ch * 64 + 16 * nt + s;
             const long long ii = idx[nt] < total ? idx[nt] : total - 1;
             const int n = (int)(ii / npts);
-            const float4* P = planes4 + (size_t)n * 3 * H * W * 8;
+            const float4* P = planes4 + (size_t)n * 3 * (TRI ? D : 1) * H * W * 8;
             float X[8];
             f32x4 c2[2];
-            gather_sample<3>(P, H, W, q, coords[3 * ii], coords[3 * ii + 1], coords[3 * ii + 2], scale, X);
+            gather_sample<3, TRI>(P, H, W, q, coords[3 * ii], coords[3 * ii + 1], coords[3 * ii + 2], scale, X, D);
             decode_tile(dec, lane, X, c2, sig[nt]);
             col[0][nt] = c2[0]; col[1][nt] = c2[1];
             __builtin_amdgcn_sched_barrier(0);
@@ -846,18 +892,27 @@ static void launch_render(const RenderArgs& a, int R, int grid, hipStream_t st)
     hipLaunchKernelGGL((render_kernel<NTC, NTF, 2, 3>), dim3(grid), dim3(256), 0, st, a, R);
 }
 
+// tri-grid variants: only the three covering shapes are instantiated (a secondary configuration)
+template <int NTC, int NTF>
+static void launch_render_tri(const RenderArgs& a, int R, int grid, hipStream_t st)
+{
+    hipLaunchKernelGGL((render_kernel<NTC, NTF, 2, 3, true>), dim3(grid), dim3(256), 0, st, a, R);
+}
+
 }  // namespace r3d
 
 using namespace r3d;
 
 extern "C" int r3d_planes_to_nhwc(const float* planes_nchw, const float* add_nchw, float* planes_nhwc,
-                                  int N, int C, int H, int W, int add_flip, r3d_stream_t stream)
+                                  int N, int C, int H, int W, int depth, int add_flip, r3d_stream_t stream)
 {
-    if (!planes_nchw || !planes_nhwc || N <= 0 || C <= 0 || H <= 0 || W <= 0 || add_flip < 0 || add_flip > 63) { set_error("planes_to_nhwc: bad argument"); return R3D_ERR_INVALID_ARG; }
+    if (!planes_nchw || !planes_nhwc || N <= 0 || C <= 0 || H <= 0 || W <= 0 || depth < 1 || depth > 16 || add_flip < 0 || add_flip > 63) {
+        set_error("planes_to_nhwc: bad argument"); return R3D_ERR_INVALID_ARG;
+    }
     const int HW = H * W;
-    dim3 grid((HW + 31) / 32, (C + 31) / 32, N * 3), block(32, 8);
+    dim3 grid((HW + 31) / 32, (C + 31) / 32, N * 3 * depth), block(32, 8);
     ProfScope ps(R3D_PROF_LAYOUT, (hipStream_t)stream);
-    hipLaunchKernelGGL(planes_to_nhwc_kernel, grid, block, 0, (hipStream_t)stream, planes_nchw, add_nchw, planes_nhwc, C, HW, W, add_flip);
+    hipLaunchKernelGGL(planes_to_nhwc_kernel, grid, block, 0, (hipStream_t)stream, planes_nchw, add_nchw, planes_nhwc, C, HW, W, add_flip, depth);
     return check_launch("planes_to_nhwc");
 }
 
@@ -878,7 +933,7 @@ extern "C" size_t r3d_render_workspace_bytes(int N, int M, int Nc, int Nf)
     return sizeof(RenderWs) + 2 * nrays * sizeof(float) + 64;
 }
 
-extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
+extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W, int triplane_depth,
                                   const float* w1, const float* b1, const float* w2, const float* b2,
                                   const float* origins, const float* dirs, int M,
                                   int Nc, int Nf, float box_warp, int white_back,
@@ -889,7 +944,7 @@ extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
     if (!planes_nhwc || !w1 || !b1 || !w2 || !b2 || !origins || !dirs || !rgb || !depth || !wsum || !valid) {
         set_error("render_forward: NULL pointer"); return R3D_ERR_INVALID_ARG;
     }
-    if (N <= 0 || M <= 0 || H <= 1 || W <= 1 || !(box_warp > 0.f)) { set_error("render_forward: bad shape"); return R3D_ERR_INVALID_ARG; }
+    if (N <= 0 || M <= 0 || H <= 1 || W <= 1 || triplane_depth < 1 || triplane_depth > 16 || !(box_warp > 0.f)) { set_error("render_forward: bad shape"); return R3D_ERR_INVALID_ARG; }
     if (Nc < 4 || Nc > 96 || Nf < 0 || Nf > 96) {
         set_error("render_forward: depth_resolution %d / importance %d outside [4,96] / [0,96]", Nc, Nf);
         return R3D_ERR_INVALID_ARG;
@@ -910,7 +965,7 @@ extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
     }
 
     RenderArgs a;
-    a.planes4 = reinterpret_cast<const float4*>(planes_nhwc); a.N = N; a.H = H; a.W = W; a.M = M;
+    a.planes4 = reinterpret_cast<const float4*>(planes_nhwc); a.N = N; a.H = H; a.W = W; a.M = M; a.D = triplane_depth;
     a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
     a.origins = origins; a.dirs = dirs; a.ray_start = ray_start; a.ray_end = ray_end; a.valid = valid;
     a.gstate = gstate; a.Nc = Nc; a.Nf = Nf; a.scale = 2.0f / box_warp; a.white_back = white_back;
@@ -929,7 +984,11 @@ extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
     {
     ProfScope ps(R3D_PROF_RENDER, st);
 #define R3D_CASE(C_, F_) else if (ntc == C_ && ntf == F_) launch_render<C_, F_>(a, R, grid, st)
-    if (false) {}
+    if (triplane_depth > 1) {
+        if (ntf == 0) launch_render_tri<6, 0>(a, R, grid, st);
+        else if (ntc <= 3 && ntf <= 3) launch_render_tri<3, 3>(a, R, grid, st);
+        else launch_render_tri<6, 6>(a, R, grid, st);
+    }
     R3D_CASE(1, 0); R3D_CASE(1, 1); R3D_CASE(2, 0); R3D_CASE(2, 1); R3D_CASE(2, 2);
     R3D_CASE(3, 0); R3D_CASE(3, 1); R3D_CASE(3, 2); R3D_CASE(3, 3);
     R3D_CASE(4, 0); R3D_CASE(4, 4); R3D_CASE(6, 0); R3D_CASE(6, 6);
@@ -944,20 +1003,25 @@ extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
     return check_launch("render_forward");
 }
 
-extern "C" int r3d_run_model(const float* planes_nhwc, int N, int H, int W,
+extern "C" int r3d_run_model(const float* planes_nhwc, int N, int H, int W, int triplane_depth,
                              const float* w1, const float* b1, const float* w2, const float* b2,
                              const float* coords, int npts, float box_warp,
                              float* rgb, float* sigma, r3d_stream_t stream)
 {
-    if (!planes_nhwc || !w1 || !b1 || !w2 || !b2 || !coords || !rgb || !sigma || N <= 0 || npts <= 0 || !(box_warp > 0.f)) {
+    if (!planes_nhwc || !w1 || !b1 || !w2 || !b2 || !coords || !rgb || !sigma || N <= 0 || npts <= 0 || triplane_depth < 1 || triplane_depth > 16 || !(box_warp > 0.f)) {
         set_error("run_model: bad argument"); return R3D_ERR_INVALID_ARG;
     }
     const long long chunks = ((long long)N * npts + 63) / 64;
     int grid = (int)((chunks + kWavesPerBlock - 1) / kWavesPerBlock);
     if (grid > 1024) grid = 1024;
     ProfScope ps(R3D_PROF_RENDER, (hipStream_t)stream);
-    hipLaunchKernelGGL(run_model_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<const float4*>(planes_nhwc), N, H, W, w1, b1, w2, b2, coords, npts,
-                       2.0f / box_warp, rgb, sigma);
+    if (triplane_depth > 1)
+        hipLaunchKernelGGL(run_model_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const float4*>(planes_nhwc), N, H, W, triplane_depth, w1, b1, w2, b2, coords, npts,
+                           2.0f / box_warp, rgb, sigma);
+    else
+        hipLaunchKernelGGL(run_model_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
+                           reinterpret_cast<const float4*>(planes_nhwc), N, H, W, triplane_depth, w1, b1, w2, b2, coords, npts,
+                           2.0f / box_warp, rgb, sigma);
     return check_launch("run_model");
 }

@@ -109,6 +109,9 @@ class ImportanceRenderer(nn.Module):
         super().__init__()
         self.hparams = dict(hp) if hp is not None else {}
         self.triplane_feature_type = self.hparams.get("triplane_feature_type", "triplane")
+        # 'trigrid' / 'trigrid_v2': planes are [N,3,C*D,H,W] volumes sampled tri-linearly (renderer.py:78-89,180-181);
+        # the reference reads the depth from hparams['triplane_depth'] (default 1)
+        self.triplane_depth = int(self.hparams.get("triplane_depth", 1)) if self.triplane_feature_type in ("trigrid", "trigrid_v2") else 1
         self.noise_mode = "torch"
         self.noise_override = None
         self.seed = 0
@@ -124,14 +127,17 @@ class ImportanceRenderer(nn.Module):
         SegFormerSECC2PlaneBackbone.forward): the flips are applied while the residual is read."""
         lib = _lib.load()
         planes = _f32c(planes)
-        N, P, C, H, W = planes.shape
+        N, P, CD, H, W = planes.shape
+        D = self.triplane_depth
         assert P == 3, "expected tri-planes [N,3,C,H,W]"
-        if C != 32:
-            raise NotImplementedError("HIP renderer is built for 32 feature channels, got %d" % C)
-        out = torch.empty(N, 3, H, W, C, device=planes.device, dtype=torch.float32)
+        if CD != 32 * D:
+            raise NotImplementedError("HIP renderer is built for 32 feature channels (x triplane_depth %d), got %d" % (D, CD))
+        C = CD // D
+        out = torch.empty((N, 3, H, W, C) if D == 1 else (N, 3, D, H, W, C), device=planes.device, dtype=torch.float32)
         addc = _f32c(add).reshape(planes.shape) if add is not None else None
-        _lib.check(lib.r3d_planes_to_nhwc(_lib.ptr(planes), _lib.ptr(addc), _lib.ptr(out), N, C, H, W,
+        _lib.check(lib.r3d_planes_to_nhwc(_lib.ptr(planes), _lib.ptr(addc), _lib.ptr(out), N, C, H, W, D,
                                           int(add_flip), _lib.stream_ptr()), "planes_to_nhwc")
+        out._r3d_nhwc = True
         return out
 
     def _planes_nhwc(self, planes):
@@ -145,9 +151,8 @@ class ImportanceRenderer(nn.Module):
         return out
 
     def _check_options(self, opts):
-        if self.triplane_feature_type != "triplane":
-            raise NotImplementedError("triplane_feature_type=%r (trigrid/3dgrid) is a 'next' row, not built"
-                                      % self.triplane_feature_type)
+        if self.triplane_feature_type not in ("triplane", "trigrid", "trigrid_v2"):
+            raise NotImplementedError("triplane_feature_type=%r (3dgrid) is not built" % self.triplane_feature_type)
         if not (opts.get("ray_start") == "auto" and opts.get("ray_end") == "auto"):
             raise NotImplementedError("only ray_start == ray_end == 'auto' is supported "
                                       "(the numeric branch raises UnboundLocalError upstream)")
@@ -163,7 +168,9 @@ class ImportanceRenderer(nn.Module):
         lib = _lib.load()
         self._check_options(rendering_options)
         planes_nhwc = self._planes_nhwc(planes)
-        N, _, H, W, _ = planes_nhwc.shape
+        N, H, W = planes_nhwc.shape[0], planes_nhwc.shape[-3], planes_nhwc.shape[-2]
+        D = self.triplane_depth
+        assert planes_nhwc.dim() == (5 if D == 1 else 6) and (D == 1 or planes_nhwc.shape[2] == D), planes_nhwc.shape
         o, d = _f32c(ray_origins), _f32c(ray_directions)
         M = o.shape[1]
         Nc = int(rendering_options["depth_resolution"])
@@ -190,7 +197,7 @@ class ImportanceRenderer(nn.Module):
         if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
             self._workspace = torch.empty(need, device=dev, dtype=torch.uint8)
         _lib.check(lib.r3d_render_forward(
-            _lib.ptr(planes_nhwc), N, H, W, _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2),
+            _lib.ptr(planes_nhwc), N, H, W, D, _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2),
             _lib.ptr(o), _lib.ptr(d), M, Nc, Nf, float(rendering_options["box_warp"]),
             int(bool(rendering_options.get("white_back", False))),
             _lib.ptr(noise_c), _lib.ptr(u_f), int(self.seed) & 0xFFFFFFFFFFFFFFFF,
@@ -200,18 +207,20 @@ class ImportanceRenderer(nn.Module):
 
     def run_model(self, planes, decoder, sample_coordinates, sample_directions, options):
         lib = _lib.load()
-        if self.triplane_feature_type != "triplane":
+        if self.triplane_feature_type not in ("triplane", "trigrid", "trigrid_v2"):
             raise NotImplementedError("triplane_feature_type=%r" % self.triplane_feature_type)
         if options.get("density_noise", 0) > 0:
             raise NotImplementedError("density_noise is a training-only branch")
         planes_nhwc = self._planes_nhwc(planes)
-        N, _, H, W, _ = planes_nhwc.shape
+        N, H, W = planes_nhwc.shape[0], planes_nhwc.shape[-3], planes_nhwc.shape[-2]
+        D = self.triplane_depth
+        assert planes_nhwc.dim() == (5 if D == 1 else 6) and (D == 1 or planes_nhwc.shape[2] == D), planes_nhwc.shape
         coords = _f32c(sample_coordinates)
         npts = coords.shape[1]
         w1, b1, w2, b2 = decoder_params(decoder)
         rgb = torch.empty(N, npts, 32, device=coords.device, dtype=torch.float32)
         sigma = torch.empty(N, npts, 1, device=coords.device, dtype=torch.float32)
-        _lib.check(lib.r3d_run_model(_lib.ptr(planes_nhwc), N, H, W, _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2),
+        _lib.check(lib.r3d_run_model(_lib.ptr(planes_nhwc), N, H, W, D, _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2),
                                      _lib.ptr(b2), _lib.ptr(coords), npts, float(options["box_warp"]),
                                      _lib.ptr(rgb), _lib.ptr(sigma), _lib.stream_ptr()), "run_model")
         return {"rgb": rgb, "sigma": sigma}

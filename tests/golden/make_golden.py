@@ -92,7 +92,7 @@ def opts(Nc, Nf, box_warp=1.0, white_back=False):
 
 
 def render_case(name, planes, cams, R, Nc, Nf, dec_seed, noise_seed, box_warp=1.0, white_back=False,
-                sigma_bias=0.0, store_planes=True, planes_spec=None):
+                sigma_bias=0.0, store_planes=True, planes_spec=None, trigrid_depth=1):
     cams = np.asarray(cams, np.float32).reshape(-1, 25)
     N, M = cams.shape[0], R * R
     dec_np = synth.synth_decoder(dec_seed, sigma_bias=sigma_bias)
@@ -104,12 +104,14 @@ def render_case(name, planes, cams, R, Nc, Nf, dec_seed, noise_seed, box_warp=1.
     with torch.no_grad():
         o, d = RaySampler()(c2w, K, R)
         rs, re = math_utils.get_ray_limits_box(o, d, box_side_length=box_warp)
-        ren = ImportanceRenderer(hp={"enable_rescale_plane_regulation": False,
-                                     "triplane_feature_type": "triplane"}).eval()
+        hp = {"enable_rescale_plane_regulation": False, "triplane_feature_type": "triplane"}
+        if trigrid_depth > 1:       # sample_from_trigrids branch (renderer.py:180-181), depth from hparams
+            hp = {"enable_rescale_plane_regulation": False, "triplane_feature_type": "trigrid", "triplane_depth": trigrid_depth}
+        ren = ImportanceRenderer(hp=hp).eval()
         with injected_noise(noise_c, u_f) as st:
             rgb, depth, wsum, valid = ren(torch.from_numpy(planes), dec, o, d, opts(Nc, Nf, box_warp, white_back))
         assert st["c"] == 1 and st["f"] == (1 if Nf > 0 else 0)
-    out = dict(cams=cams, R=R, Nc=Nc, Nf=Nf, box_warp=np.float32(box_warp), white_back=int(white_back),
+    out = dict(cams=cams, R=R, Nc=Nc, Nf=Nf, box_warp=np.float32(box_warp), white_back=int(white_back), triplane_depth=trigrid_depth,
                dec_w1=dec_np[0], dec_b1=dec_np[1], dec_w2=dec_np[2], dec_b2=dec_np[3],
                noise_c=noise_c, u_f=u_f,
                origins=o.numpy(), dirs=d.numpy(), raw_start=rs.numpy(), raw_end=re.numpy(),
@@ -122,17 +124,21 @@ def render_case(name, planes, cams, R, Nc, Nf, dec_seed, noise_seed, box_warp=1.
     print(name, "rgb", rgb.shape, "valid frac", float(valid.float().mean()), "wsum mean", float(wsum.mean()))
 
 
-def run_model_case(name):
-    planes = synth.synth_planes(21, N=2, H=32, W=32)
+def run_model_case(name, trigrid_depth=1):
+    planes = synth.synth_planes(21, N=2, H=32, W=32) if trigrid_depth == 1 else \
+        synth.hash_unitvar(25, (2, 3, 32 * trigrid_depth, 16, 16), stream=1)
     dec_np = synth.synth_decoder(22)
     dec = make_decoder(dec_np)
     coords = (synth.synth_noise(23, (2, 777, 3)) - 0.5) * 1.3     # includes points outside the +-0.5 box
-    ren = ImportanceRenderer(hp={"enable_rescale_plane_regulation": False, "triplane_feature_type": "triplane"}).eval()
+    hp = {"enable_rescale_plane_regulation": False, "triplane_feature_type": "triplane"}
+    if trigrid_depth > 1:
+        hp = {"enable_rescale_plane_regulation": False, "triplane_feature_type": "trigrid_v2", "triplane_depth": trigrid_depth}
+    ren = ImportanceRenderer(hp=hp).eval()
     with torch.no_grad():
         out = ren.run_model(torch.from_numpy(planes), dec, torch.from_numpy(coords), None, opts(16, 0))
     np.savez_compressed(os.path.join(OUT, name + ".npz"), planes=planes, coords=coords.astype(np.float32),
                         dec_w1=dec_np[0], dec_b1=dec_np[1], dec_w2=dec_np[2], dec_b2=dec_np[3],
-                        rgb=out["rgb"].numpy(), sigma=out["sigma"].numpy(), box_warp=np.float32(1.0))
+                        rgb=out["rgb"].numpy(), sigma=out["sigma"].numpy(), box_warp=np.float32(1.0), triplane_depth=trigrid_depth)
     print(name, out["rgb"].shape)
 
 
@@ -301,6 +307,9 @@ def main():
         cam = synth.look_at_camera(0.1, 0.05)
         cam[3] += 0.45
         render_case("render_c_invalid_r16_16p0", small, [cam], 16, 16, 0, 7, 8)
+        grid = (synth.hash_unitvar(17, (1, 3, 32 * 3, 24, 24), stream=1)).astype(np.float32)
+        render_case("render_f_trigrid_d3_r12_20p12", grid, [synth.look_at_camera(0.15, -0.1)], 12, 20, 12, 14, 15,
+                    sigma_bias=2.0, trigrid_depth=3)
         render_case("render_e_white_r12_32p16_bw", small, [synth.look_at_camera(-0.2, 0.15)], 12, 32, 16, 9, 10,
                     box_warp=1.2, white_back=True, sigma_bias=2.0)
         big = synth.synth_planes(11, N=1)
@@ -308,6 +317,7 @@ def main():
                     store_planes=False, planes_spec=(11, 1, 32, 256, 256, 1.0), sigma_bias=3.0)
     if "run_model" in which:
         run_model_case("run_model_a")
+        run_model_case("run_model_b_trigrid_d3", trigrid_depth=3)
     if "sr_small" in which:
         sr_small_case("sr_small_a")
     if "sr_full" in which:

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 RGB_TOL, DEPTH_TOL, SR_TOL = 2e-4, 1e-4, 2e-4
 RENDER_CASES = ["render_a_r16_16p16", "render_b_n2_r16_48p48", "render_c_invalid_r16_16p0",
-                "render_e_white_r12_32p16_bw", "render_d_cfg1_r64_16p16"]
+                "render_e_white_r12_32p16_bw", "render_d_cfg1_r64_16p16", "render_f_trigrid_d3_r12_20p12"]
 
 
 @pytest.fixture(scope="module")
@@ -45,9 +45,11 @@ def opts(Nc, Nf, box_warp=1.0, white_back=False):
             "white_back": white_back}
 
 
-def hip_render(torch, planes, dec_np, o, d, Nc, Nf, noise_c, u_f, box_warp=1.0, white_back=False):
+def hip_render(torch, planes, dec_np, o, d, Nc, Nf, noise_c, u_f, box_warp=1.0, white_back=False, triplane_depth=1):
     from real3dportrait_amd import ImportanceRenderer
-    ren = ImportanceRenderer(hp={"triplane_feature_type": "triplane"})
+    hp = {"triplane_feature_type": "triplane"} if triplane_depth == 1 else \
+        {"triplane_feature_type": "trigrid", "triplane_depth": triplane_depth}
+    ren = ImportanceRenderer(hp=hp)
     ren.noise_override = (T(torch, noise_c), T(torch, u_f) if Nf > 0 else None)
     out = ren(T(torch, planes), make_decoder(torch, dec_np), T(torch, o), T(torch, d), opts(Nc, Nf, box_warp, white_back))
     torch.cuda.synchronize()
@@ -74,18 +76,20 @@ def test_render_golden(torch_cuda, name):
     g = load_golden(name)
     rgb, depth, wsum, valid = hip_render(torch_cuda, golden_planes(g), dec_of(g), g["origins"], g["dirs"],
                                          int(g["Nc"]), int(g["Nf"]), g["noise_c"], g["u_f"],
-                                         float(g["box_warp"]), bool(g["white_back"]))
+                                         float(g["box_warp"]), bool(g["white_back"]), int(g["triplane_depth"]))
     assert np.array_equal(valid, g["valid"])
     assert np.abs(rgb - g["rgb"]).max() <= RGB_TOL
     assert np.abs(wsum - g["wsum"]).max() <= RGB_TOL
     assert np.abs(depth - g["depth"]).max() <= DEPTH_TOL
 
 
-def test_run_model_golden(torch_cuda):
+@pytest.mark.parametrize("name", ["run_model_a", "run_model_b_trigrid_d3"])
+def test_run_model_golden(torch_cuda, name):
     torch = torch_cuda
     from real3dportrait_amd import ImportanceRenderer
-    g = load_golden("run_model_a")
-    ren = ImportanceRenderer(hp={})
+    g = load_golden(name)
+    D = int(g["triplane_depth"])
+    ren = ImportanceRenderer(hp={} if D == 1 else {"triplane_feature_type": "trigrid_v2", "triplane_depth": D})
     out = ren.run_model(T(torch, g["planes"]), make_decoder(torch, dec_of(g)), T(torch, g["coords"]), None, opts(16, 0))
     assert np.abs(out["rgb"].cpu().numpy() - g["rgb"]).max() <= 2e-5
     assert np.abs(out["sigma"].cpu().numpy() - g["sigma"]).max() <= 2e-4
@@ -293,6 +297,23 @@ def test_render_vs_oracle(torch_cuda, oracle, R, Nc, Nf, N, HW):
     assert np.array_equal(got[3], ref[3])
     assert np.abs(got[0] - ref[0]).max() <= RGB_TOL
     assert np.abs(got[2] - ref[2]).max() <= RGB_TOL
+    assert np.abs(got[1] - ref[1]).max() <= DEPTH_TOL
+
+
+def test_trigrid_vs_oracle(torch_cuda, oracle):
+    """Tri-grid sampling (depth 3, the img2plane.yaml configuration) on a fresh seeded case, 48+48 samples, N=2."""
+    torch = torch_cuda
+    from real3dportrait_amd import RaySampler, synth
+    R, Nc, Nf, N, HW, D = 20, 48, 48, 2, 40, 3
+    grids = synth.hash_unitvar(91, (N, 3, 32 * D, HW, HW), stream=1)
+    dec = synth.synth_decoder(92, sigma_bias=3.0)
+    cams = synth.camera_sweep(N, -0.25, 0.3)
+    o, d = oracle.raygen(cams[:, :16], cams[:, 16:], R)
+    noise_c = synth.synth_noise(93, (N, R * R, Nc, 1)); u_f = synth.synth_noise(94, (N * R * R, Nf))
+    ref = oracle.render(grids, dec, o, d, Nc, Nf, noise_c, u_f, triplane_depth=D)
+    got = hip_render(torch, grids, dec, o, d, Nc, Nf, noise_c, u_f, triplane_depth=D)
+    assert np.array_equal(got[3], ref[3])
+    assert np.abs(got[0] - ref[0]).max() <= RGB_TOL and np.abs(got[2] - ref[2]).max() <= RGB_TOL
     assert np.abs(got[1] - ref[1]).max() <= DEPTH_TOL
 
 

@@ -51,9 +51,12 @@ def test_operators_refuse_cpu_tensors_and_bad_options():
     from real3dportrait_amd import ImportanceRenderer, RaySampler
     with pytest.raises(AssertionError):
         RaySampler()(torch.eye(4)[None], torch.eye(3)[None], 8)          # device tensors only, no CPU fallback
-    ren = ImportanceRenderer(hp={"triplane_feature_type": "trigrid_v2"})
+    ren = ImportanceRenderer(hp={"triplane_feature_type": "3dgrid"})
     with pytest.raises(NotImplementedError):
         ren._check_options({"ray_start": "auto", "ray_end": "auto"})
+    tri = ImportanceRenderer(hp={"triplane_feature_type": "trigrid_v2", "triplane_depth": 3})
+    assert tri.triplane_depth == 3 and ImportanceRenderer(hp={"triplane_depth": 3}).triplane_depth == 1   # depth only for trigrids
+    tri._check_options({"ray_start": "auto", "ray_end": "auto"})
     ren = ImportanceRenderer(hp={})
     with pytest.raises(NotImplementedError):
         ren._check_options({"ray_start": 2.25, "ray_end": 3.3})

@@ -6,7 +6,7 @@ import pytest
 from conftest import golden_planes, load_golden
 
 RENDER_CASES = ["render_a_r16_16p16", "render_b_n2_r16_48p48", "render_c_invalid_r16_16p0",
-                "render_e_white_r12_32p16_bw", "render_d_cfg1_r64_16p16"]
+                "render_e_white_r12_32p16_bw", "render_d_cfg1_r64_16p16", "render_f_trigrid_d3_r12_20p12"]
 
 # fp32 tolerances (rgb in [-1,1]); SURVEY 8(d): rgb <= 2e-4, depth <= 1e-4
 RGB_TOL, DEPTH_TOL = 2e-4, 1e-4
@@ -36,16 +36,18 @@ def test_render_matches_reference(oracle, name):
     g = load_golden(name)
     planes = golden_planes(g)
     rgb, depth, wsum, valid = oracle.render(planes, dec_of(g), g["origins"], g["dirs"], int(g["Nc"]), int(g["Nf"]),
-                                            g["noise_c"], g["u_f"], float(g["box_warp"]), bool(g["white_back"]))
+                                            g["noise_c"], g["u_f"], float(g["box_warp"]), bool(g["white_back"]),
+                                            triplane_depth=int(g["triplane_depth"]))
     assert np.array_equal(valid, g["valid"])
     assert np.abs(rgb - g["rgb"]).max() <= RGB_TOL
     assert np.abs(wsum - g["wsum"]).max() <= RGB_TOL
     assert np.abs(depth - g["depth"]).max() <= DEPTH_TOL
 
 
-def test_run_model_matches_reference(oracle):
-    g = load_golden("run_model_a")
-    rgb, sigma = oracle.run_model(g["planes"], dec_of(g), g["coords"], float(g["box_warp"]))
+@pytest.mark.parametrize("name", ["run_model_a", "run_model_b_trigrid_d3"])
+def test_run_model_matches_reference(oracle, name):
+    g = load_golden(name)
+    rgb, sigma = oracle.run_model(g["planes"], dec_of(g), g["coords"], float(g["box_warp"]), triplane_depth=int(g["triplane_depth"]))
     assert np.abs(rgb - g["rgb"]).max() <= 2e-5
     assert np.abs(sigma - g["sigma"]).max() <= 2e-4     # sigma is unbounded (|sigma| ~ 10)
 
