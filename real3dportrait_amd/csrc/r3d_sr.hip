@@ -401,7 +401,7 @@ extern "C" size_t r3d_sr_block_workspace_bytes(int N, int Cin, int Cout, int Hin
     const size_t T = align256((size_t)N * Cout * 4 * (Hin + 1) * (Win + 1) * 4);
     const size_t y0 = align256((size_t)N * Cout * 4 * Hin * Win * 4);
     const size_t xo = align256((size_t)N * Cout * 4 * Hin * Win * 4);
-    const size_t rgbp = align256((size_t)N * (Cout / BLOCK_M) * 3 * 4 * Hin * Win * 4);
+    const size_t rgbp = align256((size_t)N * (Cout / 64) * 3 * 4 * Hin * Win * 4);     // toRGB partial planes, one per 64 couts
     return xin + T + y0 + xo + rgbp;
 }
 

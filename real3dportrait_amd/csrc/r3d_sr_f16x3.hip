@@ -86,6 +86,18 @@ __global__ void to_split_kernel(const float* __restrict__ src, int cb8, const fl
     d[plane] = *reinterpret_cast<uint4*>(&lo);
 }
 
+__device__ uint4 g_zero16[1];      // DMA source of zero-filled (out-of-image / padding) patch slots
+
+// LDS-DMA of one wave-instruction: 64 lanes x 16 B from per-lane global addresses to LDS [dst, dst + 1 KB).  Inline asm so
+// that hipcc does not serialise the ds_reads of the other buffer behind it (waits are the explicit vmcnt(0) per stage).
+__device__ __forceinline__ void dma64(const uint4* gsrc, uint4* lds_dst_uniform)
+{
+    const unsigned d = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) uint4*)lds_dst_uniform);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(d) : "memory");
+}
+
 // ---- conv ----------------------------------------------------------------------------------------------------
 struct Conv2Args {
     const uint4* x; size_t x_stride_n;        // SPLIT input (hi plane, lo plane), per-n stride in uint4 units
@@ -101,6 +113,103 @@ struct Conv2Args {
     int act; float act_slope, act_gain, clamp; // act: leaky-relu(slope) * gain after the bias; clamp < 0: off
     ConvPhase ph[4];
 };
+
+// Epilogue of a 128-cout x 16x16-pixel block held as acc[2][NT] per wave: demodulation * acc (+ bias -> lrelu * gain ->
+// clamp) -> any of {fp32 channel-blocked, fp32 NCHW, SPLIT scaled by the next layer's styles} + toRGB partial sums.
+// toRGB partials: one plane per 64-cout half (index 2 * blockIdx.y + wm); rgb_finalize_kernel adds them up.
+template <bool FULL_EPI, int WN, int NT>
+__device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhase& ph, int n, f32x16 (&acc)[2][NT],
+                                              int i0, int j0, int m0)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int li = lane & 31, h = lane >> 5;
+    const int prow = li >> 4, pcol = ((li & 15) - 2 * prow) & 15;
+    const int row0 = wn * 2 * NT;
+    // ---- epilogue ------------------------------------------------------------------------------------------------
+    const bool do_rgb = FULL_EPI && a.rgb_partial != nullptr;
+    float rgbp[NT][3];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { rgbp[nt][0] = 0.f; rgbp[nt][1] = 0.f; rgbp[nt][2] = 0.f; }
+    const size_t oplane = (size_t)(a.CoutReal >> 3) * a.OH * a.OW;
+    float* Yf = a.y_f32 ? a.y_f32 + (size_t)n * a.y_f32_stride_n + ph.out_off : nullptr;
+    float* Yn = (FULL_EPI && a.y_nchw) ? a.y_nchw + (size_t)n * a.y_nchw_stride_n : nullptr;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int i = i0 + row0 + nt * 2 + prow, j = j0 + pcol;
+        const bool inside = i < ph.outH && j < ph.outW;
+        const int oy = i * ph.oy_mul + ph.oy_add, ox = j * ph.ox_mul + ph.ox_add;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int co = m0 + 64 * wm + 32 * mt + 8 * g + 4 * h;
+                if (co >= a.CoutReal) continue;                       // channels that only exist as weight padding
+                float4 d4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.out_scale) d4 = *reinterpret_cast<const float4*>(a.out_scale + (size_t)n * a.out_scale_stride_n + co);
+                if (FULL_EPI && a.bias) b4 = *reinterpret_cast<const float4*>(a.bias + (size_t)n * a.bias_stride_n + co);
+                const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float t = acc[mt][nt][4 * g + r] * dv[r];
+                    if (FULL_EPI) {
+                        t += bv[r];
+                        if (a.act) t = (t < 0.f ? t * a.act_slope : t) * a.act_gain;
+                        if (a.clamp >= 0.f) t = fminf(fmaxf(t, -a.clamp), a.clamp);
+                    }
+                    v[r] = t;
+                }
+                if (do_rgb) {
+                    const float* wr = a.wrgb + (size_t)n * a.wrgb_stride_n;
+                    const float4 w0 = *reinterpret_cast<const float4*>(wr + co);
+                    const float4 w1 = *reinterpret_cast<const float4*>(wr + a.CoutReal + co);
+                    const float4 w2 = *reinterpret_cast<const float4*>(wr + 2 * a.CoutReal + co);
+                    rgbp[nt][0] += v[0] * w0.x + v[1] * w0.y + v[2] * w0.z + v[3] * w0.w;
+                    rgbp[nt][1] += v[0] * w1.x + v[1] * w1.y + v[2] * w1.z + v[3] * w1.w;
+                    rgbp[nt][2] += v[0] * w2.x + v[1] * w2.y + v[2] * w2.z + v[3] * w2.w;
+                }
+                if (!inside) continue;
+                const size_t pix = ((size_t)(co >> 3) * a.OH + oy) * a.OW + ox;
+                if (Yf) *reinterpret_cast<float4*>(Yf + pix * 8 + (co & 7)) = make_float4(v[0], v[1], v[2], v[3]);
+                if (Yn) {
+                    const size_t hw = (size_t)a.OH * a.OW, p0 = (size_t)oy * a.OW + ox;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) Yn[(size_t)(co + r) * hw + p0] = v[r];
+                }
+                if (FULL_EPI && a.y_split) {
+                    float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f);
+                    if (a.next_scale) s4 = *reinterpret_cast<const float4*>(a.next_scale + (size_t)n * a.next_scale_stride_n + co);
+                    const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
+                    h4 hi, lo;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { _Float16 x0, x1; split1(v[r] * sv[r], x0, x1); hi[r] = x0; lo[r] = x1; }
+                    uint2* dst = reinterpret_cast<uint2*>(a.y_split + (size_t)n * a.y_split_stride_n + pix) + ((co & 7) >> 2);
+                    dst[0] = *reinterpret_cast<uint2*>(&hi);
+                    dst[2 * oplane] = *reinterpret_cast<uint2*>(&lo);
+                }
+            }
+    }
+    if (do_rgb) {
+        // add the two lane halves (disjoint couts); each 64-cout wave row stores its own partial plane
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int o = 0; o < 3; ++o) rgbp[nt][o] += __shfl_xor(rgbp[nt][o], 32);
+        if (h == 0) {
+            float* P = a.rgb_partial + (size_t)n * a.rgbp_stride_n + (size_t)(2 * blockIdx.y + wm) * 3 * a.OH * a.OW;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int i = i0 + row0 + nt * 2 + prow, j = j0 + pcol;
+                if (i < ph.outH && j < ph.outW) {
+                    const int oy = i * ph.oy_mul + ph.oy_add, ox = j * ph.ox_mul + ph.ox_add;
+#pragma unroll
+                    for (int o = 0; o < 3; ++o) P[(size_t)o * a.OH * a.OW + (size_t)oy * a.OW + ox] = rgbp[nt][o];
+                }
+            }
+        }
+    }
+}
 
 // One block: 128 couts x 16x16 pixels, WN x 2 waves; wave (wm, wn) owns couts [64wm, +64) and pixel rows
 // [2*NT*wn, +2*NT) as 2 x NT MFMA tiles (WN=2,NT=4: 4 waves x 128 accumulators; WN=4,NT=2: 8 waves x 64 accumulators
@@ -266,102 +375,152 @@ __device__ __forceinline__ void conv2_block(const Conv2Args& a, const ConvPhase&
         }
     }
     __syncthreads();
-    uint4* patch = lds;      // LDS is reused by the epilogue's toRGB reduction
+    conv_epilogue<FULL_EPI, WN, NT>(a, ph, n, acc, i0, j0, m0);
+}
 
-    // ---- epilogue ------------------------------------------------------------------------------------------------
-    const float* B = a.bias ? a.bias + (size_t)n * a.bias_stride_n : nullptr;
-    const float* D = a.out_scale ? a.out_scale + (size_t)n * a.out_scale_stride_n : nullptr;
-    const float* NS = a.next_scale ? a.next_scale + (size_t)n * a.next_scale_stride_n : nullptr;
-    const bool do_rgb = FULL_EPI && a.rgb_partial != nullptr;
-    float rgbp[NT][3];
+// ---- plain 3x3 conv, LDS-DMA pipeline ------------------------------------------------------------------------------
+// Same tile as conv2_block<9, ., 4, 2> (128 couts x 16x16 pixels, 8 waves x (64 couts x 64 px)) but every byte reaches LDS
+// by global_load_lds (no staging VGPRs, no ds_write): the register-staged version spilled its third patch prefetch and
+// waited for it right after issuing it, once per stage.
+//   * patch (B operand, 16 channels, hi|lo): double-buffered, 21 x 64-slot DMA segments (out-of-image slots read a zero
+//     block); patch(s+1) is issued as soon as stage s-1 is finished with that buffer, two sub-stages ahead of its first use.
+//   * weights (A operand): sub-stages of TWO taps ([ts][chunk][hi|lo][128 couts] = 16 KB, two DMAs per wave), double-
+//     buffered.  The tap sequence runs across stages (9 taps = 4.5 sub-stages), so the loop is unrolled over 9 sub-stages
+//     = 2 stages; an odd last stage skips the missing taps.
+//   * one barrier per sub-stage (24 MFMAs per wave): wait for this sub-stage's weights (counted vmcnt: a patch DMA issued
+//     after them stays in flight), barrier, issue the next sub-stage's DMAs, compute.
+// LDS: 2 x 21.5 KB patch + 2 x 16 KB weights = 75.8 KB -> 2 blocks/CU.
+static constexpr int P_SEGS = 21, P_BUF = P_SEGS * 64;               // 1344 uint4 per patch buffer (1296 used)
+static constexpr int W2_BUF = 2 * 2 * 2 * 128;                        // 1024 uint4 per 2-tap weight sub-stage
+static constexpr int F3_LDS_UINT4 = 2 * P_BUF + 2 * W2_BUF;           // 4736 uint4 = 75.8 KB
+
+template <bool FULL_EPI>
+__device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const ConvPhase& ph, int n, uint4* lds)
+{
+    constexpr int WN = 4, NT = 2;
+    uint4* pbuf = lds;                                                // [2][P_BUF]
+    uint4* wbuf = lds + 2 * P_BUF;                                    // [2][W2_BUF]
+    const int tiles_x = (ph.outW + F_TILE_W - 1) / F_TILE_W;
+    const int tile = blockIdx.x;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int i0 = ty * F_TILE_H, j0 = tx * F_TILE_W;
+    const int m0 = blockIdx.y * BLOCK_M;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int li = lane & 31, h = lane >> 5;
+    const int nchunks = a.Cin >> 3, nst = a.Cin >> 4;
+    const int chunk_stride = a.H * a.W;
+    const size_t plane = (size_t)nchunks * chunk_stride;
+    const uint4* X = a.x + (size_t)n * a.x_stride_n;
+    const uint4* WP = a.wp + m0 + (wave_u & 1) * 64 + lane;           // this wave's 64-cout half of the 128-cout rows
+
+    f32x16 acc[2][NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { rgbp[nt][0] = 0.f; rgbp[nt][1] = 0.f; rgbp[nt][2] = 0.f; }
-    const size_t oplane = (size_t)(a.CoutReal >> 3) * a.OH * a.OW;
-    float* Yf = a.y_f32 ? a.y_f32 + (size_t)n * a.y_f32_stride_n + ph.out_off : nullptr;
-    float* Yn = (FULL_EPI && a.y_nchw) ? a.y_nchw + (size_t)n * a.y_nchw_stride_n : nullptr;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int i = i0 + row0 + nt * 2 + prow, j = j0 + pcol;
-        const bool inside = i < ph.outH && j < ph.outW;
-        const int oy = i * ph.oy_mul + ph.oy_add, ox = j * ph.ox_mul + ph.ox_add;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = m0 + 64 * wm + 32 * mt + 8 * g + 4 * h;
-                if (co >= a.CoutReal) continue;                       // channels that only exist as weight padding
-                float dv[4] = {1.f, 1.f, 1.f, 1.f}, bv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (D) { const float4 d4 = *reinterpret_cast<const float4*>(D + co); dv[0] = d4.x; dv[1] = d4.y; dv[2] = d4.z; dv[3] = d4.w; }
-                if (FULL_EPI && B) { const float4 b4 = *reinterpret_cast<const float4*>(B + co); bv[0] = b4.x; bv[1] = b4.y; bv[2] = b4.z; bv[3] = b4.w; }
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float t = acc[mt][nt][4 * g + r] * dv[r];
-                    if (FULL_EPI) {
-                        t += bv[r];
-                        if (a.act) t = (t < 0.f ? t * a.act_slope : t) * a.act_gain;
-                        if (a.clamp >= 0.f) t = fminf(fmaxf(t, -a.clamp), a.clamp);
-                    }
-                    v[r] = t;
-                }
-                if (do_rgb) {
-                    const float* wr = a.wrgb + (size_t)n * a.wrgb_stride_n;
-                    const float4 w0 = *reinterpret_cast<const float4*>(wr + co);
-                    const float4 w1 = *reinterpret_cast<const float4*>(wr + a.CoutReal + co);
-                    const float4 w2 = *reinterpret_cast<const float4*>(wr + 2 * a.CoutReal + co);
-                    rgbp[nt][0] += v[0] * w0.x + v[1] * w0.y + v[2] * w0.z + v[3] * w0.w;
-                    rgbp[nt][1] += v[0] * w1.x + v[1] * w1.y + v[2] * w1.z + v[3] * w1.w;
-                    rgbp[nt][2] += v[0] * w2.x + v[1] * w2.y + v[2] * w2.z + v[3] * w2.w;
-                }
-                if (!inside) continue;
-                const size_t pix = ((size_t)(co >> 3) * a.OH + oy) * a.OW + ox;
-                if (Yf) *reinterpret_cast<float4*>(Yf + pix * 8 + (co & 7)) = make_float4(v[0], v[1], v[2], v[3]);
-                if (Yn) {
-                    const size_t hw = (size_t)a.OH * a.OW, p0 = (size_t)oy * a.OW + ox;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) Yn[(size_t)(co + r) * hw + p0] = v[r];
-                }
-                if (FULL_EPI && a.y_split) {
-                    float sv[4] = {1.f, 1.f, 1.f, 1.f};
-                    if (NS) { const float4 s4 = *reinterpret_cast<const float4*>(NS + co); sv[0] = s4.x; sv[1] = s4.y; sv[2] = s4.z; sv[3] = s4.w; }
-                    h4 hi, lo;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { _Float16 x0, x1; split1(v[r] * sv[r], x0, x1); hi[r] = x0; lo[r] = x1; }
-                    uint2* dst = reinterpret_cast<uint2*>(a.y_split + (size_t)n * a.y_split_stride_n + pix) + ((co & 7) >> 2);
-                    dst[0] = *reinterpret_cast<uint2*>(&hi);
-                    dst[2 * oplane] = *reinterpret_cast<uint2*>(&lo);
-                }
-            }
-    }
-    if (do_rgb) {
-        // reduce the two lane halves (disjoint couts), then the two cout-waves through LDS (reusing the patch)
-        float* red = reinterpret_cast<float*>(patch);
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int o = 0; o < 3; ++o) rgbp[nt][o] += __shfl_xor(rgbp[nt][o], 32);
-        __syncthreads();
-        if (wm == 1 && h == 0) {
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    const int prow = li >> 4, pcol = ((li & 15) - 2 * prow) & 15;
+    const int row0 = wn * 2 * NT;
+    int boff[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt) boff[nt] = (row0 + nt * 2 + prow + 1) * F_PATCH_W + (pcol + 1) + h * F_PATCH_PIX;
+    const int aoff = h * 256 + 64 * wm + li;                          // [ts][chunk = h][hi|lo][128]: + ts*512 + mt*32 (+128 for lo)
+
+    // patch DMA: wave w fills segments w, w+8, w+16 (< 21); slot e = 64*seg + lane -> (plane, chunk, 18x18 pixel)
+    unsigned pf_off[3];
+    unsigned pf_valid = 0;
 #pragma unroll
-                for (int o = 0; o < 3; ++o) red[((wn * NT + nt) * 3 + o) * 32 + li] = rgbp[nt][o];
+    for (int k = 0; k < 3; ++k) {
+        const int e = (8 * k + wave_u) * 64 + lane;
+        unsigned off = 0;
+        if (e < 4 * F_PATCH_PIX) {
+            const int pl = e / (2 * F_PATCH_PIX), rem = e - pl * (2 * F_PATCH_PIX);
+            const int c = rem / F_PATCH_PIX, pp = rem - c * F_PATCH_PIX;
+            const int py = pp / F_PATCH_W, px = pp - py * F_PATCH_W;
+            const int iy = i0 + py - 1, ix = j0 + px - 1;
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+                off = (unsigned)(pl * plane) + (unsigned)(c * chunk_stride + iy * a.W + ix);
+                pf_valid |= 1u << k;
+            }
         }
-        __syncthreads();
-        if (wm == 0 && h == 0) {
+        pf_off[k] = off;
+    }
+    const bool three = wave_u < P_SEGS - 16;                          // waves 0..4 issue three patch DMAs, the others two
+    auto dma_patch = [&](int st, uint4* dst) {
+        const uint4* Xs = X + (size_t)(2 * st) * chunk_stride;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int i = i0 + row0 + nt * 2 + prow, j = j0 + pcol;
-                if (i < ph.outH && j < ph.outW) {
-                    const int oy = i * ph.oy_mul + ph.oy_add, ox = j * ph.ox_mul + ph.ox_add;
+        for (int k = 0; k < 3; ++k)
+            if (k < 2 || three) dma64((pf_valid & (1u << k)) ? Xs + pf_off[k] : g_zero16, dst + 64 * (8 * k + wave_u));
+    };
+    // weights of linear tap T (stage T / 9, tap T % 9) -> slot ts of a sub-stage buffer; wave w moves (chunk, hi|lo, cout half)
+    // = bits (2, 1, 0) of w for both taps of the sub-stage
+    auto dma_weights2 = [&](int T0, uint4* dst) {
 #pragma unroll
-                    for (int o = 0; o < 3; ++o)
-                        a.rgb_partial[(size_t)n * a.rgbp_stride_n + ((size_t)blockIdx.y * 3 + o) * a.OH * a.OW + (size_t)oy * a.OW + ox] =
-                            rgbp[nt][o] + red[((wn * NT + nt) * 3 + o) * 32 + li];
+        for (int ts = 0; ts < 2; ++ts) {
+            const int T = T0 + ts;
+            if (T < 9 * nst) {
+                const int st = T / 9, t = T - 9 * st;
+                const int hc = (wave_u >> 2) & 1, hl = (wave_u >> 1) & 1;
+                dma64(WP + (((size_t)ph.widx[t] * nchunks + (2 * st + hc)) * 2 + hl) * a.Cout, dst + ts * 512 + wave_u * 64);
+            }
+        }
+    };
+
+    // prologue: patch(0) and the first weight sub-stage
+    dma_weights2(0, wbuf);
+    dma_patch(0, pbuf);
+    for (int sp = 0; sp < nst; sp += 2) {
+#pragma unroll
+        for (int uu = 0; uu < 9; ++uu) {
+            const int T0 = 9 * sp + 2 * uu;                           // first linear tap of this sub-stage
+            if (T0 >= 9 * nst) break;
+            // a patch DMA was issued AFTER the weights this sub-stage needs (at the top of uu = 0 / 5): leave it in flight
+            const bool patch_behind = (uu == 1 && sp + 1 < nst) || (uu == 6 && sp + 2 < nst);
+            if (patch_behind) {
+                if (three) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int par = (uu + (sp >> 1)) & 1;                     // 9 sub-stages per stage pair: the buffer parity alternates between pairs
+            const uint4* curW = wbuf + par * W2_BUF;
+            dma_weights2(T0 + 2, wbuf + (par ^ 1) * W2_BUF);
+            if (uu == 0 && sp + 1 < nst) dma_patch(sp + 1, pbuf + P_BUF);
+            if (uu == 5 && sp + 2 < nst) dma_patch(sp + 2, pbuf);
+#pragma unroll
+            for (int ts = 0; ts < 2; ++ts) {
+                const int Tl = 2 * uu + ts;                           // 0..17 within the stage pair (compile time)
+                const int sl = Tl / 9, t = Tl - 9 * sl;
+                if (sp + sl < nst) {
+                    const uint4* curP = pbuf + sl * P_BUF;
+                    h8 ah[2], al[2];
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        uint4 q0 = curW[ts * 512 + aoff + mt * 32], q1 = curW[ts * 512 + aoff + mt * 32 + 128];
+                        ah[mt] = *reinterpret_cast<h8*>(&q0); al[mt] = *reinterpret_cast<h8*>(&q1);
+                    }
+                    const int toff = ph.dy[t] * F_PATCH_W + ph.dx[t];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        uint4 r0 = curP[boff[nt] + toff];
+                        uint4 r1 = curP[boff[nt] + toff + 2 * F_PATCH_PIX];
+                        const h8 bh = *reinterpret_cast<h8*>(&r0), bl = *reinterpret_cast<h8*>(&r1);
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
+                        }
+                    }
                 }
             }
         }
     }
+    __syncthreads();
+    conv_epilogue<FULL_EPI, WN, NT>(a, ph, n, acc, i0, j0, m0);
 }
 
 static constexpr int F_LDS_UINT4 = 2 * 2 * F_PATCH_PIX + 2 * 3 * 2 * 256;      // patch (20.7 KB) + 2 x 3-tap weight sub-stage (2 x 24.6 KB)
@@ -370,8 +529,13 @@ static constexpr int F_LDS_UINT4 = 2 * 2 * F_PATCH_PIX + 2 * 3 * 2 * 256;      /
 template <int WN, int NT, int OCC>
 __global__ __launch_bounds__(128 * WN, OCC) void conv_mfma_f16x3_kernel(Conv2Args a)
 {
-    __shared__ uint4 lds[F_LDS_UINT4];
-    conv2_block<9, true, WN, NT>(a, a.ph[0], blockIdx.z, lds);
+    if constexpr (WN == 4 && NT == 2) {
+        __shared__ uint4 lds[F3_LDS_UINT4];
+        conv3x3_dma_block<true>(a, a.ph[0], blockIdx.z, lds);
+    } else {
+        __shared__ uint4 lds[F_LDS_UINT4];
+        conv2_block<9, true, WN, NT>(a, a.ph[0], blockIdx.z, lds);
+    }
 }
 
 // 1x1 conv with the full epilogue (nn.Conv2d(k=1) layers of the torso/background fusion stack)
@@ -416,8 +580,6 @@ static constexpr int U_PATCH = 4 * U_PPLANE;                        // uint4: [h
 static constexpr int U_STAGE = U_PATCH + U_WSTAGE;                  // 2432 uint4 per stage buffer
 static constexpr int U_LDS_UINT4 = 2 * U_STAGE;                     // double-buffered: 77.8 KB (epilogue slice: 2048 uint4)
 
-__device__ uint4 g_zero16[1];
-                                       // DMA source of zero-filled (out-of-image / padding) patch slots
 
 struct UpArgs {
     const uint4* x; size_t x_stride_n;          // SPLIT input [hi|lo][Cin/8][H][W]
@@ -447,16 +609,6 @@ __global__ void sr_prepack_up_kernel(const float* __restrict__ w, int Cin, int C
         v8[j] = hl ? b : a;
     }
     out[e] = *reinterpret_cast<uint4*>(&v8);
-}
-
-// LDS-DMA of one wave-instruction: 64 lanes x 16 B from per-lane global addresses to LDS [dst, dst + 1 KB).  Inline asm so
-// that hipcc does not serialise the ds_reads of the other buffer behind it (waits are the explicit vmcnt(0) per stage).
-__device__ __forceinline__ void dma64(const uint4* gsrc, uint4* lds_dst_uniform)
-{
-    const unsigned d = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) uint4*)lds_dst_uniform);
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(d) : "memory");
 }
 
 __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
@@ -965,7 +1117,7 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
             a.y_split = reinterpret_cast<uint4*>(x_out); a.y_split_stride_n = (size_t)Cout / 8 * OH * OW * 2;
             a.next_scale = next_scale; a.next_scale_stride_n = next_scale_stride;
         }
-        a.wrgb = pk + L.wrgb; a.wrgb_stride_n = L.total; a.rgb_partial = rgbp; a.rgbp_stride_n = (size_t)(Cout / BLOCK_M) * 3 * OH * OW;
+        a.wrgb = pk + L.wrgb; a.wrgb_stride_n = L.total; a.rgb_partial = rgbp; a.rgbp_stride_n = (size_t)(Cout / 64) * 3 * OH * OW;
         a.Cin = Cout; a.Cout = Cout; a.CoutReal = Cout; a.H = OH; a.W = OW; a.nphase = 1;
         a.act = 1; a.act_slope = 0.2f; a.act_gain = 1.4142135623730951f; a.clamp = clamp;
         sr_fill_conv3x3_phase(a.ph, OH, OW);
@@ -976,7 +1128,7 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
     {
         ProfScope ps(R3D_PROF_TORGB, st);
         hipLaunchKernelGGL(rgb_finalize_kernel, dim3((OH * OW + 255) / 256, N), dim3(256), 0, st, img, rgbp,
-                           (size_t)(Cout / BLOCK_M) * 3 * OH * OW, Cout / BLOCK_M, pk + L.brgb, L.total, img_out, OH, OW, clamp, up);
+                           (size_t)(Cout / 64) * 3 * OH * OW, Cout / 64, pk + L.brgb, L.total, img_out, OH, OW, clamp, up);
     }
     return check_launch("sr_block_forward(f16x3)");
 }

@@ -424,6 +424,38 @@ def test_unsupported_options_raise(torch_cuda):
         ren(torch.zeros(1, 3, 32, 8, 8, device="cuda"), None, o, o, bad)
 
 
+def test_sr_concurrent_streams_are_bit_identical(torch_cuda):
+    """SR shells that share parameters, run on three HIP streams at once (different kernels co-resident on the CUs), must
+    reproduce the single-stream output bit for bit, every time (guards the LDS-DMA pipelines against timing-dependent
+    hazards: a staging variant of the conv epilogue passed every single-stream test and failed this one)."""
+    torch = torch_cuda
+    from real3dportrait_amd import SuperresolutionHybrid8XDC
+    torch.manual_seed(0)
+    base = SuperresolutionHybrid8XDC(32, 512, 0, True).cuda()
+
+    def shell():
+        sr = SuperresolutionHybrid8XDC(32, 512, 0, True).cuda()
+        for name in ("block0", "block1"):
+            src, dst = getattr(base, name), getattr(sr, name)
+            dst.conv0, dst.conv1, dst.torgb = src.conv0, src.conv1, src.torgb
+        return sr
+    x = torch.randn(1, 32, 128, 128, device="cuda"); rgb = torch.randn(1, 3, 128, 128, device="cuda") * 0.3
+    ws = torch.ones(1, 14, 512, device="cuda")
+    ref = base(rgb, x, ws, noise_mode="none").clone()
+    shells = [shell() for _ in range(3)]; streams = [torch.cuda.Stream() for _ in range(3)]
+    for s_ in shells:
+        s_(rgb, x, ws, noise_mode="none")
+    torch.cuda.synchronize()
+    for _ in range(12):
+        outs = []
+        for s_, st in zip(shells, streams):
+            with torch.cuda.stream(st):
+                outs.append(s_(rgb, x, ws, noise_mode="none"))
+        torch.cuda.synchronize()
+        for o in outs:
+            assert torch.equal(o, ref)
+
+
 def test_multi_stream_pipeline_is_bit_identical(torch_cuda):
     """Frames issued round-robin on several HIP streams (own workspaces, shared parameters) must equal the
     single-stream frames bit for bit: the hash noise depends on the frame index only."""
