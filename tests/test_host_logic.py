@@ -47,6 +47,48 @@ def test_decoder_and_generator_keys():
     assert G.rendering_kwargs["depth_resolution"] == 48 and G.rendering_kwargs["depth_resolution_importance"] == 48
 
 
+def test_conv_stack_mirrors_torch_sequential():
+    """ConvStack.from_torch keeps the reference's state_dict keys/shapes (the fusion stacks and to_plane_cnn are plain
+    nn.Sequential upstream: sr_with_ref.py:24-63, segformer.py:691-700) and rejects what the HIP conv does not cover."""
+    from real3dportrait_amd import synth
+    from real3dportrait_amd.superresolution import Conv2d, ConvStack, SynthesisBlockNoUp
+    nn = torch.nn
+    seq = nn.Sequential(nn.Conv2d(256, 256, 3, 1, padding=1), nn.LeakyReLU(0.01, inplace=True), nn.UpsamplingBilinear2d(scale_factor=2.),
+                        nn.Conv2d(256, 96, 3, 1, padding=1))
+    st = ConvStack.from_torch(seq)
+    assert list(st.state_dict().keys()) == list(seq.state_dict().keys())
+    for k, v in seq.state_dict().items():
+        assert torch.equal(st.state_dict()[k], v)
+    assert isinstance(st[0], Conv2d) and st[1].negative_slope == 0.01
+    with pytest.raises(NotImplementedError):
+        ConvStack.from_torch(nn.Sequential(nn.Conv2d(8, 8, 3, 2, padding=1)))           # stride 2
+    with pytest.raises(NotImplementedError):
+        ConvStack.from_torch(nn.Sequential(nn.Conv2d(8, 8, 3, 1, padding=1), nn.ReLU()))
+    with pytest.raises(NotImplementedError):
+        Conv2d(32, 1, 3, 1, padding=1)                                                   # Cout % 4 (alpha predictor head)
+    blk = SynthesisBlockNoUp(256, 256, w_dim=512, resolution=256, img_channels=3, is_last=False, conv_clamp=None)
+    assert blk._UP == 0 and blk.conv0.up == 1 and blk.conv0.weight.shape == (256, 256, 3, 3)
+    assert [c for c, *_ in synth.FUSION_STACKS["fuse_fg_bg_convs"]] == [512, 64, 256]
+
+
+def test_noup_block_keys_match_reference():
+    """The reference's SynthesisBlockNoUp (superresolution.py:159) and ours expose the same state_dict."""
+    import os, sys
+    ref = os.environ.get("R3D_REFERENCE", "/root/reference")
+    if not os.path.isdir(ref):
+        pytest.skip("reference checkout not present (GPU box)")
+    sys.path.insert(0, ref)
+    try:
+        from modules.eg3ds.models.superresolution import SynthesisBlockNoUp as RefNoUp
+    finally:
+        sys.path.remove(ref)
+    from real3dportrait_amd.superresolution import SynthesisBlockNoUp
+    kw = dict(w_dim=512, resolution=256, img_channels=3, is_last=False, use_fp16=False, conv_clamp=None)
+    a = RefNoUp(256, 256, channel_base=32768, channel_max=512, fused_modconv_default="inference_only", **kw).state_dict()
+    b = SynthesisBlockNoUp(256, 256, **kw).state_dict()
+    assert {k: tuple(v.shape) for k, v in a.items()} == {k: tuple(v.shape) for k, v in b.items()}
+
+
 def test_operators_refuse_cpu_tensors_and_bad_options():
     from real3dportrait_amd import ImportanceRenderer, RaySampler
     with pytest.raises(AssertionError):
