@@ -371,6 +371,32 @@ def test_full_size_properties(torch_cuda):
     assert torch.equal(r2[0][0], r2[0][1]) and torch.equal(r2[1][0], r2[1][1])
 
 
+@pytest.mark.parametrize("up", [True, False])
+@pytest.mark.parametrize("N,Cin,Cout,H,W,clamp", [(2, 32, 128, 20, 12, None), (1, 64, 256, 15, 33, 0.75), (3, 16, 128, 9, 9, 256.0)])
+def test_sr_block_ragged_vs_oracle(torch_cuda, oracle, up, N, Cin, Cout, H, W, clamp):
+    """SynthesisBlock / SynthesisBlockNoUp on non-square, non-tile-multiple sizes, batch > 1, per-sample styles and an
+    ACTIVE conv_clamp (the reference default 256 is inert; 0.75 clips), against the C oracle."""
+    torch = torch_cuda
+    from real3dportrait_amd import synth
+    from real3dportrait_amd.superresolution import SynthesisBlock, SynthesisBlockNoUp
+    params = synth.synth_sr_block(41, Cin, Cout, 512, 700)
+    blk = (SynthesisBlock if up else SynthesisBlockNoUp)(Cin, Cout, w_dim=512, resolution=2 * H if up else H, img_channels=3,
+                                                         is_last=False, conv_clamp=clamp).cuda()
+    load_block(torch, blk, params)
+    x = synth.hash_unitvar(42, (N, Cin, H, W), stream=1)
+    img = synth.hash_unitvar(42, (N, 3, H, W), stream=2) * np.float32(0.5)
+    ws = np.ones((N, 3, 512), np.float32) + synth.hash_unitvar(42, (N, 3, 512), stream=3) * np.float32(0.2)   # differs per sample
+    xo, io = blk(T(torch, x), T(torch, img), T(torch, ws), noise_mode="none")
+    xo, io = xo.cpu().numpy(), io.cpu().numpy()
+    for n in range(N):
+        rx, ri = oracle.sr_block(x[n], img[n], params, ws[n], clamp=clamp, up=up)
+        assert xo[n].shape == rx.shape and io[n].shape == ri.shape
+        assert np.abs(xo[n] - rx).max() <= SR_TOL * max(1.0, np.abs(rx).max())
+        assert np.abs(io[n] - ri).max() <= SR_TOL * max(1.0, np.abs(ri).max())
+    if clamp is not None and clamp < 1:
+        assert np.abs(xo).max() <= clamp + 1e-6 and (np.abs(xo) >= clamp - 1e-6).mean() > 0.01      # the clamp really bites
+
+
 def test_sr_rgb_skip_is_linear(torch_cuda):
     """The RGB skip path is linear: SR(rgb + delta, x) - SR(rgb, x) == upsample2d(upsample2d(delta)) and does not
     depend on x (networks_stylegan2.py:463-469)."""
