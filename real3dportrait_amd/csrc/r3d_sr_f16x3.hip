@@ -611,6 +611,7 @@ __global__ void sr_prepack_up_kernel(const float* __restrict__ w, int Cin, int C
     out[e] = *reinterpret_cast<uint4*>(&v8);
 }
 
+template <bool CLAMP>
 __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
 {
     __shared__ uint4 lds[U_LDS_UINT4];
@@ -777,7 +778,7 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
                 f2 ha[5], hb[5];
 #pragma unroll
                 for (int rr = 0; rr < 5; ++rr) {                    // H row 2rp+1+rr = phase (rr+1)&1 at grid row rp + (rr+1)/2
-                    const int gyy = live ? rp + ((rr + 1) >> 1) : 0;
+                    const int gyy = min(rp, U_TILE - 1) + ((rr + 1) >> 1);   // (clamped: dead items read valid LDS)
                     const float4 t4 = hls[((((rr + 1) & 1) * 2 + half) * 16 + gyy) * 32 + ((oc + 8 * half) & 31)];
                     ha[rr] = f2{t4.x, t4.y}; hb[rr] = f2{t4.z, t4.w};
                 }
@@ -787,7 +788,7 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
                     f2 vb = bb + (hb[dy] + hb[dy + 3]) * c0 + (hb[dy + 1] + hb[dy + 2]) * c1;
                     va = __builtin_elementwise_max(va, va * 0.2f);  // leaky relu (slope 0.2); sqrt(2) gain is inside ma/mb
                     vb = __builtin_elementwise_max(vb, vb * 0.2f);
-                    if (a.clamp >= 0.f) {                           // conv_clamp acts on the gained activation
+                    if constexpr (CLAMP) {                          // conv_clamp acts on the gained activation
                         const f2 lim = f2{a.clamp, a.clamp} * 0.7071067811865476f;
                         va = __builtin_elementwise_min(__builtin_elementwise_max(va, -lim), lim);
                         vb = __builtin_elementwise_min(__builtin_elementwise_max(vb, -lim), lim);
@@ -798,15 +799,16 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
                     const hh2 hia = __builtin_convertvector(va, hh2), hib = __builtin_convertvector(vb, hh2);
                     const hh2 loa = __builtin_convertvector(va - __builtin_convertvector(hia, f2), hh2);
                     const hh2 lob = __builtin_convertvector(vb - __builtin_convertvector(hib, f2), hh2);
-                    const unsigned h0 = *reinterpret_cast<const unsigned*>(&hia), h1 = *reinterpret_cast<const unsigned*>(&hib);
-                    const unsigned l0 = *reinterpret_cast<const unsigned*>(&loa), l1 = *reinterpret_cast<const unsigned*>(&lob);
-                    // lanes 2j (couts 0-3) and 2j+1 (couts 4-7) hold the same pixel: the even lane stores the 16-byte hi word,
-                    // the odd lane the lo word
-                    const unsigned s0 = half ? h0 : l0, s1 = half ? h1 : l1;
-                    const unsigned r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
-                    const uint4 w = half ? make_uint4(r0, r1, l0, l1) : make_uint4(h0, h1, r0, r1);
+                    // lanes 2j (couts 0-3) and 2j+1 (couts 4-7) hold the same pixel: each stores its 8-byte half of the 16-byte
+                    // hi word and of the lo word (a wave store covers 32 pixels x 16 contiguous bytes per plane)
+                    const uint2 hw = make_uint2(*reinterpret_cast<const unsigned*>(&hia), *reinterpret_cast<const unsigned*>(&hib));
+                    const uint2 lw = make_uint2(*reinterpret_cast<const unsigned*>(&loa), *reinterpret_cast<const unsigned*>(&lob));
                     const int oy = 2 * (i0 + rp) + dy, ox = 2 * j0 + oc;
-                    if (live && oy < OH && ox < OW) d[(half ? oplane : 0) + (size_t)oy * OW + ox] = w;
+                    if (live && oy < OH && ox < OW) {
+                        uint2* d2 = reinterpret_cast<uint2*>(d + (size_t)oy * OW + ox) + half;
+                        d2[0] = hw;
+                        d2[2 * oplane] = lw;
+                    }
                 }
             }
         }
@@ -1067,7 +1069,8 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
         u.tiles_per_xcd = (u.ntiles + 7) / 8;
         u.clamp = clamp;
         ProfScope ps(R3D_PROF_UPCONV, st);
-        hipLaunchKernelGGL(upconv_fir_f16x3_kernel, dim3(8 * u.tiles_per_xcd * (Cout / 32), N), dim3(256), 0, st, u);
+        if (clamp >= 0.f) hipLaunchKernelGGL(upconv_fir_f16x3_kernel<true>, dim3(8 * u.tiles_per_xcd * (Cout / 32), N), dim3(256), 0, st, u);
+        else hipLaunchKernelGGL(upconv_fir_f16x3_kernel<false>, dim3(8 * u.tiles_per_xcd * (Cout / 32), N), dim3(256), 0, st, u);
     } else if (up) {
         // ---- conv0: stride-2 transposed conv as 4 phases -> T (demodulated, fp32), then FIR + bias + lrelu -> SPLIT ----
         {
