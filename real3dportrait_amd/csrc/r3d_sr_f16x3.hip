@@ -7,14 +7,19 @@
 //
 // Dataflow.  Activations travel between kernels already multiplied by the consumer's style vector and already
 // split: "SPLIT" format = two planes [C/8][H][W][8 halfs] (hi plane, lo plane; same bytes as fp32).  The producer
-// (input conversion, the FIR kernel, the previous conv's epilogue) does the scale + split once per element;
-// the conv kernel's halo-patch staging is then a pure 16-byte copy global -> registers -> LDS, prefetched one
-// stage ahead under the MFMAs.  Weights are split once at prepack time ([tap][ci/8][cout][8 hi | 8 lo]) and
-// stream from L2 into A-operand registers one tap ahead.  Epilogue: demodulation * acc + bias -> lrelu*sqrt2
-// (+clamp) -> any of {fp32 channel-blocked, SPLIT scaled by the next layer's styles} + the block's toRGB partial
-// sums (128 couts per block) so the 134 MB activation of the last layer never goes to HBM.
+// (input conversion, the up-sampling conv's epilogue, the previous conv's epilogue) does the scale + split once per
+// element.  Weights are split once at prepack time.  Every operand byte reaches LDS by LDS-DMA (global_load_lds_dwordx4
+// from per-lane addresses, inline asm): no staging VGPRs, no ds_write, loads of stage s+1 in flight during stage s.
 //
-// Block = 128 couts x (16x16) pixels, 4 waves of 64 couts x 128 pixels (2x4 MFMA tiles, 128 accumulators).
+// Kernels.
+//   conv_mfma_f16x3_kernel    plain 3x3 conv (conv3x3_dma_block): 128 couts x 16x16 px per block, 8 waves x (64 x 64),
+//                             double-buffered patch, two-tap weight sub-stages, one barrier per sub-stage; epilogue =
+//                             demodulation * acc + bias -> lrelu*sqrt2 (+clamp) -> {fp32 CB8, fp32 NCHW, SPLIT} + toRGB partials
+//   upconv_fir_f16x3_kernel   up=2 layers: transposed conv (4 output phases) + FIR 4x4 + bias + lrelu + split, fused;
+//                             32 couts x 16x16 grid x 4 phases per block, the fp32 T never leaves the CU
+//   conv1x1_mfma_f16x3_kernel / tconv_mfma_f16x3_kernel (conv2_block): 1x1 convs of the fusion stacks; the per-phase
+//                             transposed conv is kept behind R3D_UPCONV=0 for A/B runs with fir_bias_act_split_kernel
+//   to_split / upsample2x_bilinear / rgb_finalize / prepack kernels: layout and glue
 // Behaviour restated from modules/eg3ds/models/networks_stylegan2.py:37-94,286-373,429-473 and
 // modules/eg3ds/torch_utils/ops/{conv2d_resample.py:116-133, upfirdn2d.py:171-215,317-354, bias_act.py:93-122}.
 #include <stdlib.h>
