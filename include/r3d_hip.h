@@ -169,6 +169,14 @@ int r3d_conv_forward(const void* prepacked, int N, int Cin, int Cout, int H, int
                      void* y, int y_format, const float* next_scale, size_t next_scale_stride,
                      void* workspace, size_t workspace_bytes, r3d_stream_t stream);
 
+/* Alpha / occlusion blend + channel concatenation, emitted as the SPLIT input of the next conv:
+ *   y = cat([a * mask, b * (1 - mask)], dim=1),  a [N,Ca,H,W], b [N,Cb,H,W] (NCHW or CB8 fp32), mask [N,1,H,W]
+ * replaces `torch.cat([x * head_torso_alpha, x_torso * (1 - head_torso_alpha)], dim=1)` and the person_occlusion / x_bg
+ * twin in SuperresolutionHybrid8XDC_Warp.forward (modules/real3d/super_resolution/sr_with_ref.py:104,114,126,136).
+ * y_split: [N][hi|lo][(Ca+Cb)/8][H][W][8] halfs.  Ca % 8 == Cb % 8 == 0, (Ca + Cb) % 16 == 0. */
+int r3d_blend_cat_to_split(const float* a, int a_format, int Ca, const float* b, int b_format, int Cb, const float* mask,
+                           int N, int H, int W, void* y_split, r3d_stream_t stream);
+
 /* torch.nn.UpsamplingBilinear2d(scale_factor=2) (align_corners=True), the resampling step inside to_plane_cnn
  * (modules/real3d/segformer.py:691-700), between two r3d_conv_forward layers: x fp32 channel-blocked [N,C/8,H,W,8] ->
  * y at 2H x 2W in R3D_FMT_CB8 or R3D_FMT_SPLIT (scaled by next_scale, NULL = 1).  C % 8 == 0. */

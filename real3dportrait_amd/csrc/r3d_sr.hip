@@ -618,3 +618,16 @@ extern "C" int r3d_upsample2x_bilinear(const float* x_cb8, int N, int C, int H, 
     if (y_format != R3D_FMT_CB8 && y_format != R3D_FMT_SPLIT) { set_error("upsample2x_bilinear: y_format %d must be CB8 or SPLIT", y_format); return R3D_ERR_INVALID_ARG; }
     return upsample2x_bilinear_f16x3(x_cb8, N, C, H, W, y, y_format, next_scale, next_scale_stride, (hipStream_t)stream);
 }
+
+extern "C" int r3d_blend_cat_to_split(const float* a, int a_format, int Ca, const float* b, int b_format, int Cb, const float* mask,
+                                      int N, int H, int W, void* y_split, r3d_stream_t stream)
+{
+    using namespace r3d;
+    if (!a || !b || !mask || !y_split || N <= 0 || H <= 0 || W <= 0 || Ca <= 0 || Cb <= 0 || (Ca & 7) || (Cb & 7) || ((Ca + Cb) & 15)) {
+        set_error("blend_cat_to_split: bad argument (Ca %d, Cb %d: multiples of 8, sum a multiple of 16)", Ca, Cb); return R3D_ERR_INVALID_ARG;
+    }
+    if ((a_format != R3D_FMT_NCHW && a_format != R3D_FMT_CB8) || (b_format != R3D_FMT_NCHW && b_format != R3D_FMT_CB8)) {
+        set_error("blend_cat_to_split: inputs must be NCHW or CB8 (a %d, b %d)", a_format, b_format); return R3D_ERR_INVALID_ARG;
+    }
+    return blend_cat_to_split_f16x3(a, a_format, Ca, b, b_format, Cb, mask, N, H, W, y_split, (hipStream_t)stream);
+}

@@ -943,6 +943,52 @@ __global__ void cb8_to_nchw2_kernel(const float* __restrict__ src, float* __rest
     d[(size_t)4 * HW] = b.x; d[(size_t)5 * HW] = b.y; d[(size_t)6 * HW] = b.z; d[(size_t)7 * HW] = b.w;
 }
 
+// ---- alpha / occlusion blend + channel concatenation as the input conversion of the next conv --------------------------
+// y = cat([a * m, b * (1 - m)], dim=1) with a per-pixel mask m [N,1,H,W]: the `x = torch.cat([x * head_torso_alpha,
+// x_torso * (1 - head_torso_alpha)], dim=1)` and `torch.cat([x * person_occlusion, x_bg * (1 - person_occlusion)])` steps of
+// SuperresolutionHybrid8XDC_Warp.forward (modules/real3d/super_resolution/sr_with_ref.py:104,114,126,136), written
+// directly in the SPLIT format of fuse_head_torso_convs / fuse_fg_bg_convs' first conv (no fp32 concat tensor).
+// blockIdx.y < Ca/8: channels of a (scaled by m); else channels of b (scaled by 1 - m).
+__global__ void blend_cat_to_split_kernel(const float* __restrict__ a, int a_cb8, int Ca, const float* __restrict__ b, int b_cb8, int Cb,
+                                          const float* __restrict__ mask, uint4* __restrict__ dst, int HW)
+{
+    const int n = blockIdx.z, cb = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    const bool first = cb < Ca / 8;
+    const float* src = first ? a : b;
+    const int C = first ? Ca : Cb, c8 = first ? cb : cb - Ca / 8, cb8 = first ? a_cb8 : b_cb8;
+    const float m = mask[(size_t)n * HW + p];
+    const float sc = first ? m : 1.0f - m;
+    float v[8];
+    if (cb8) {
+        const float4* s4 = reinterpret_cast<const float4*>(src + (((size_t)n * (C / 8) + c8) * HW + p) * 8);
+        const float4 x0 = s4[0], x1 = s4[1];
+        v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+    } else {
+        const float* s1 = src + ((size_t)n * C + c8 * 8) * HW + p;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = s1[(size_t)c * HW];
+    }
+    h8 hi, lo;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { _Float16 x0, x1; split1(v[c] * sc, x0, x1); hi[c] = x0; lo[c] = x1; }
+    const size_t plane = (size_t)((Ca + Cb) / 8) * HW;
+    uint4* d = dst + (size_t)n * 2 * plane + (size_t)cb * HW + p;
+    d[0] = *reinterpret_cast<uint4*>(&hi);
+    d[plane] = *reinterpret_cast<uint4*>(&lo);
+}
+
+int blend_cat_to_split_f16x3(const float* a, int a_format, int Ca, const float* b, int b_format, int Cb, const float* mask,
+                             int N, int H, int W, void* y_split, hipStream_t st)
+{
+    ProfScope ps(R3D_PROF_LAYOUT, st);
+    hipLaunchKernelGGL(blend_cat_to_split_kernel, dim3((H * W + 255) / 256, (Ca + Cb) / 8, N), dim3(256), 0, st,
+                       a, a_format == R3D_FMT_CB8 ? 1 : 0, Ca, b, b_format == R3D_FMT_CB8 ? 1 : 0, Cb, mask,
+                       reinterpret_cast<uint4*>(y_split), H * W);
+    return check_launch("blend_cat_to_split");
+}
+
 // ---- torch.nn.UpsamplingBilinear2d(scale_factor=2) (align_corners=True) between two conv layers of to_plane_cnn
 // (modules/real3d/segformer.py:691-700): fp32 channel-blocked in -> SPLIT (or fp32 channel-blocked) out at 2H x 2W.
 // Source index = dst * (in - 1) / (out - 1), lambda in fp32, as ATen's upsample_bilinear2d (area_pixel_compute_scale).

@@ -275,6 +275,29 @@ def upsample2x_bilinear(x, out_format="split"):
     return y
 
 
+def blend_cat(a, b, mask):
+    """cat([a * mask, b * (1 - mask)], dim=1) (sr_with_ref.py:104,114,126,136) written directly as the SPLIT input of the
+    next Conv2d / ConvStack (r3d_blend_cat_to_split).  a, b: NCHW fp32 or 'cb8'-tagged tensors; mask [N,1,H,W]."""
+    lib = _lib.load()
+
+    def desc(t):
+        fmt = getattr(t, "_r3d_fmt", "nchw")
+        assert fmt in ("nchw", "cb8"), fmt
+        t = _f32c(t)
+        if fmt == "nchw":
+            return t, 0, t.shape[1], t.shape[0], t.shape[2], t.shape[3]
+        return t, 1, t.shape[1] * 8, t.shape[0], t.shape[2], t.shape[3]
+    a, fa, Ca, N, H, W = desc(a)
+    b, fb, Cb, Nb, Hb, Wb = desc(b)
+    mask = _f32c(mask)
+    assert (N, H, W) == (Nb, Hb, Wb) and tuple(mask.shape) == (N, 1, H, W), (a.shape, b.shape, mask.shape)
+    y = torch.empty(N, 2, (Ca + Cb) // 8, H, W, 8, device=a.device, dtype=torch.float16)
+    _lib.check(lib.r3d_blend_cat_to_split(_lib.ptr(a), fa, Ca, _lib.ptr(b), fb, Cb, _lib.ptr(mask), N, H, W, _lib.ptr(y),
+                                          _lib.stream_ptr()), "blend_cat_to_split")
+    y._r3d_fmt = "split"
+    return y
+
+
 class ConvStack(nn.Sequential):
     """An nn.Sequential of Conv2d / LeakyReLU [/ UpsamplingBilinear2d(2)] modules (the shape of torso_encoder, bg_encoder,
     fuse_head_torso_convs, fuse_fg_bg_convs, sr_with_ref.py:24-63, and of SegFormerSECC2PlaneBackbone.to_plane_cnn,

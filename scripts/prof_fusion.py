@@ -4,7 +4,7 @@ import numpy as np
 import torch
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from real3dportrait_amd import synth
-from real3dportrait_amd.superresolution import Conv2d, ConvStack, SynthesisBlockNoUp
+from real3dportrait_amd.superresolution import Conv2d, ConvStack, SynthesisBlockNoUp, blend_cat
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 R = 256
@@ -29,9 +29,9 @@ def step():
     x_torso = stacks["torso_encoder"](hid)
     x_bg = stacks["bg_encoder"](bg)
     rgb1 = rgb * alpha + rgb_t * (1 - alpha)
-    x1 = stacks["fuse_head_torso_convs"](torch.cat([x_head * alpha, x_torso * (1 - alpha)], dim=1))
+    x1 = stacks["fuse_head_torso_convs"](blend_cat(x_head, x_torso, alpha))
     x2, rgb2 = blk(x1, rgb1, ws, noise_mode="none")
-    return stacks["fuse_fg_bg_convs"](torch.cat([x2 * occ, x_bg * (1 - occ)], dim=1)), rgb2
+    return stacks["fuse_fg_bg_convs"](blend_cat(x2, x_bg, occ)), rgb2
 
 
 for _ in range(3):
