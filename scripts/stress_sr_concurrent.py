@@ -19,7 +19,8 @@ shells = [shell() for _ in range(NS)]; streams = [torch.cuda.Stream() for _ in r
 for s in shells: s(rgb, x, ws, noise_mode="none")
 torch.cuda.synchronize()
 bad = 0; worst = 0.0; npx = 0
-for it in range(20):
+ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+for it in range(ITERS):
     outs = []
     for s, st in zip(shells, streams):
         with torch.cuda.stream(st):
@@ -34,4 +35,4 @@ for it in range(20):
                 tiles = collections.Counter((int(c), int(y) // 16, int(xx) // 16) for c, y, xx in idx.tolist())
                 print("  diff #%d: %d values; (channel, tile_y, tile_x) -> count:" % (bad, len(idx)), sorted(tiles.items())[:12])
                 rows = collections.Counter((int(c), int(y)) for c, y, xx in idx.tolist()); print("   rows per (c,y):", sorted(rows.items())[:10])
-print("SR concurrent on %d streams: %d / %d outputs differ, worst abs diff %.4g, differing values %d" % (NS, bad, 20 * NS, worst, npx))
+print("SR concurrent on %d streams: %d / %d outputs differ, worst abs diff %.4g, differing values %d" % (NS, bad, ITERS * NS, worst, npx))
