@@ -121,7 +121,9 @@ def patch_model(model):
     * model.renderer     -> ImportanceRenderer    (img2plane_baseline.py:104-105 / triplane.py:36-37)
     * model.superresolution (vanilla SuperresolutionHybrid8XDC) -> HIP SuperresolutionHybrid8XDC, or, for the
       torso model whose superresolution is SuperresolutionHybrid8XDC_Warp (secc_img2plane_torso.py:10-11),
-      only its .block0 / .block1 (called at sr_with_ref.py:83,124 as block(x, img, ws, **kw) -> (x, img)).
+      its .block0 / .block1 (called at sr_with_ref.py:83,124 as block(x, img, ws, **kw) -> (x, img)), its torso / background
+      fusion stacks (nn.Sequential -> ConvStack, :24-63) and head_torso_block (-> SynthesisBlockNoUp).
+    * <backbone>.to_plane_cnn (segformer.py:691-700) -> ConvStack.
     Parameters are copied with strict key matching; the decoder module is left untouched (the renderer reads
     decoder.net[0|2].{weight,bias} directly)."""
     dev = next(model.parameters()).device
@@ -146,4 +148,35 @@ def patch_model(model):
                                  conv_clamp=old.conv1.conv_clamp).to(dev)
             new.load_state_dict(old.state_dict(), strict=True)
             setattr(sr, name, new)
+        _patch_fusion_stacks(sr, dev)
+    for owner in (getattr(model, "secc_img2plane_backbone", None), getattr(model, "img2plane_backbone", None)):
+        _patch_sequential(owner, "to_plane_cnn", dev)       # per-frame plane producer tail (segformer.py:691-700)
     return model
+
+
+def _patch_sequential(owner, name, dev):
+    """owner.<name>: nn.Sequential of Conv2d / LeakyReLU / UpsamplingBilinear2d(2) -> ConvStack (same state_dict keys, NCHW in
+    and out, so the surrounding reference code is unchanged).  Stacks the HIP conv does not cover are left alone."""
+    from .superresolution import ConvStack
+    seq = getattr(owner, name, None) if owner is not None else None
+    if seq is None or type(seq).__name__ != "Sequential":
+        return False
+    try:
+        setattr(owner, name, ConvStack.from_torch(seq).to(dev))
+    except NotImplementedError:
+        return False
+    return True
+
+
+def _patch_fusion_stacks(sr, dev):
+    """SuperresolutionHybrid8XDC_Warp (sr_with_ref.py:24-63): the torso / background fusion stacks and head_torso_block."""
+    from .superresolution import SynthesisBlockNoUp
+    for name in ("torso_encoder", "bg_encoder", "fuse_head_torso_convs", "fuse_fg_bg_convs"):
+        _patch_sequential(sr, name, dev)
+    old = getattr(sr, "head_torso_block", None)
+    if old is not None and type(old).__name__ == "SynthesisBlockNoUp":
+        new = SynthesisBlockNoUp(old.in_channels, old.conv1.out_channels, w_dim=old.w_dim, resolution=old.resolution,
+                                 img_channels=old.img_channels, is_last=old.is_last, use_fp16=False,
+                                 conv_clamp=old.conv1.conv_clamp).to(dev)
+        new.load_state_dict(old.state_dict(), strict=True)
+        sr.head_torso_block = new

@@ -89,6 +89,42 @@ def test_noup_block_keys_match_reference():
     assert {k: tuple(v.shape) for k, v in a.items()} == {k: tuple(v.shape) for k, v in b.items()}
 
 
+def test_patch_model_converts_fusion_stacks_of_a_warp_sr():
+    """patch_model on a model whose superresolution has the SuperresolutionHybrid8XDC_Warp attributes (sr_with_ref.py:24-63):
+    Sequential stacks -> ConvStack (keys preserved), unsupported stacks (the 1-channel alpha predictor) left untouched."""
+    from real3dportrait_amd import patch_model
+    from real3dportrait_amd.superresolution import ConvStack
+    nn = torch.nn
+
+    class WarpSR(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.torso_encoder = nn.Sequential(nn.Conv2d(64, 256, 1, 1, padding=0))
+            self.fuse_fg_bg_convs = nn.Sequential(nn.Conv2d(512, 64, 1, 1, padding=0), nn.LeakyReLU(), nn.Conv2d(64, 256, 3, 1, padding=1))
+            self.head_torso_alpha_predictor = nn.Sequential(nn.Conv2d(7, 32, 3, 1, padding=1), nn.LeakyReLU(), nn.Conv2d(32, 1, 3, 1, padding=1), nn.Sigmoid())
+
+    class Backbone(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.to_plane_cnn = nn.Sequential(nn.Conv2d(256, 256, 3, 1, padding=1), nn.LeakyReLU(0.01, inplace=True),
+                                              nn.UpsamplingBilinear2d(scale_factor=2.), nn.Conv2d(256, 96, 3, 1, padding=1))
+
+    class Model(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.renderer = nn.Identity(); self.ray_sampler = nn.Identity()
+            self.superresolution = WarpSR(); self.secc_img2plane_backbone = Backbone()
+            self.p = nn.Parameter(torch.zeros(1))
+    m = Model()
+    keys = {k: v.clone() for k, v in m.state_dict().items()}
+    patch_model(m)
+    assert isinstance(m.superresolution.torso_encoder, ConvStack) and isinstance(m.superresolution.fuse_fg_bg_convs, ConvStack)
+    assert isinstance(m.secc_img2plane_backbone.to_plane_cnn, ConvStack)
+    assert type(m.superresolution.head_torso_alpha_predictor).__name__ == "Sequential"       # Cout = 1: not covered, untouched
+    after = m.state_dict()
+    assert set(after) == set(keys) and all(torch.equal(after[k], keys[k]) for k in keys)
+
+
 def test_operators_refuse_cpu_tensors_and_bad_options():
     from real3dportrait_amd import ImportanceRenderer, RaySampler
     with pytest.raises(AssertionError):
