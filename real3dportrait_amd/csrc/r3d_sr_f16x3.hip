@@ -733,10 +733,23 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
     const int OH = 2 * a.H, OW = 2 * a.W;
     const size_t oplane = (size_t)(a.Cout >> 3) * OH * OW;
     const float c0 = 0.25f, c1 = 0.75f;                             // [1,3,3,1]/8 * 2 per axis (gain 4 in 2-D)
+    // all per-cout vectors of the four slices in one batch of loads, waited for ONCE here: loaded inside the slice loop,
+    // hipcc re-waited with s_waitcnt vmcnt(0) in front of every conditional store group (loads and stores share vmcnt), which
+    // serialised the epilogue on store latency
+    float4 dv4[4], bv4[4], nv4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        dv4[g] = *reinterpret_cast<const float4*>(D + 8 * g + 4 * h);
+        bv4[g] = *reinterpret_cast<const float4*>(Bv + 8 * g + 4 * (tid & 1));
+        nv4[g] = *reinterpret_cast<const float4*>(NS + 8 * g + 4 * (tid & 1));
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        asm volatile("" :: "v"(dv4[g].x), "v"(dv4[g].w), "v"(bv4[g].x), "v"(bv4[g].w), "v"(nv4[g].x), "v"(nv4[g].w));
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         if (g == 0) __syncthreads();                                // the main loop's LDS reads are done
-        const float4 d4 = *reinterpret_cast<const float4*>(D + 8 * g + 4 * h);
+        const float4 d4 = dv4[g];
 #pragma unroll
         for (int p = 0; p < 4; ++p)
 #pragma unroll
@@ -769,8 +782,7 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
         }
         __syncthreads();
         {   // vertical: item (row pair rp, column oc, half): H rows 2rp+1 .. 2rp+5 -> y rows 2rp, 2rp+1 (4 couts each)
-            const float4 b4 = *reinterpret_cast<const float4*>(Bv + 8 * g + 4 * (tid & 1));
-            const float4 n4 = *reinterpret_cast<const float4*>(NS + 8 * g + 4 * (tid & 1));
+            const float4 b4 = bv4[g], n4 = nv4[g];
             const f2 ba = f2{b4.x, b4.y}, bb = f2{b4.z, b4.w};
             const float m = 1.4142135623730951f;
             const f2 ma = f2{n4.x, n4.y} * m, mb = f2{n4.z, n4.w} * m;
