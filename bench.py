@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("R3D_BENCH_STREAMS", "3")),
                     help="HIP streams that consecutive frames are issued on (frames are independent)")
+    ap.add_argument("--clip", type=int, default=0,
+                    help="strong-scaling mode (BASELINE config 3): render ONE clip of this many frames, frame-sharded over the ranks "
+                         "(uneven tail), gathered to rank 0 inside the timed region; --steps is ignored")
     return ap.parse_args()
 
 
@@ -106,6 +109,92 @@ def cpu_baseline(seed=7):
             "sample": sample}
 
 
+def cpu_baseline_reference():
+    """The REFERENCE's own PyTorch CPU renderer + SR on the same frame (scripts/time_reference_cpu.py).  It can only run where the
+    reference checkout exists (the build container, not the GPU box), so the committed measurement is reported, with where / when /
+    how many cores stated -- next to `cpu_baseline` (the C port timed on THIS box in THIS run)."""
+    path = os.path.join(ROOT, "profiles", "cpu_reference_r02.json")
+    try:
+        r = json.load(open(path))
+    except Exception:
+        return None
+    return {"value": round(r["value"], 4), "unit": r["unit"], "cores": r["cores"], "kind": "reference",
+            "sample": "1 full frame: reference ImportanceRenderer.forward R=128 48+48 (%.2fs) + SuperresolutionHybrid8XDC.forward "
+                      "128^2->512^2 (%.2fs), torch %s CPU" % (r["render_s"], r["sr_s"], r["torch"]),
+            "measured": "%s, %s, %d cores; committed as profiles/cpu_reference_r02.json (the GPU box has no reference checkout)"
+                        % (r["where"], r["when"], r["cores"])}
+
+
+def build_torso_frame(torch, dev, G, seed=7):
+    """BASELINE config 4 surrogate: everything real3d_infer.py:480-492 runs per frame with the shipped torso model that is on the
+    hot path -- to_plane_cnn (segformer.py:691-700) -> flips + cano add + layout -> rays -> fused ray kernel -> fused
+    SuperresolutionHybrid8XDC_Warp.forward (block0, torso/background fusion convs at 256^2, SynthesisBlockNoUp, block1) -> uint8.
+    The cold encoders in front (MiT SegFormer) and the face-vid2vid warp network are out of scope: their per-frame OUTPUTS are
+    synthetic tensors of the documented shapes (a stand-in torso_model returns them without computing)."""
+    import numpy as np
+    from real3dportrait_amd import synth
+    from real3dportrait_amd.sr_with_ref import SuperresolutionHybrid8XDC_Warp
+    from real3dportrait_amd.superresolution import Conv2d, ConvStack, const_bound
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    class StandInTorso(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.rgb_torso = T(synth.hash_unitvar(seed, (1, 3, 256, 256), stream=31) * np.float32(0.3))
+            self.ret = {"deformed_torso_hid": T(synth.hash_unitvar(seed, (1, 64, 256, 256), stream=32)),
+                        "occlusion_2": T(synth.synth_noise(seed, (1, 1, 64, 64), stream=33))}
+
+        def forward(self, *a, **k):
+            return self.rgb_torso, self.ret
+    sr = SuperresolutionHybrid8XDC_Warp(32, 512, 0, True, torso_model=StandInTorso()).to(dev).eval()
+    with torch.no_grad():
+        for blk, p in ((sr.block0, synth.synth_sr_block(seed, 32, 256, 512, 100)), (sr.block1, synth.synth_sr_block(seed, 256, 128, 512, 200)),
+                       (sr.head_torso_block, synth.synth_sr_block(seed, 256, 256, 512, 400))):
+            for name in ("conv0", "conv1", "torgb"):
+                l = getattr(blk, name); w, b, aw, ab = p[name]
+                l.weight.copy_(T(w)); l.bias.copy_(T(b)); l.affine.weight.copy_(T(aw)); l.affine.bias.copy_(T(ab))
+        for i, (name, plan) in enumerate(synth.FUSION_STACKS.items()):
+            for m, (w, b) in zip([m for m in getattr(sr, name) if hasattr(m, "weight")], synth.synth_conv_stack(seed, plan, 300 + 20 * i)):
+                m.weight.copy_(T(w)); m.bias.copy_(T(b))
+        mods = []
+        for i, ((ci, co, k, lrelu), (w, b)) in enumerate(zip(synth.TO_PLANE_CNN, synth.synth_conv_stack(seed, synth.TO_PLANE_CNN, 500))):
+            if i == synth.TO_PLANE_CNN_UP_BEFORE:
+                mods.append(torch.nn.UpsamplingBilinear2d(scale_factor=2.))
+            c = Conv2d(ci, co, k, 1, padding=1)
+            c.weight.copy_(torch.from_numpy(w)); c.bias.copy_(torch.from_numpy(b))
+            mods.append(c)
+            if lrelu:
+                mods.append(torch.nn.LeakyReLU(0.01))
+        cnn = ConvStack(*mods).to(dev)
+    feat = T(synth.hash_unitvar(seed, (1, 256, 128, 128), stream=41))          # fused SegFormer feature map (output of the cold encoder)
+    cano = T(synth.synth_planes(seed, N=1))
+    ref_torso, ref_bg = T(synth.hash_unitvar(seed, (1, 3, 512, 512), stream=42) * np.float32(0.5)), T(synth.hash_unitvar(seed, (1, 3, 512, 512), stream=43) * np.float32(0.5))
+    cams = T(synth.camera_sweep(8, -0.4, 0.4))
+    ws = torch.ones(1, 14, 512, device=dev)
+    G.renderer.noise_mode = "hash"
+
+    def frame(t):
+        raw = cnn(feat)                                                                            # [1,96,256,256], not flipped
+        planes = G.renderer.prepare_planes(cano, add=raw, add_flip=G.renderer.SECC_PLANE_FLIPS)
+        cam = cams[t % 8: t % 8 + 1]
+        o, d = G.ray_sampler(cam[:, :16].view(-1, 4, 4), cam[:, 16:25].view(-1, 3, 3), 128)
+        fe, depth, wsum, valid = G.renderer(planes, G.decoder, o, d, G.rendering_kwargs)
+        fimg = fe.permute(0, 2, 1).reshape(1, 32, 128, 128).contiguous()
+        fimg._r3d_bound = const_bound(1.01, 1, dev)
+        wimg = wsum.permute(0, 2, 1).reshape(1, 1, 128, 128).contiguous()
+        img, _ = sr(fimg[:, :3], fimg, ws, ref_torso, ref_bg, wimg, None, None, None, noise_mode="none")
+        return img
+    # algorithmic conv FLOPs of this frame (2 * taps * Cin * Cout * pixels): to_plane_cnn + SR blocks + fusion stacks + NoUp block
+    px = 256 * 256
+    fl = 3 * 2 * 9 * 256 * 256 * 128 * 128 + 2 * 9 * 256 * 96 * px                                 # to_plane_cnn
+    fl += sum(conv_flops_per_frame(128))                                                           # block0 + block1
+    fl += 2 * 64 * 256 * px                                                                        # torso_encoder (1x1)
+    fl += 2 * 9 * 512 * 256 * px + 2 * 9 * 256 * 256 * px                                          # fuse_head_torso_convs
+    fl += 2 * 2 * 9 * 256 * 256 * px                                                               # head_torso_block conv0 + conv1
+    fl += 2 * 512 * 64 * px + 2 * 9 * 64 * 256 * px + 2 * 9 * 256 * 256 * px                      # fuse_fg_bg_convs
+    return frame, fl
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "RANK" not in os.environ:      # convenience: self-launch one process per GPU
@@ -128,7 +217,15 @@ def main():
     lib = _lib.load()
 
     K, W = args.steps, args.warmup
-    G, clip, dec, scene = build_scene(torch, dev, n_frames=max(64, K * world))
+    from real3dportrait_amd.frames import shard_frames
+    clip_lo = 0
+    if args.clip > 0:                                    # strong scaling: this rank's contiguous chunk of ONE clip
+        clip_lo, clip_hi = shard_frames(args.clip, world, rank)
+        K = (args.clip + world - 1) // world             # ring slots per rank (the gather moves equal-sized rings)
+        K_mine = clip_hi - clip_lo
+    else:
+        K_mine = K
+    G, clip, dec, scene = build_scene(torch, dev, n_frames=max(64, K * world, args.clip))
     ring = torch.zeros(K, 512, 512, 3, dtype=torch.uint8, device=dev)
 
     pipe = None
@@ -138,7 +235,7 @@ def main():
         pipe = PipelinedClipRenderer(G, cano, residuals, cams, clip.ws, base_seed=clip.base_seed, n_streams=args.streams)
 
     def step(i):
-        t = rank * K + i
+        t = (clip_lo if args.clip > 0 else rank * K) + i
         (pipe or clip).render_u8(t, out=ring[i:i + 1])
 
     def barrier():
@@ -151,20 +248,21 @@ def main():
     if pipe is not None:
         pipe.sync()
     from real3dportrait_amd.frames import gather_frames
+    total_frames = args.clip if args.clip > 0 else K * world
     if use_dist:                                         # warm the gather path too
-        clip_out = gather_frames(ring, K * world)
+        clip_out = gather_frames(ring, total_frames)
     import ctypes
     lib.r3d_profile_configure(1 << 1); lib.r3d_profile_reset()      # event pairs around the dominant kernel, on its launch stream
     barrier()
     t0 = time.perf_counter()
-    for i in range(K):
+    for i in range(K_mine):
         step(i)
     if pipe is not None:
         pipe.sync()
     if use_dist:
-        clip_out = gather_frames(ring, K * world)
+        clip_out = gather_frames(ring, total_frames)
         if rank == 0:
-            assert clip_out.shape == (K * world, 512, 512, 3)
+            assert clip_out.shape == (total_frames, 512, 512, 3)
     barrier()
     elapsed = time.perf_counter() - t0
     lib.r3d_profile_configure(0)
@@ -200,7 +298,7 @@ def main():
     achieved_tf = dom_flops / (conv_ms_per_frame * 1e-3) / 1e12 if cnt.value else 0.0
     up_ms_per_frame = ums.value / max(1, ucnt.value) * 2
     up_tf = (flops[0] + flops[2]) / (up_ms_per_frame * 1e-3) / 1e12 if (ucnt.value and prec != "f32") else None
-    traffic = None
+    traffic = None                                       # HBM bytes per launch from the PMC passes of scripts/gpu_profile.sh (committed, not re-measured here)
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
@@ -213,7 +311,8 @@ def main():
         kname, peak, products = "conv_mfma_f16x3_kernel", PEAK_F16_MFMA_TFLOPS, 3
     roofline = {"kernel": kname, "bound": "mfma", "achieved": round(achieved_tf, 2),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(achieved_tf / peak, 4),
-                "traffic": traffic, "launches_per_frame": launches,
+                "traffic": traffic, "traffic_source": "profiles/traffic.json (rocprofv3 --pmc passes, committed; not re-measured in this run)",
+                "launches_per_frame": launches,
                 "avg_launch_ms": round(ms.value / max(1, cnt.value), 4),
                 "avg_launch_ms_in_timed_region": round(in_region_ms, 4),
                 "algorithmic_gflop_per_launch": round(dom_flops / launches / 1e9, 3),
@@ -225,18 +324,33 @@ def main():
                                                "achieved": round(up_tf, 2), "frac": round(up_tf / peak, 4),
                                                "pipe_frac": round(up_tf * products / peak, 4)}
 
+    # ---- the same K frames on ONE stream (no frame pipelining), so that the gain of the multi-stream issue is visible ----
+    single_stream_fps = None
+    if args.streams > 1 and args.clip == 0:
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(K):
+            clip.render_u8(rank * K + i, out=ring[i:i + 1])
+        torch.cuda.synchronize()
+        single_stream_fps = K / (time.perf_counter() - t1)
+
     out = None
     if rank == 0:
-        fps = K * world / elapsed
+        fps = total_frames / elapsed
         out = {"metric": "rendered frames/sec @ 512x512, 48 depth samples", "value": round(fps, 2), "unit": "frames/s",
                "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 4),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "strong" if args.clip > 0 else "weak", "vs_baseline": None,
+               "dtype": "f32 (f16x3 split: fp32 operands as two fp16 terms, 3 MFMA products per MAC, fp32 accumulate)" if prec != "f32" else "f32",
+               "data": "synthetic",
                "config": {"workload": "ref_frame_512: TriPlaneGenerator.synthesis path, 1 frame/step/GPU: "
                                       "planes cano+residual [1,3,32,256,256] -> 128^2 rays x (48 coarse + 48 importance) "
                                       "-> SuperresolutionHybrid8XDC -> 512^2 uint8; clip gathered to rank 0",
                           "neural_rendering_resolution": 128, "depth_samples": "48+48", "final_resolution": 512,
-                          "frames_total": K * world, "streams_per_gpu": args.streams, "parallelism": "frame-sharded dp%d + gather" % world},
+                          "frames_total": total_frames, "streams_per_gpu": args.streams, "parallelism": "frame-sharded dp%d + gather" % world},
                "roofline": roofline}
+        if single_stream_fps is not None:
+            out["value_single_stream"] = round(single_stream_fps, 2)
+            out["stream_pipelining_gain"] = round(fps / world / single_stream_fps, 4)
 
     # ---- per-family breakdown + the literal 512^2 neural render (untimed extras, rank 0 of a 1-GPU run) -------
     if rank == 0 and world == 1 and not args.no_extras:
@@ -274,8 +388,39 @@ def main():
             alt["R512_48+%d_fps" % nf] = round(5 / (time.perf_counter() - t1), 2)
         out["alt_neural_render_512"] = alt
 
+    # ---- BASELINE config 4 surrogate: the per-frame hot path of the shipped torso model (extra, rank 0 of a 1-GPU run) ----
+    if rank == 0 and world == 1 and not args.no_extras:
+        frame, tf_flops = build_torso_frame(torch, dev, G)
+        for i in range(3):
+            frame(i)
+        torch.cuda.synchronize()
+        lib.r3d_profile_configure(0x7F); lib.r3d_profile_reset()
+        nb = 10
+        t1 = time.perf_counter()
+        for i in range(nb):
+            frame(i)
+        torch.cuda.synchronize()
+        t_frame = (time.perf_counter() - t1) / nb
+        bd2 = {}
+        for j, nme in enumerate(["render", "conv_mfma", "upconv_fir", "torgb", "sr_pack", "layout", "misc"]):
+            _lib.check(lib.r3d_profile_read(j, ctypes.byref(ms), ctypes.byref(cnt)), "profile_read")
+            bd2[nme] = round(ms.value / nb, 4)
+        lib.r3d_profile_configure(0)
+        conv_ms = bd2["conv_mfma"] + bd2["upconv_fir"]
+        out["torso_frame"] = {"what": "to_plane_cnn -> planes -> 128^2 rays x (48+48) -> fused SuperresolutionHybrid8XDC_Warp.forward (fuse mode v2) "
+                                      "-> 512^2; cold encoders and the face-vid2vid warp net replaced by synthetic outputs",
+                              "ms_per_frame": round(t_frame * 1e3, 4), "fps": round(1.0 / t_frame, 2),
+                              "breakdown_ms_per_frame": bd2, "conv_gflop_per_frame": round(tf_flops / 1e9, 1),
+                              "roofline": {"bound": "mfma", "achieved": round(tf_flops / (conv_ms * 1e-3) / 1e12, 2), "peak": PEAK_F16_MFMA_TFLOPS,
+                                           "unit": "TFLOP/s", "frac": round(tf_flops / (conv_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
+                                           "note": "all conv kernels of the frame (algorithmic FLOPs / summed conv time)"}}
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        ref = cpu_baseline_reference()
+        if ref is not None:
+            out["cpu_baseline_reference"] = ref
     if rank == 0:
         print(json.dumps(out))
     if use_dist:

@@ -123,6 +123,12 @@ int r3d_run_model(const float* planes_nhwc, int N, int H, int W, int triplane_de
  *   output it is scaled with `next_scale` ([N][Cout] floats, stride next_scale_stride: the next block's conv0 styles,
  *   i.e. the start of that block's styles buffer).
  *   clamp < 0 disables conv_clamp (the fp32 configuration Real3D uses, img2plane_baseline.py:102-104).
+ *   img_u8 (may be NULL; R3D_SR_F16X3 only): [N,OH,OW,3] uint8 -- the block is the last one of the network and the frame leaves
+ *   as clamp(-1,1) -> ((x + 1) / 2 * 255).int() (triplane.py:136 + inference/real3d_infer.py:472,518-522), fused into the
+ *   toRGB finalize kernel; img_out may then be NULL.
+ *   x_absmax (may be NULL; R3D_SR_F16X3 only): device float[N], atomically maxed with |x_out| (see r3d_chain_fold).
+ *   R3D_SR_F16X3 reads the FOLDED vectors of the styles buffer: call r3d_chain_fold (below) after r3d_sr_block_styles and
+ *   before r3d_sr_block_forward, every forward.
  *
  * precision: R3D_SR_F32   exact fp32 on v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain);
  *            R3D_SR_F16X3 fp32-accurate on the f16 matrix pipe: every operand is split x = hi + lo (two fp16
@@ -144,44 +150,100 @@ int r3d_sr_block_styles(const float* ws3, int N, int WD, int Cin, int Cout,
 int r3d_sr_block_forward(const void* prepacked, const void* styles, int N, int Cin, int Cout, int Hin, int Win, int up,
                          const void* x, int x_format, const float* img, float clamp,
                          void* x_out, int x_out_format, const float* next_scale, size_t next_scale_stride,
-                         float* img_out, int precision,
+                         float* img_out, uint8_t* img_u8, float* x_absmax, int precision,
                          void* workspace, size_t workspace_bytes, r3d_stream_t stream);
+
+/* --- fp16 range management of the R3D_SR_F16X3 path ----------------------------------------------------------------
+ * The reference runs these layers in fp32 with conv_clamp=None (no range limit).  The f16x3 kernels keep fp32 accuracy while a
+ * stored fp16 operand tensor has rms >= 2^-3 and max < 65504, so every operand is stored times an exact power of two:
+ * weight rows at prepack time (max|w[co]| -> [2^10, 2^11)), activations per sample from a guaranteed bound B >= max|x| that is
+ * propagated layer to layer (B_out = gain * max_co(|b[co]| + d[co] * sum|w[co] * s| * B_in)); the factors are taken out again in
+ * the fp32 epilogue.  r3d_chain_fold walks a chain of layers ON THE DEVICE (one launch, no host sync) and writes each layer's
+ * folded multipliers: SR blocks into their styles buffer, plain convs into their `scales` buffer (r3d_conv_scales_bytes).
+ *   src_a / src_b: where the layer's input bound comes from: k >= 0 = output bound of op k (k < this op's index);
+ *   -1 - j = ext_bounds[j] (device float[N]: a measured r3d_absmax result, a previous chain's bound, or a constant);
+ *   R3D_CHAIN_SRC_NONE = unused.  Two sources = a concatenation / blend of two tensors (r3d_blend_cat_to_split): the max.
+ * The bound loosens ~5 binades per layer (10 binades of slack remain after one layer): re-measure (r3d_absmax on an fp32 tensor)
+ * after at most 3 chained layers.  r3d_*_bound_offset: float offset, within one sample's buffer, of the op's output bound.
+ * Measuring without an extra pass: r3d_sr_block_forward / r3d_conv_forward take `y_absmax` (device float[N] or NULL): the conv
+ * epilogue then atomically maxes |y| into it; the slot must be zero beforehand -- pass it in `zero_slots` of the r3d_chain_fold
+ * launch that precedes the producer (up to R3D_CHAIN_MAX_ZERO slots of N floats each are cleared by the fold kernel). */
+#define R3D_CHAIN_MAX_ZERO 4
+#define R3D_CHAIN_MAX_OPS 12
+#define R3D_CHAIN_MAX_EXT 4
+#define R3D_CHAIN_SRC_NONE (-1000)
+enum r3d_chain_kind {
+    R3D_CHAIN_SR_BLOCK = 0,       /* both layers of an SR block from the bound of the block input */
+    R3D_CHAIN_CONV = 1,           /* a plain conv layer */
+    R3D_CHAIN_SR_BLOCK_TAIL = 2   /* re-fold only the block's second layer (conv1 operand) from a MEASURED max|block input|: the
+                                     block's input was already written with the multipliers of an earlier R3D_CHAIN_SR_BLOCK fold */
+};
+typedef struct r3d_chain_op {
+    int kind;                 /* r3d_chain_kind */
+    int Cin, Cout, ksize;     /* ksize: R3D_CHAIN_CONV only */
+    int act;                  /* R3D_CHAIN_CONV: activation after the bias (|act(t)| <= gain * |t|); SR blocks always activate */
+    float gain, clamp;        /* act gain (sqrt(2) for SR blocks); clamp < 0: off */
+    int src_a, src_b;
+    void* scales;             /* SR block: styles buffer (r3d_sr_block_styles).  conv: r3d_conv_scales_bytes() buffer */
+    const void* prepacked;    /* conv: r3d_conv_prepack buffer (its tail holds 2^-kw[co] and sum|w[co]|) */
+    const float* bias;        /* conv: [Cout] or NULL */
+} r3d_chain_op;
+int r3d_chain_fold(const r3d_chain_op* ops, int nops, int N, const float* const* ext_bounds, int n_ext,
+                   float* const* zero_slots, int n_zero, r3d_stream_t stream);
+size_t r3d_sr_block_bound_offset(int Cin, int Cout);
+size_t r3d_conv_scales_bound_offset(int Cin, int Cout);
+/* out[n] = max |x[n, :]| over count_per_sample floats.  `out` (float[N]) must be zero on entry; zero_next (float[N], may be NULL)
+ * is cleared by the same launch so that two alternating slots need no memset. */
+int r3d_absmax(const float* x, size_t count_per_sample, int N, float* out, float* zero_next, r3d_stream_t stream);
 
 /* --- plain convolution layers around the SR blocks --------------------------------------
  * replaces torch.nn.Conv2d(Cin, Cout, k, 1, padding=k//2) [+ torch.nn.LeakyReLU] as used by the torso / background
  * fusion stacks of SuperresolutionHybrid8XDC_Warp (modules/real3d/super_resolution/sr_with_ref.py:24-63:
- * torso_encoder, bg_encoder, fuse_head_torso_convs, fuse_fg_bg_convs), on the f16x3 convolution kernel of the SR
- * blocks (fp32-accurate, see r3d_sr_precision).
- *   y = act(out_scale[co] * conv_k(in_scale[ci] * x, W) + bias[co]),  act(t) = (t < 0 ? act_slope * t : t) * act_gain
- *   when act != 0, then clamp to +-clamp when clamp >= 0.  in_scale / out_scale / bias may be NULL (1, 1, 0); each
- *   is [N][C] floats with the given per-sample stride (stride 0 = shared by the batch), 16-byte aligned.
- *   ksize 1 | 3.  weight [Cout,Cin,k,k] fp32 (torch layout).  Cout % 4 == 0.
+ * torso_encoder, bg_encoder, fuse_head_torso_convs, fuse_fg_bg_convs) and by to_plane_cnn (modules/real3d/segformer.py:691-700),
+ * on the f16x3 convolution kernel of the SR blocks (fp32-accurate, see r3d_sr_precision).
+ *   y = act(conv_k(x, W) + bias[co]),  act(t) = (t < 0 ? act_slope * t : t) * act_gain when act != 0, then clamp to +-clamp
+ *   when clamp >= 0.  ksize 1 | 3.  weight [Cout,Cin,k,k] fp32 (torch layout).  Cout % 4 == 0.  bias [Cout] or NULL.
+ *   scales: this layer's r3d_conv_scales_bytes() buffer, filled by r3d_chain_fold for this forward.
  *   x / y formats as for the SR blocks; blocked formats (CB8, SPLIT) need Cin % 16 == 0 / Cout % 8 == 0, NCHW takes
- *   any Cin (zero padded to 16 inside).  A SPLIT y is scaled by next_scale (NULL = 1) for the consumer.
+ *   any Cin (zero padded to 16 inside).  A SPLIT x must have been written with this layer's in-multiplier (the start of
+ *   `scales`); a SPLIT y is multiplied by next_scale = the CONSUMER's in-multiplier vector (start of its scales / styles
+ *   buffer, already folded), NULL = 1.
  *   workspace (r3d_conv_workspace_bytes) is only used for non-SPLIT inputs. */
 size_t r3d_conv_prepacked_bytes(int Cin, int Cout, int ksize);
 size_t r3d_conv_workspace_bytes(int N, int Cin, int H, int W);
+size_t r3d_conv_scales_bytes(int N, int Cin, int Cout);
 int r3d_conv_prepack(const float* weight, int Cin, int Cout, int ksize, void* prepacked, r3d_stream_t stream);
-int r3d_conv_forward(const void* prepacked, int N, int Cin, int Cout, int H, int W, int ksize,
-                     const void* x, int x_format, const float* in_scale, size_t in_scale_stride,
-                     const float* out_scale, size_t out_scale_stride, const float* bias, size_t bias_stride,
-                     int act, float act_slope, float act_gain, float clamp,
-                     void* y, int y_format, const float* next_scale, size_t next_scale_stride,
+int r3d_conv_forward(const void* prepacked, const void* scales, const float* bias,
+                     int N, int Cin, int Cout, int H, int W, int ksize,
+                     const void* x, int x_format, int act, float act_slope, float act_gain, float clamp,
+                     void* y, int y_format, const float* next_scale, size_t next_scale_stride, float* y_absmax,
                      void* workspace, size_t workspace_bytes, r3d_stream_t stream);
 
 /* Alpha / occlusion blend + channel concatenation, emitted as the SPLIT input of the next conv:
  *   y = cat([a * mask, b * (1 - mask)], dim=1),  a [N,Ca,H,W], b [N,Cb,H,W] (NCHW or CB8 fp32), mask [N,1,H,W]
  * replaces `torch.cat([x * head_torso_alpha, x_torso * (1 - head_torso_alpha)], dim=1)` and the person_occlusion / x_bg
  * twin in SuperresolutionHybrid8XDC_Warp.forward (modules/real3d/super_resolution/sr_with_ref.py:104,114,126,136).
- * y_split: [N][hi|lo][(Ca+Cb)/8][H][W][8] halfs.  Ca % 8 == Cb % 8 == 0, (Ca + Cb) % 16 == 0. */
+ * y_split: [N][hi|lo][(Ca+Cb)/8][H][W][8] halfs, multiplied by next_scale ([N][Ca+Cb], the consumer's in-multiplier; NULL = 1).
+ * Ca % 8 == Cb % 8 == 0, (Ca + Cb) % 16 == 0. */
 int r3d_blend_cat_to_split(const float* a, int a_format, int Ca, const float* b, int b_format, int Cb, const float* mask,
-                           int N, int H, int W, void* y_split, r3d_stream_t stream);
+                           int N, int H, int W, void* y_split, const float* next_scale, size_t next_scale_stride,
+                           r3d_stream_t stream);
 
 /* torch.nn.UpsamplingBilinear2d(scale_factor=2) (align_corners=True), the resampling step inside to_plane_cnn
  * (modules/real3d/segformer.py:691-700), between two r3d_conv_forward layers: x fp32 channel-blocked [N,C/8,H,W,8] ->
  * y at 2H x 2W in R3D_FMT_CB8 or R3D_FMT_SPLIT (scaled by next_scale, NULL = 1).  C % 8 == 0. */
 int r3d_upsample2x_bilinear(const float* x_cb8, int N, int C, int H, int W, void* y, int y_format,
                             const float* next_scale, size_t next_scale_stride, r3d_stream_t stream);
+
+/* --- small image ops of the torso / background fusion forward (modules/real3d/super_resolution/sr_with_ref.py:67-137) --------------
+ * r3d_resize_bilinear: torch.nn.functional.interpolate(x, size=(OH, OW), mode='bilinear', align_corners=False, antialias=A) on
+ *   `planes` = N*C contiguous H x W planes (the 128 -> 256 / 512 -> 256 / occlusion resizes of :76-81,110,120).
+ * r3d_blend: out = a * mask + b * (1 - mask), a, b [N,C,H,W], mask [N,1,H,W]  (`rgb * alpha + rgb_torso * (1 - alpha)` :103,113).
+ * r3d_person_occlusion: clamp(torso_occlusion + where(alpha > head_threshold, 1, alpha), 0, 1)  (:107-112,117-122). */
+int r3d_resize_bilinear(const float* x, int planes, int H, int W, float* y, int OH, int OW, int antialias, r3d_stream_t stream);
+int r3d_blend(const float* a, const float* b, const float* mask, int N, int C, int H, int W, float* out, r3d_stream_t stream);
+int r3d_person_occlusion(const float* alpha, const float* torso_occlusion, float head_threshold, size_t count, float* out,
+                         r3d_stream_t stream);
 
 /* --- output side --------------------------------------------------------------------------------
  * clamp(-1,1) -> (x+1)*127.5 -> uint8 HWC, the conversion real3d_infer.py:495-521 does on the host

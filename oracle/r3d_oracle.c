@@ -493,35 +493,44 @@ static void modulate(const float* Wt /*[Co][Ci][k][k]*/, const float* styles, in
     }
 }
 
-/* plain 3x3 correlation, pad 1 (F.conv2d; conv2d_resample.py:139-141 fast path) NCHW one image */
+/* plain 3x3 correlation, pad 1 (F.conv2d; conv2d_resample.py:139-141 fast path) NCHW one image.
+ * Output-stationary bands of BAND rows x one output channel (the band of y stays in L1 while all input channels and taps stream
+ * past); every output element is still accumulated in the order (c, ky, kx), so the result does not depend on BAND or threads. */
+#define R3D_BAND 8
 static void conv3x3(const float* x, int Ci, int Hh, int Ww, const float* w /*[Co][Ci][3][3]*/, int Co, float* y)
 {
-#pragma omp parallel for schedule(static)
-    for (int o = 0; o < Co; ++o) {
-        float* yo = y + (size_t)o * Hh * Ww;
-        memset(yo, 0, sizeof(float) * (size_t)Hh * Ww);
-        for (int c = 0; c < Ci; ++c) {
-            const float* xc = x + (size_t)c * Hh * Ww;
-            const float* wk = w + ((size_t)o * Ci + c) * 9;
-            for (int ky = 0; ky < 3; ++ky)
-                for (int kx = 0; kx < 3; ++kx) {
-                    const float wv = wk[ky * 3 + kx];
-                    const int dy = ky - 1, dx = kx - 1;
-                    const int y0 = dy < 0 ? -dy : 0, y1 = dy > 0 ? Hh - dy : Hh;
-                    const int x0 = dx < 0 ? -dx : 0, x1 = dx > 0 ? Ww - dx : Ww;
-                    for (int yy = y0; yy < y1; ++yy) {
-                        float* yr = yo + (size_t)yy * Ww;
-                        const float* xr = xc + (size_t)(yy + dy) * Ww + dx;
-                        for (int xx = x0; xx < x1; ++xx) yr[xx] += wv * xr[xx];
+    const int nb = (Hh + R3D_BAND - 1) / R3D_BAND;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int o = 0; o < Co; ++o)
+        for (int b = 0; b < nb; ++b) {
+            const int r0 = b * R3D_BAND, r1 = r0 + R3D_BAND < Hh ? r0 + R3D_BAND : Hh;
+            float* yo = y + (size_t)o * Hh * Ww;
+            memset(yo + (size_t)r0 * Ww, 0, sizeof(float) * (size_t)(r1 - r0) * Ww);
+            for (int c = 0; c < Ci; ++c) {
+                const float* xc = x + (size_t)c * Hh * Ww;
+                const float* wk = w + ((size_t)o * Ci + c) * 9;
+                for (int ky = 0; ky < 3; ++ky)
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float wv = wk[ky * 3 + kx];
+                        const int dy = ky - 1, dx = kx - 1;
+                        int y0 = dy < 0 ? -dy : 0, y1 = dy > 0 ? Hh - dy : Hh;
+                        const int x0 = dx < 0 ? -dx : 0, x1 = dx > 0 ? Ww - dx : Ww;
+                        if (y0 < r0) y0 = r0;
+                        if (y1 > r1) y1 = r1;
+                        for (int yy = y0; yy < y1; ++yy) {
+                            float* yr = yo + (size_t)yy * Ww;
+                            const float* xr = xc + (size_t)(yy + dy) * Ww + dx;
+                            for (int xx = x0; xx < x1; ++xx) yr[xx] += wv * xr[xx];
+                        }
                     }
-                }
+            }
         }
-    }
 }
 
 /* up=2 path of conv2d_resample (conv2d_resample.py:116-133 with padding=1, f 4x4):
  * conv_transpose2d(stride 2, no padding, weight used un-flipped) -> [Co][2H+1][2W+1],
- * then upfirdn2d(pad 1,1,1,1, gain 4) with f = outer([1,3,3,1])/64 (upfirdn2d.py:72-116,171-215). */
+ * then upfirdn2d(pad 1,1,1,1, gain 4) with f = outer([1,3,3,1])/64 (upfirdn2d.py:72-116,171-215).
+ * T is built in bands of T rows (output-stationary, accumulation order (c, ky, kx) per element as before), then filtered. */
 static void upconv3x3(const float* x, int Ci, int Hh, int Ww, const float* w /*[Co][Ci][3][3]*/, int Co, float* y /*[Co][2H][2W]*/)
 {
     const int Th = 2 * Hh + 1, Tw = 2 * Ww + 1;
@@ -529,49 +538,60 @@ static void upconv3x3(const float* x, int Ci, int Hh, int Ww, const float* w /*[
     static const float f1[4] = { 1.0f, 3.0f, 3.0f, 1.0f };
     float f2[4][4];
     for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) f2[a][b] = (f1[a] * f1[b] / 64.0f) * 4.0f;
-#pragma omp parallel
-    {
-        float* T = (float*)malloc(sizeof(float) * (size_t)Th * Tw);
-#pragma omp for schedule(static)
-        for (int o = 0; o < Co; ++o) {
-            memset(T, 0, sizeof(float) * (size_t)Th * Tw);
+    float* Tall = (float*)malloc(sizeof(float) * (size_t)Co * Th * Tw);
+    if (!Tall) return;
+    const int tband = 2 * R3D_BAND, nb = (Th + tband - 1) / tband;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int o = 0; o < Co; ++o)
+        for (int b = 0; b < nb; ++b) {
+            const int t0 = b * tband, t1 = t0 + tband < Th ? t0 + tband : Th;
+            float* T = Tall + (size_t)o * Th * Tw;
+            memset(T + (size_t)t0 * Tw, 0, sizeof(float) * (size_t)(t1 - t0) * Tw);
             for (int c = 0; c < Ci; ++c) {
                 const float* xc = x + (size_t)c * Hh * Ww;
                 const float* wk = w + ((size_t)o * Ci + c) * 9;
                 for (int ky = 0; ky < 3; ++ky)
                     for (int kx = 0; kx < 3; ++kx) {
                         const float wv = wk[ky * 3 + kx];
-                        for (int iy = 0; iy < Hh; ++iy) {
+                        /* T row 2*iy + ky in [t0, t1) */
+                        int i0 = (t0 - ky + 1) / 2, i1 = (t1 - ky + 1) / 2;
+                        if (i0 < 0) i0 = 0;
+                        if (i1 > Hh) i1 = Hh;
+                        for (int iy = i0; iy < i1; ++iy) {
                             float* tr = T + (size_t)(2 * iy + ky) * Tw + kx;
                             const float* xr = xc + (size_t)iy * Ww;
                             for (int ix = 0; ix < Ww; ++ix) tr[2 * ix] += wv * xr[ix];
                         }
                     }
             }
-            float* yo = y + (size_t)o * Oh * Ow;
-            for (int yy = 0; yy < Oh; ++yy)
-                for (int xx = 0; xx < Ow; ++xx) {
-                    float acc = 0.0f;
-                    for (int a = 0; a < 4; ++a) {
-                        const int ty = yy + a - 1;
-                        if (ty < 0 || ty >= Th) continue;
-                        for (int b = 0; b < 4; ++b) {
-                            const int tx = xx + b - 1;
-                            if (tx < 0 || tx >= Tw) continue;
-                            acc += T[(size_t)ty * Tw + tx] * f2[a][b];
-                        }
-                    }
-                    yo[(size_t)yy * Ow + xx] = acc;
-                }
         }
-        free(T);
-    }
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int o = 0; o < Co; ++o)
+        for (int yy = 0; yy < Oh; ++yy) {
+            const float* T = Tall + (size_t)o * Th * Tw;
+            float* yo = y + (size_t)o * Oh * Ow;
+            for (int xx = 0; xx < Ow; ++xx) {
+                float acc = 0.0f;
+                for (int a = 0; a < 4; ++a) {
+                    const int ty = yy + a - 1;
+                    if (ty < 0 || ty >= Th) continue;
+                    for (int b = 0; b < 4; ++b) {
+                        const int tx = xx + b - 1;
+                        if (tx < 0 || tx >= Tw) continue;
+                        acc += T[(size_t)ty * Tw + tx] * f2[a][b];
+                    }
+                }
+                yo[(size_t)yy * Ow + xx] = acc;
+            }
+        }
+    free(Tall);
 }
 
 /* bias_act: lrelu(alpha .2)*sqrt(2) or linear  (bias_act.py:93-122; networks_stylegan2.py:339-341) */
 static void bias_act_inplace(float* x, int Cc, size_t hw, const float* b, int lrelu, float clampv)
 {
     const float gain = lrelu ? (float)sqrt(2.0) : 1.0f;
+#pragma omp parallel for schedule(static)
     for (int c = 0; c < Cc; ++c) {
         float* xc = x + (size_t)c * hw;
         const float bc = b[c];
@@ -589,6 +609,7 @@ static void upsample2d_rgb(const float* img, int Cc, int Hh, int Ww, float* out 
 {
     static const float f1[4] = { 1.0f, 3.0f, 3.0f, 1.0f };
     const int Oh = 2 * Hh, Ow = 2 * Ww;
+#pragma omp parallel for collapse(2) schedule(static)
     for (int c = 0; c < Cc; ++c)
         for (int yy = 0; yy < Oh; ++yy)
             for (int xx = 0; xx < Ow; ++xx) {
@@ -698,6 +719,7 @@ R3D_API int r3d_oracle_sr_block_noup(const float* x, const float* img, int Ci, i
     for (int o = 0; o < 3; ++o) {
         float* yo = img_out + (size_t)o * hw;
         const float* io = img + (size_t)o * hw;
+#pragma omp parallel for schedule(static)
         for (size_t i = 0; i < hw; ++i) {
             float acc = 0.0f;
             for (int c = 0; c < Co; ++c) acc += x_out[(size_t)c * hw + i] * wm2[(size_t)o * Co + c];
@@ -748,6 +770,7 @@ R3D_API int r3d_oracle_sr_block(const float* x, const float* img, int Ci, int Co
     upsample2d_rgb(img, 3, Hh, Ww, img_out);
     for (int o = 0; o < 3; ++o) {
         float* yo = img_out + (size_t)o * ohw;
+#pragma omp parallel for schedule(static)
         for (size_t i = 0; i < ohw; ++i) {
             float acc = 0.0f;
             for (int c = 0; c < Co; ++c) acc += x_out[(size_t)c * ohw + i] * wm2[(size_t)o * Co + c];

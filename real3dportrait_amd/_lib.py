@@ -21,7 +21,7 @@ SIGNATURES = {
     "r3d_version": (c_int, []),
     "r3d_last_error": (ctypes.c_char_p, []),
     "r3d_planes_to_nhwc": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    "r3d_blend_cat_to_split": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, P, P]),
+    "r3d_blend_cat_to_split": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, P, P, c_size_t, P]),
     "r3d_upsample2x_bilinear": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P, c_size_t, P]),
     "r3d_raygen": (c_int, [P, P, c_int, c_int, P, P, P]),
     "r3d_render_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
@@ -34,13 +34,21 @@ SIGNATURES = {
     "r3d_sr_block_prepack": (c_int, [c_int, c_int, P, P, P, c_int, P]),
     "r3d_sr_block_styles": (c_int, [P, c_int, c_int, c_int, c_int] + [P] * 12 + [P, P]),
     "r3d_sr_block_forward": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_float, P, c_int, P, c_size_t,
-                                     P, c_int, P, c_size_t, P]),
+                                     P, P, P, c_int, P, c_size_t, P]),
+    "r3d_chain_fold": (c_int, [P, c_int, c_int, P, c_int, P, c_int, P]),
+    "r3d_sr_block_bound_offset": (c_size_t, [c_int, c_int]),
+    "r3d_conv_scales_bound_offset": (c_size_t, [c_int, c_int]),
+    "r3d_conv_scales_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "r3d_absmax": (c_int, [P, c_size_t, c_int, P, P, P]),
     "r3d_conv_prepacked_bytes": (c_size_t, [c_int, c_int, c_int]),
     "r3d_conv_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "r3d_conv_prepack": (c_int, [P, c_int, c_int, c_int, P, P]),
-    "r3d_conv_forward": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, P, c_size_t, P, c_size_t, P, c_size_t,
-                                 c_int, c_float, c_float, c_float, P, c_int, P, c_size_t, P, c_size_t, P]),
+    "r3d_conv_forward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int,
+                                 c_int, c_float, c_float, c_float, P, c_int, P, c_size_t, P, P, c_size_t, P]),
     "r3d_frames_to_u8": (c_int, [P, c_int, c_int, c_int, P, P]),
+    "r3d_resize_bilinear": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, c_int, P]),
+    "r3d_blend": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P]),
+    "r3d_person_occlusion": (c_int, [P, P, c_float, c_size_t, P, P]),
     "r3d_profile_configure": (c_int, [ctypes.c_uint32]),
     "r3d_profile_reset": (c_int, []),
     "r3d_profile_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
@@ -49,6 +57,17 @@ SIGNATURES = {
     "r3d_event_elapsed_ms": (c_int, [P, P, ctypes.POINTER(c_float)]),
     "r3d_event_destroy": (c_int, [P]),
 }
+
+
+
+class ChainOp(ctypes.Structure):
+    """r3d_chain_op of include/r3d_hip.h (one layer of an r3d_chain_fold chain)."""
+    _fields_ = [("kind", c_int), ("Cin", c_int), ("Cout", c_int), ("ksize", c_int), ("act", c_int),
+                ("gain", c_float), ("clamp", c_float), ("src_a", c_int), ("src_b", c_int),
+                ("scales", c_void_p), ("prepacked", c_void_p), ("bias", c_void_p)]
+
+
+CHAIN_SR_BLOCK, CHAIN_CONV, CHAIN_SR_BLOCK_TAIL, CHAIN_SRC_NONE, CHAIN_MAX_OPS, CHAIN_MAX_EXT, CHAIN_MAX_ZERO = 0, 1, 2, -1000, 12, 4, 4
 
 _lib = None
 

@@ -61,18 +61,105 @@ __global__ void frames_to_u8_kernel(const float* __restrict__ img, int HW, uint8
     const float* s = img + (size_t)n * 3 * HW;
     uint8_t* d = out + ((size_t)n * HW + p) * 3;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float v = s[(size_t)c * HW + p];
-        v = fminf(fmaxf(v, -1.0f), 1.0f);
-        d[c] = (uint8_t)((v + 1.0f) * 127.5f);     // ((x+1)/2*255).to(uint8): truncation
+    for (int c = 0; c < 3; ++c) d[c] = frame_u8(s[(size_t)c * HW + p]);
+}
+
+// ---- small image ops of SuperresolutionHybrid8XDC_Warp.forward (modules/real3d/super_resolution/sr_with_ref.py:67-137) -------------
+// F.interpolate(mode='bilinear', align_corners=False, antialias=A): ATen's separable "aa" weights (UpSampleKernel.cpp
+// _compute_indices_weights_aa): scale = in / out, support = max(scale, 1), centre = scale * (i + 0.5), taps
+// [int(centre - support + 0.5), int(centre + support + 0.5)) clipped to the image, triangle weights (1 - |t| / max(scale, 1))
+// normalised to sum 1.  antialias = 0 -> support 1 (plain bilinear with edge clamping, which the same formulas give).
+__device__ __forceinline__ void aa_window(int i, float scale, int in_size, int antialias, int& lo, int& cnt, float& inv)
+{
+    const float sup = (antialias && scale >= 1.0f) ? scale : 1.0f;
+    const float centre = scale * ((float)i + 0.5f);
+    lo = max((int)(centre - sup + 0.5f), 0);
+    cnt = min((int)(centre + sup + 0.5f), in_size) - lo;
+    inv = (antialias && scale >= 1.0f) ? 1.0f / scale : 1.0f;
+}
+__device__ __forceinline__ float aa_tri(float t) { t = fabsf(t); return t < 1.0f ? 1.0f - t : 0.0f; }
+
+__global__ void resize_bilinear_kernel(const float* __restrict__ x, int H, int W, float* __restrict__ y, int OH, int OW, int antialias)
+{
+    const int plane = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= OH * OW) return;
+    const int oy = p / OW, ox = p - oy * OW;
+    const float sy = (float)H / (float)OH, sx = (float)W / (float)OW;
+    int y0, ny, x0, nx; float iy, ix;
+    aa_window(oy, sy, H, antialias, y0, ny, iy);
+    aa_window(ox, sx, W, antialias, x0, nx, ix);
+    const float cy = sy * ((float)oy + 0.5f), cx = sx * ((float)ox + 0.5f);
+    float wys = 0.f, wxs = 0.f;
+    for (int j = 0; j < ny; ++j) wys += aa_tri(((float)(j + y0) - cy + 0.5f) * iy);
+    for (int k = 0; k < nx; ++k) wxs += aa_tri(((float)(k + x0) - cx + 0.5f) * ix);
+    const float* X = x + (size_t)plane * H * W;
+    float acc = 0.f;
+    for (int j = 0; j < ny; ++j) {
+        const float wy = aa_tri(((float)(j + y0) - cy + 0.5f) * iy) / wys;
+        float row = 0.f;
+        for (int k = 0; k < nx; ++k) row += X[(size_t)(y0 + j) * W + x0 + k] * (aa_tri(((float)(k + x0) - cx + 0.5f) * ix) / wxs);
+        acc += wy * row;
     }
+    y[(size_t)plane * OH * OW + p] = acc;
+}
+
+// out = a * m + b * (1 - m)  (`rgb * head_torso_alpha + rgb_torso * (1 - head_torso_alpha)`, sr_with_ref.py:103,113,125,135)
+__global__ void blend_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ mask, int C, int HW,
+                             float* __restrict__ out)
+{
+    const int n = blockIdx.y;
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= HW) return;
+    const float m = mask[(size_t)n * HW + p];
+    for (int c = 0; c < C; ++c) {
+        const size_t i = ((size_t)n * C + c) * HW + p;
+        out[i] = a[i] * m + b[i] * (1.0f - m);
+    }
+}
+
+// person_occlusion = clamp(torso_occlusion + head_occlusion, 0, 1), head_occlusion = alpha with values > threshold set to 1
+// (sr_with_ref.py:107-112,117-122)
+__global__ void person_occlusion_kernel(const float* __restrict__ alpha, const float* __restrict__ torso_occ, float thr, size_t n,
+                                        float* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float a = alpha[i];
+    out[i] = fminf(fmaxf(torso_occ[i] + (a > thr ? 1.0f : a), 0.0f), 1.0f);
 }
 
 }  // namespace r3d
 
 using namespace r3d;
 
-extern "C" int r3d_version(void) { return 10; }   // 0.1.0
+extern "C" int r3d_version(void) { return 20; }   // 0.2.0
+
+extern "C" int r3d_resize_bilinear(const float* x, int planes, int H, int W, float* y, int OH, int OW, int antialias, r3d_stream_t stream)
+{
+    if (!x || !y || planes <= 0 || H <= 0 || W <= 0 || OH <= 0 || OW <= 0) { set_error("resize_bilinear: bad argument"); return R3D_ERR_INVALID_ARG; }
+    ProfScope ps(R3D_PROF_LAYOUT, (hipStream_t)stream);
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3((OH * OW + 255) / 256, planes), dim3(256), 0, (hipStream_t)stream, x, H, W, y, OH, OW, antialias);
+    return check_launch("resize_bilinear");
+}
+
+extern "C" int r3d_blend(const float* a, const float* b, const float* mask, int N, int C, int H, int W, float* out, r3d_stream_t stream)
+{
+    if (!a || !b || !mask || !out || N <= 0 || C <= 0 || H <= 0 || W <= 0) { set_error("blend: bad argument"); return R3D_ERR_INVALID_ARG; }
+    ProfScope ps(R3D_PROF_LAYOUT, (hipStream_t)stream);
+    hipLaunchKernelGGL(blend_kernel, dim3((H * W + 255) / 256, N), dim3(256), 0, (hipStream_t)stream, a, b, mask, C, H * W, out);
+    return check_launch("blend");
+}
+
+extern "C" int r3d_person_occlusion(const float* alpha, const float* torso_occlusion, float head_threshold, size_t count, float* out,
+                                    r3d_stream_t stream)
+{
+    if (!alpha || !torso_occlusion || !out || count == 0) { set_error("person_occlusion: bad argument"); return R3D_ERR_INVALID_ARG; }
+    ProfScope ps(R3D_PROF_LAYOUT, (hipStream_t)stream);
+    hipLaunchKernelGGL(person_occlusion_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, (hipStream_t)stream, alpha, torso_occlusion,
+                       head_threshold, count, out);
+    return check_launch("person_occlusion");
+}
 extern "C" const char* r3d_last_error(void) { return g_err; }
 
 extern "C" int r3d_frames_to_u8(const float* img, int N, int H, int W, uint8_t* out, r3d_stream_t stream)

@@ -40,6 +40,13 @@ __device__ __forceinline__ float softplus20(float x) {
 }
 __device__ __forceinline__ float sigmoidf(float x) { return __builtin_amdgcn_rcpf(1.0f + fexp(-x)); }
 
+// ---- output side: clamp(-1,1) then ((x + 1) / 2 * 255).int() -> uint8 (inference/real3d_infer.py:472,518-522).  (x + 1) / 2 is exact,
+// so fl((x + 1) * 127.5) is the same single rounding as fl(((x + 1) / 2) * 255); truncation toward zero; NaN -> 0.
+__device__ __forceinline__ uint8_t frame_u8(float v) {
+    v = fminf(fmaxf(v, -1.0f), 1.0f);
+    return (uint8_t)(int)((v + 1.0f) * 127.5f);
+}
+
 // ---- counter-based uniform [0,1) (used when the caller passes no noise tensors) ---------------------
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;

@@ -108,6 +108,8 @@ __global__ void sr_styles_kernel(const float* __restrict__ ws3, int WD, int Cin,
 
 // grid (Cout + 1, N, 2): blocks [0, Cout) of layer z: one BLOCK per output channel: d = rsqrt(sum_{ci,k} (W*s)^2 + 1e-8)
 // (networks_stylegan2.py:65-70); block Cout of layer 0: modulated toRGB weights (:366-368) + bias copies.
+// Also per cout, for the fp16 range management of the f16x3 path (r3d_sr_common.h): the bound coefficient
+// c[co] = d[co] * sum |W*s|  (|conv output| <= c[co] * max|input|) and the weight-row factor 2^-kw[co].
 __global__ void sr_demod_kernel(int Cin, int Cout, const float* __restrict__ w0, const float* __restrict__ w1,
                                 const float* __restrict__ wrgb, const float* __restrict__ b0, const float* __restrict__ b1,
                                 const float* __restrict__ brgb, float* __restrict__ styles, size_t stride_n)
@@ -127,14 +129,140 @@ __global__ void sr_demod_kernel(int Cin, int Cout, const float* __restrict__ w0,
     const int Ci = layer == 0 ? Cin : Cout;
     const float* W = (layer == 0 ? w0 : w1) + (size_t)co * Ci * 9;
     const float* st = base + (layer == 0 ? L.s0 : L.s1);
-    float ss = 0.f;
-    for (int i = threadIdx.x; i < Ci * 9; i += blockDim.x) { const float v = W[i] * st[i / 9]; ss += v * v; }
+    float ss = 0.f, l1 = 0.f, mx = 0.f;
+    for (int i = threadIdx.x; i < Ci * 9; i += blockDim.x) {
+        const float wv = W[i], v = wv * st[i / 9];
+        ss += v * v; l1 += fabsf(v); mx = fmaxf(mx, fabsf(wv));
+    }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) ss += __shfl_xor(ss, d);
-    __shared__ float red[4];
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    for (int d = 32; d >= 1; d >>= 1) { ss += __shfl_xor(ss, d); l1 += __shfl_xor(l1, d); mx = fmaxf(mx, __shfl_xor(mx, d)); }
+    __shared__ float red[3][4];
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = ss; red[1][threadIdx.x >> 6] = l1; red[2][threadIdx.x >> 6] = mx; }
     __syncthreads();
-    if (threadIdx.x == 0) base[(layer == 0 ? L.d0 : L.d1) + co] = rsqrtf(red[0] + red[1] + red[2] + red[3] + 1e-8f);
+    if (threadIdx.x == 0) {
+        const float d = rsqrtf(red[0][0] + red[0][1] + red[0][2] + red[0][3] + 1e-8f);
+        base[(layer == 0 ? L.d0 : L.d1) + co] = d;
+        base[(layer == 0 ? L.c0 : L.c1) + co] = d * (red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+        base[(layer == 0 ? L.wi0 : L.wi1) + co] = pow2f(-weight_row_exp(fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]))));
+    }
+}
+
+// ---- range fold (r3d_chain_fold): one block per sample walks a chain of layers, propagating a guaranteed bound on max|x| and
+// writing each layer's power-of-two folded multipliers (see r3d_sr_common.h).  Runs once per forward in front of the convs.
+struct ChainArgs {
+    r3d_chain_op ops[R3D_CHAIN_MAX_OPS];
+    const float* ext[R3D_CHAIN_MAX_EXT];
+    float* zero[R3D_CHAIN_MAX_ZERO];
+    int nops, N, nzero;
+};
+
+__device__ __forceinline__ float block_max(float v, float* red)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__global__ __launch_bounds__(256) void chain_fold_kernel(ChainArgs a)
+{
+    __shared__ float red[4];
+    __shared__ float bounds[R3D_CHAIN_MAX_OPS];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    if (tid < a.nzero) a.zero[tid][n] = 0.f;                  // absmax slots of the tensors the following kernels measure
+    for (int k = 0; k < a.nops; ++k) {
+        const r3d_chain_op& op = a.ops[k];
+        float B = 0.f;
+        const int srcs[2] = {op.src_a, op.src_b};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int s = srcs[j];
+            if (s >= 0) B = fmaxf(B, bounds[s]);
+            else if (s >= -R3D_CHAIN_MAX_EXT) B = fmaxf(B, fabsf(a.ext[-1 - s][n]));
+        }
+        float Bout;
+        if (op.kind == R3D_CHAIN_SR_BLOCK || op.kind == R3D_CHAIN_SR_BLOCK_TAIL) {
+            const SrStyleLayout L = sr_style_layout(op.Cin, op.Cout);
+            float* base = reinterpret_cast<float*>(op.scales) + (size_t)n * L.total;
+            float Bin = B;
+            if (op.kind == R3D_CHAIN_SR_BLOCK_TAIL) {
+                // B is a measured max|block input|: tighten the bound after conv0 with it, keep layer 0's multipliers as they are
+                float bo = 0.f;
+                for (int i = tid; i < op.Cout; i += 256) bo = fmaxf(bo, fabsf(base[L.b0 + i]) + base[L.c0 + i] * B);
+                bo = block_max(bo, red) * op.gain;
+                if (op.clamp >= 0.f) bo = fminf(bo, op.clamp);
+                Bin = fminf(bo, base[L.meta + SR_META_BOUND_MID]);
+            }
+            for (int layer = (op.kind == R3D_CHAIN_SR_BLOCK_TAIL ? 1 : 0); layer < 2; ++layer) {
+                const int Ci = layer ? op.Cout : op.Cin;
+                const size_t so = layer ? L.s1 : L.s0, sf = layer ? L.s1f : L.s0f, d_ = layer ? L.d1 : L.d0, df = layer ? L.d1f : L.d0f;
+                const size_t c_ = layer ? L.c1 : L.c0, wi = layer ? L.wi1 : L.wi0, b_ = layer ? L.b1 : L.b0;
+                float sm = 0.f;
+                for (int i = tid; i < Ci; i += 256) sm = fmaxf(sm, fabsf(base[so + i]));
+                sm = block_max(sm, red);
+                const int e = act_exp(Bin, sm);
+                const float up = pow2f(e), dn = pow2f(-e);
+                for (int i = tid; i < Ci; i += 256) base[sf + i] = base[so + i] * up;
+                float bo = 0.f;
+                for (int i = tid; i < op.Cout; i += 256) {
+                    base[df + i] = base[d_ + i] * base[wi + i] * dn;
+                    bo = fmaxf(bo, fabsf(base[b_ + i]) + base[c_ + i] * Bin);
+                }
+                bo = block_max(bo, red) * op.gain;
+                if (op.clamp >= 0.f) bo = fminf(bo, op.clamp);
+                if (tid == 0) {
+                    base[L.meta + (layer ? SR_META_E1 : SR_META_E0)] = (float)e;
+                    base[L.meta + (layer ? SR_META_SMAX1 : SR_META_SMAX0)] = sm;
+                    base[L.meta + (layer ? SR_META_BOUND_OUT : SR_META_BOUND_MID)] = bo;
+                    if (!layer) base[L.meta + SR_META_BOUND_IN] = Bin;
+                }
+                Bin = bo;
+            }
+            Bout = Bin;
+        } else {
+            const int Ci = (op.Cin + 15) / 16 * 16, Co = (op.Cout + BLOCK_M - 1) / BLOCK_M * BLOCK_M;
+            const ConvScales S = conv_scales_layout(Ci, Co);
+            const ConvTail T = conv_tail_layout(Co);
+            float* base = reinterpret_cast<float*>(op.scales) + (size_t)n * S.total;
+            const float* tail = reinterpret_cast<const float*>(op.prepacked) + (size_t)(op.ksize * op.ksize) * Ci * Co;
+            const int e = act_exp(B, 1.0f);
+            const float up = pow2f(e), dn = pow2f(-e);
+            for (int i = tid; i < Ci; i += 256) base[S.in_vec + i] = up;
+            float bo = 0.f;
+            for (int i = tid; i < Co; i += 256) {
+                base[S.out_vec + i] = tail[T.winv + i] * dn;
+                if (i < op.Cout) bo = fmaxf(bo, (op.bias ? fabsf(op.bias[i]) : 0.f) + tail[T.l1 + i] * B);
+            }
+            bo = block_max(bo, red);
+            if (op.act) bo *= op.gain;
+            if (op.clamp >= 0.f) bo = fminf(bo, op.clamp);
+            if (tid == 0) { base[S.meta + 0] = B; base[S.meta + 1] = bo; base[S.meta + 2] = (float)e; }
+            Bout = bo;
+        }
+        if (tid == 0) bounds[k] = Bout;
+        __syncthreads();
+    }
+}
+
+// ---- per-sample max |x| of an fp32 tensor (the measured bound at an fp32 -> SPLIT conversion).  `out` must be zero on entry;
+// `zero_next` (the slot of the NEXT call, ping-pong) is cleared here so that no separate memset is needed.
+__global__ void absmax_kernel(const float* __restrict__ x, size_t count, unsigned* __restrict__ out, unsigned* __restrict__ zero_next)
+{
+    const int n = blockIdx.y;
+    if (zero_next && blockIdx.x == 0 && threadIdx.x == 0) zero_next[n] = 0u;
+    const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)n * count);
+    const size_t n4 = (count & 3) ? 0 : (count >> 2);                  // vector path only when every sample stays 16-byte aligned
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = x4[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    if (!n4) for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[(size_t)n * count + i]));
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(&out[n], __float_as_uint(m));     // non-negative floats order like unsigned ints; NaN never wins
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -386,8 +514,8 @@ using namespace r3d;
 
 extern "C" size_t r3d_sr_block_prepacked_bytes(int Cin, int Cout)
 {
-    // conv0 (plain layout) + conv1 + conv0 again in the fused up-conv layout (f16x3)
-    return ((size_t)2 * 9 * Cin * Cout + (size_t)9 * Cout * Cout) * sizeof(float);
+    // conv0 (plain layout) + conv1 + conv0 again in the fused up-conv layout (f16x3) + the two per-cout weight-row tails
+    return ((size_t)2 * 9 * Cin * Cout + (size_t)9 * Cout * Cout + 2 * conv_tail_layout(Cout).total) * sizeof(float);
 }
 
 extern "C" size_t r3d_sr_block_styles_bytes(int N, int Cin, int Cout)
@@ -480,11 +608,12 @@ extern "C" int r3d_sr_block_styles(const float* ws3, int N, int WD, int Cin, int
 extern "C" int r3d_sr_block_forward(const void* prepacked, const void* styles, int N, int Cin, int Cout, int Hin, int Win, int up,
                                     const void* x, int x_format, const float* img, float clamp,
                                     void* x_out, int x_out_format, const float* next_scale, size_t next_scale_stride,
-                                    float* img_out, int precision,
+                                    float* img_out, uint8_t* img_u8, float* x_absmax, int precision,
                                     void* workspace, size_t workspace_bytes, r3d_stream_t stream)
 {
     if (precision != R3D_SR_F32 && precision != R3D_SR_F16X3) { set_error("sr_block_forward: unknown precision %d", precision); return R3D_ERR_INVALID_ARG; }
-    if (!prepacked || !styles || !x || !img || !img_out || N <= 0 || Hin <= 0 || Win <= 0 || (Cin & 15) || (Cout % BLOCK_M) || (up != 0 && up != 1)) {
+    if ((img_u8 || x_absmax) && precision != R3D_SR_F16X3) { set_error("sr_block_forward: the fused uint8 output / x_absmax need R3D_SR_F16X3"); return R3D_ERR_INVALID_ARG; }
+    if (!prepacked || !styles || !x || !img || (!img_out && !img_u8) || N <= 0 || Hin <= 0 || Win <= 0 || (Cin & 15) || (Cout % BLOCK_M) || (up != 0 && up != 1)) {
         set_error("sr_block_forward: bad argument"); return R3D_ERR_INVALID_ARG;
     }
     if (!up && precision != R3D_SR_F16X3) { set_error("sr_block_forward: up=0 (SynthesisBlockNoUp) needs R3D_SR_F16X3"); return R3D_ERR_INVALID_ARG; }
@@ -502,7 +631,7 @@ extern "C" int r3d_sr_block_forward(const void* prepacked, const void* styles, i
     hipStream_t st = (hipStream_t)stream;
     if (f16)
         return sr_block_forward_f16x3(prepacked, styles, N, Cin, Cout, Hin, Win, up, x, x_format, img, clamp, x_out, x_out_format,
-                                      next_scale, next_scale_stride, img_out, workspace, workspace_bytes, st);
+                                      next_scale, next_scale_stride, img_out, img_u8, x_absmax, workspace, workspace_bytes, st);
 
     const SrStyleLayout L = sr_style_layout(Cin, Cout);
     const float* pk = reinterpret_cast<const float*>(styles);
@@ -575,6 +704,15 @@ extern "C" int r3d_sr_block_forward(const void* prepacked, const void* styles, i
 // ---- generic convolution layer (see include/r3d_hip.h) -----------------------------------------------------------
 extern "C" size_t r3d_conv_prepacked_bytes(int Cin, int Cout, int ksize) { return r3d::conv_prepacked_bytes_f16x3(Cin, Cout, ksize); }
 extern "C" size_t r3d_conv_workspace_bytes(int N, int Cin, int H, int W) { return r3d::conv_workspace_bytes_f16x3(N, Cin, H, W); }
+extern "C" size_t r3d_conv_scales_bytes(int N, int Cin, int Cout)
+{
+    return (size_t)N * conv_scales_layout((Cin + 15) / 16 * 16, (Cout + BLOCK_M - 1) / BLOCK_M * BLOCK_M).total * sizeof(float);
+}
+extern "C" size_t r3d_conv_scales_bound_offset(int Cin, int Cout)
+{
+    return conv_scales_layout((Cin + 15) / 16 * 16, (Cout + BLOCK_M - 1) / BLOCK_M * BLOCK_M).meta + 1;
+}
+extern "C" size_t r3d_sr_block_bound_offset(int Cin, int Cout) { return sr_style_layout(Cin, Cout).meta + SR_META_BOUND_OUT; }
 
 extern "C" int r3d_conv_prepack(const float* weight, int Cin, int Cout, int ksize, void* prepacked, r3d_stream_t stream)
 {
@@ -583,15 +721,68 @@ extern "C" int r3d_conv_prepack(const float* weight, int Cin, int Cout, int ksiz
     return conv_prepack_f16x3(weight, Cin, Cout, ksize, prepacked, (hipStream_t)stream);
 }
 
-extern "C" int r3d_conv_forward(const void* prepacked, int N, int Cin, int Cout, int H, int W, int ksize,
-                                const void* x, int x_format, const float* in_scale, size_t in_scale_stride,
-                                const float* out_scale, size_t out_scale_stride, const float* bias, size_t bias_stride,
-                                int act, float act_slope, float act_gain, float clamp,
-                                void* y, int y_format, const float* next_scale, size_t next_scale_stride,
+extern "C" int r3d_chain_fold(const r3d_chain_op* ops, int nops, int N, const float* const* ext_bounds, int n_ext,
+                              float* const* zero_slots, int n_zero, r3d_stream_t stream)
+{
+    using namespace r3d;
+    if (!ops || nops <= 0 || nops > R3D_CHAIN_MAX_OPS || N <= 0 || n_ext < 0 || n_ext > R3D_CHAIN_MAX_EXT || (n_ext && !ext_bounds) ||
+        n_zero < 0 || n_zero > R3D_CHAIN_MAX_ZERO || (n_zero && !zero_slots)) {
+        set_error("chain_fold: bad argument (1..%d ops, 0..%d external bounds, 0..%d zero slots)", R3D_CHAIN_MAX_OPS, R3D_CHAIN_MAX_EXT, R3D_CHAIN_MAX_ZERO);
+        return R3D_ERR_INVALID_ARG;
+    }
+    ChainArgs a = {};
+    a.nops = nops; a.N = N; a.nzero = n_zero;
+    for (int j = 0; j < n_zero; ++j) {
+        if (!zero_slots[j]) { set_error("chain_fold: zero slot %d is NULL", j); return R3D_ERR_INVALID_ARG; }
+        a.zero[j] = zero_slots[j];
+    }
+    for (int j = 0; j < n_ext; ++j) {
+        if (!ext_bounds[j]) { set_error("chain_fold: external bound %d is NULL", j); return R3D_ERR_INVALID_ARG; }
+        a.ext[j] = ext_bounds[j];
+    }
+    for (int k = 0; k < nops; ++k) {
+        const r3d_chain_op& op = ops[k];
+        const int srcs[2] = {op.src_a, op.src_b};
+        for (int j = 0; j < 2; ++j) {
+            const int sidx = srcs[j];
+            const bool ok = sidx == R3D_CHAIN_SRC_NONE || (sidx >= 0 && sidx < k) || (sidx < 0 && sidx >= -n_ext);
+            if (!ok) { set_error("chain_fold: op %d reads bound source %d (must be an earlier op or an external bound)", k, sidx); return R3D_ERR_INVALID_ARG; }
+        }
+        if (op.src_a == R3D_CHAIN_SRC_NONE && op.src_b == R3D_CHAIN_SRC_NONE) { set_error("chain_fold: op %d has no input bound", k); return R3D_ERR_INVALID_ARG; }
+        if ((op.kind != R3D_CHAIN_SR_BLOCK && op.kind != R3D_CHAIN_CONV && op.kind != R3D_CHAIN_SR_BLOCK_TAIL) || !op.scales || op.Cin <= 0 || op.Cout <= 0 ||
+            (op.kind == R3D_CHAIN_CONV && (!op.prepacked || (op.ksize != 1 && op.ksize != 3)))) {
+            set_error("chain_fold: op %d is malformed", k); return R3D_ERR_INVALID_ARG;
+        }
+        a.ops[k] = op;
+        if (a.ops[k].src_a == R3D_CHAIN_SRC_NONE) a.ops[k].src_a = -R3D_CHAIN_MAX_EXT - 1;     // "no source" inside the kernel
+        if (a.ops[k].src_b == R3D_CHAIN_SRC_NONE) a.ops[k].src_b = -R3D_CHAIN_MAX_EXT - 1;
+    }
+    ProfScope ps(R3D_PROF_PACK, (hipStream_t)stream);
+    hipLaunchKernelGGL(chain_fold_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("chain_fold");
+}
+
+extern "C" int r3d_absmax(const float* x, size_t count_per_sample, int N, float* out, float* zero_next, r3d_stream_t stream)
+{
+    using namespace r3d;
+    if (!x || !out || N <= 0 || count_per_sample == 0) { set_error("absmax: bad argument"); return R3D_ERR_INVALID_ARG; }
+    size_t blocks = (count_per_sample / 4 + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    ProfScope ps(R3D_PROF_LAYOUT, (hipStream_t)stream);
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, x, count_per_sample,
+                       reinterpret_cast<unsigned*>(out), reinterpret_cast<unsigned*>(zero_next));
+    return check_launch("absmax");
+}
+
+extern "C" int r3d_conv_forward(const void* prepacked, const void* scales, const float* bias,
+                                int N, int Cin, int Cout, int H, int W, int ksize,
+                                const void* x, int x_format, int act, float act_slope, float act_gain, float clamp,
+                                void* y, int y_format, const float* next_scale, size_t next_scale_stride, float* y_absmax,
                                 void* workspace, size_t workspace_bytes, r3d_stream_t stream)
 {
     using namespace r3d;
-    if (!prepacked || !x || !y || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (ksize != 1 && ksize != 3)) {
+    if (!prepacked || !scales || !x || !y || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (ksize != 1 && ksize != 3)) {
         set_error("conv_forward: bad argument"); return R3D_ERR_INVALID_ARG;
     }
     if (x_format < R3D_FMT_NCHW || x_format > R3D_FMT_SPLIT || y_format < R3D_FMT_NCHW || y_format > R3D_FMT_SPLIT) {
@@ -601,12 +792,12 @@ extern "C" int r3d_conv_forward(const void* prepacked, int N, int Cin, int Cout,
     if ((x_format != R3D_FMT_NCHW && (Cin & 15)) || (y_format != R3D_FMT_NCHW && (Cout & 7))) {
         set_error("conv_forward: blocked formats need Cin %% 16 == 0 and Cout %% 8 == 0 (Cin %d, Cout %d)", Cin, Cout); return R3D_ERR_INVALID_ARG;
     }
-    if (x_format == R3D_FMT_SPLIT && in_scale) { set_error("conv_forward: a SPLIT input is already scaled (in_scale must be null)"); return R3D_ERR_INVALID_ARG; }
     if (x_format != R3D_FMT_SPLIT && (!workspace || workspace_bytes < r3d_conv_workspace_bytes(N, Cin, H, W))) {
         set_error("conv_forward: workspace too small"); return R3D_ERR_WORKSPACE;
     }
-    return conv_forward_f16x3(prepacked, N, Cin, Cout, H, W, ksize, x, x_format, in_scale, in_scale_stride, out_scale, out_scale_stride,
-                              bias, bias_stride, act, act_slope, act_gain, clamp, y, y_format, next_scale, next_scale_stride,
+    const size_t stride = conv_scales_layout((Cin + 15) / 16 * 16, (Cout + BLOCK_M - 1) / BLOCK_M * BLOCK_M).total;
+    return conv_forward_f16x3(prepacked, reinterpret_cast<const float*>(scales), stride, bias, N, Cin, Cout, H, W, ksize, x, x_format,
+                              act, act_slope, act_gain, clamp, y, y_format, next_scale, next_scale_stride, y_absmax,
                               workspace, (hipStream_t)stream);
 }
 
@@ -620,7 +811,8 @@ extern "C" int r3d_upsample2x_bilinear(const float* x_cb8, int N, int C, int H, 
 }
 
 extern "C" int r3d_blend_cat_to_split(const float* a, int a_format, int Ca, const float* b, int b_format, int Cb, const float* mask,
-                                      int N, int H, int W, void* y_split, r3d_stream_t stream)
+                                      int N, int H, int W, void* y_split, const float* next_scale, size_t next_scale_stride,
+                                      r3d_stream_t stream)
 {
     using namespace r3d;
     if (!a || !b || !mask || !y_split || N <= 0 || H <= 0 || W <= 0 || Ca <= 0 || Cb <= 0 || (Ca & 7) || (Cb & 7) || ((Ca + Cb) & 15)) {
@@ -629,5 +821,5 @@ extern "C" int r3d_blend_cat_to_split(const float* a, int a_format, int Ca, cons
     if ((a_format != R3D_FMT_NCHW && a_format != R3D_FMT_CB8) || (b_format != R3D_FMT_NCHW && b_format != R3D_FMT_CB8)) {
         set_error("blend_cat_to_split: inputs must be NCHW or CB8 (a %d, b %d)", a_format, b_format); return R3D_ERR_INVALID_ARG;
     }
-    return blend_cat_to_split_f16x3(a, a_format, Ca, b, b_format, Cb, mask, N, H, W, y_split, (hipStream_t)stream);
+    return blend_cat_to_split_f16x3(a, a_format, Ca, b, b_format, Cb, mask, N, H, W, y_split, next_scale, next_scale_stride, (hipStream_t)stream);
 }

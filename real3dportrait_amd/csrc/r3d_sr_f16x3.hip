@@ -40,9 +40,31 @@ __device__ __forceinline__ void split1(float v, _Float16& hi, _Float16& lo)
     lo = (_Float16)(v - (float)hi);
 }
 
+// ---- per-cout statistics of a weight tensor [CoutReal][row_len]: tail = {2^-kw[co], sum|w[co]|} (ConvTail), padded couts -> {1, 0}.
+// kw[co] = weight_row_exp(max|w[co]|): the row is stored as w * 2^kw (max in [2^10, 2^11)) and the conv epilogue multiplies by
+// 2^-kw -- exact, and it makes the fp16 hi/lo split independent of the overall magnitude of the trained weights.
+__global__ void weight_row_stats_kernel(const float* __restrict__ w, int row_len, int CoutReal, int Cout, float* __restrict__ tail)
+{
+    const int co = blockIdx.x;
+    const ConvTail T = conv_tail_layout(Cout);
+    float mx = 0.f, l1 = 0.f;
+    if (co < CoutReal)
+        for (int i = threadIdx.x; i < row_len; i += blockDim.x) { const float v = fabsf(w[(size_t)co * row_len + i]); mx = fmaxf(mx, v); l1 += v; }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, d)); l1 += __shfl_xor(l1, d); }
+    __shared__ float rm[4], rl[4];
+    if ((threadIdx.x & 63) == 0) { rm[threadIdx.x >> 6] = mx; rl[threadIdx.x >> 6] = l1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mx = fmaxf(fmaxf(rm[0], rm[1]), fmaxf(rm[2], rm[3]));
+        tail[T.winv + co] = pow2f(-weight_row_exp(mx));
+        tail[T.l1 + co] = rl[0] + rl[1] + rl[2] + rl[3];
+    }
+}
+
 // ---- weights: [tap][ci/8][hi|lo][cout] x 8 halfs (hi and lo in separate 16-byte planes: conflict-free ds_read_b128) ----
 __global__ void sr_prepack_f16_kernel(const float* __restrict__ w, int CiReal, int CoutReal, int ntaps, int Ci, int Cout,
-                                      uint4* __restrict__ out)
+                                      const float* __restrict__ winv, uint4* __restrict__ out)
 {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // (tap, chunk, cout) in the PADDED index space
     const size_t total = (size_t)ntaps * (Ci / 8) * Cout;
@@ -50,11 +72,12 @@ __global__ void sr_prepack_f16_kernel(const float* __restrict__ w, int CiReal, i
     const int co = e % Cout;
     const int chunk = (e / Cout) % (Ci / 8);
     const int tap = (int)(e / Cout / (Ci / 8));
+    const float ws = 1.0f / winv[co];                                    // 2^kw[co] (exact reciprocal of a power of two)
     h8 hi, lo;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int ci = chunk * 8 + j;
-        const float v = (co < CoutReal && ci < CiReal) ? w[((size_t)co * CiReal + ci) * ntaps + tap] : 0.f;
+        const float v = (co < CoutReal && ci < CiReal) ? w[((size_t)co * CiReal + ci) * ntaps + tap] * ws : 0.f;
         _Float16 a, b; split1(v, a, b); hi[j] = a; lo[j] = b;
     }
     const size_t base = ((size_t)tap * (Ci / 8) + chunk) * 2 * Cout + co;
@@ -113,6 +136,7 @@ struct Conv2Args {
     float* y_nchw; size_t y_nchw_stride_n;                 // fp32 NCHW output or null
     uint4* y_split; size_t y_split_stride_n;               // SPLIT output scaled by next_scale (null = 1), or null
     const float* next_scale; size_t next_scale_stride_n;
+    unsigned* y_absmax;                                    // [N] max |activated output| (uint bits of a non-negative float) or null
     const float* wrgb; size_t wrgb_stride_n; float* rgb_partial; size_t rgbp_stride_n;   // toRGB partials [Cout/128][3][OH*OW] or null
     int Cin, Cout, CoutReal, H, W, nphase;    // Cout: padded to 128 (weight layout); CoutReal: channels that exist in the outputs
     int act; float act_slope, act_gain, clamp; // act: leaky-relu(slope) * gain after the bias; clamp < 0: off
@@ -133,6 +157,7 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
     const int row0 = wn * 2 * NT;
     // ---- epilogue ------------------------------------------------------------------------------------------------
     const bool do_rgb = FULL_EPI && a.rgb_partial != nullptr;
+    float vmax = 0.f;
     float rgbp[NT][3];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { rgbp[nt][0] = 0.f; rgbp[nt][1] = 0.f; rgbp[nt][2] = 0.f; }
@@ -175,6 +200,7 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
                     rgbp[nt][2] += v[0] * w2.x + v[1] * w2.y + v[2] * w2.z + v[3] * w2.w;
                 }
                 if (!inside) continue;
+                if (FULL_EPI && a.y_absmax) vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
                 const size_t pix = ((size_t)(co >> 3) * a.OH + oy) * a.OW + ox;
                 if (Yf) *reinterpret_cast<float4*>(Yf + pix * 8 + (co & 7)) = make_float4(v[0], v[1], v[2], v[3]);
                 if (Yn) {
@@ -194,6 +220,11 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
                     dst[2 * oplane] = *reinterpret_cast<uint2*>(&lo);
                 }
             }
+    }
+    if (FULL_EPI && a.y_absmax) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d));
+        if (lane == 0 && vmax > 0.f) atomicMax(a.y_absmax + n, __float_as_uint(vmax));
     }
     if (do_rgb) {
         // add the two lane halves (disjoint couts); each 64-cout wave row stores its own partial plane
@@ -595,7 +626,7 @@ struct UpArgs {
     float clamp;
 };
 
-__global__ void sr_prepack_up_kernel(const float* __restrict__ w, int Cin, int Cout, uint4* __restrict__ out)
+__global__ void sr_prepack_up_kernel(const float* __restrict__ w, int Cin, int Cout, const float* __restrict__ winv, uint4* __restrict__ out)
 {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t total = (size_t)9 * (Cin / 8) * Cout * 2;
@@ -610,7 +641,7 @@ __global__ void sr_prepack_up_kernel(const float* __restrict__ w, int Cin, int C
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int ci = st * 16 + hc * 8 + j;
-        _Float16 a, b; split1(w[((size_t)cout * Cin + ci) * 9 + t], a, b);
+        _Float16 a, b; split1(w[((size_t)cout * Cin + ci) * 9 + t] * (1.0f / winv[cout]), a, b);
         v8[j] = hl ? b : a;
     }
     out[e] = *reinterpret_cast<uint4*>(&v8);
@@ -909,9 +940,12 @@ __global__ void fir_bias_act_split_kernel(const float* __restrict__ T, size_t t_
 }
 
 // ---- image finalize: img_out = upsample2d(img_in) + bias + sum_m partial[m]  (networks_stylegan2.py:463-469) ----
+// img_u8 != null: the block is the last one of the network and the frame leaves as uint8 HWC: clamp(-1,1) (the
+// `sr_image.clamp(-1, 1)` of triplane.py:136) then ((x + 1) / 2 * 255).int() (inference/real3d_infer.py:472,518-522), fused here
+// so that the fp32 image makes no extra round trip; img_out may then be null.
 __global__ void rgb_finalize_kernel(const float* __restrict__ img_prev, const float* __restrict__ partial, size_t part_stride_n,
                                     int nparts, const float* __restrict__ brgb, size_t vec_stride_n,
-                                    float* __restrict__ img_out, int H, int W, float clamp, int up)
+                                    float* __restrict__ img_out, uint8_t* __restrict__ img_u8, int H, int W, float clamp, int up)
 {
     const int n = blockIdx.y;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -923,6 +957,7 @@ __global__ void rgb_finalize_kernel(const float* __restrict__ img_prev, const fl
     if (y & 1) { r0 = ky; r1 = ky + 1; wy0 = 0.75f; wy1 = 0.25f; } else { r0 = ky - 1; r1 = ky; wy0 = 0.25f; wy1 = 0.75f; }
     if (xx & 1) { c0 = kx; c1 = kx + 1; wx0 = 0.75f; wx1 = 0.25f; } else { c0 = kx - 1; c1 = kx; wx0 = 0.25f; wx1 = 0.75f; }
     const bool vr0 = r0 >= 0 && r0 < Hh, vr1 = r1 >= 0 && r1 < Hh, vc0 = c0 >= 0 && c0 < Wh, vc1 = c1 >= 0 && c1 < Wh;
+    float rgb[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         float t = brgb[(size_t)n * vec_stride_n + c];
@@ -939,7 +974,13 @@ __global__ void rgb_finalize_kernel(const float* __restrict__ img_prev, const fl
         } else {
             upv = img_prev[((size_t)n * 3 + c) * H * W + p];        // SynthesisBlockNoUp: img.add_(y) at the same resolution
         }
-        img_out[((size_t)n * 3 + c) * H * W + p] = upv + t;
+        rgb[c] = upv + t;
+        if (img_out) img_out[((size_t)n * 3 + c) * H * W + p] = rgb[c];
+    }
+    if (img_u8) {
+        uint8_t* d = img_u8 + ((size_t)n * H * W + p) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) d[c] = frame_u8(rgb[c]);
     }
 }
 
@@ -962,7 +1003,8 @@ __global__ void cb8_to_nchw2_kernel(const float* __restrict__ src, float* __rest
 // directly in the SPLIT format of fuse_head_torso_convs / fuse_fg_bg_convs' first conv (no fp32 concat tensor).
 // blockIdx.y < Ca/8: channels of a (scaled by m); else channels of b (scaled by 1 - m).
 __global__ void blend_cat_to_split_kernel(const float* __restrict__ a, int a_cb8, int Ca, const float* __restrict__ b, int b_cb8, int Cb,
-                                          const float* __restrict__ mask, uint4* __restrict__ dst, int HW)
+                                          const float* __restrict__ mask, uint4* __restrict__ dst, int HW,
+                                          const float* __restrict__ next_scale, size_t next_scale_stride_n)
 {
     const int n = blockIdx.z, cb = blockIdx.y;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -984,7 +1026,10 @@ __global__ void blend_cat_to_split_kernel(const float* __restrict__ a, int a_cb8
     }
     h8 hi, lo;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) { _Float16 x0, x1; split1(v[c] * sc, x0, x1); hi[c] = x0; lo[c] = x1; }
+    for (int c = 0; c < 8; ++c) {
+        const float ns = next_scale ? next_scale[n * next_scale_stride_n + cb * 8 + c] : 1.f;   // consumer's input multiplier (2^e)
+        _Float16 x0, x1; split1(v[c] * sc * ns, x0, x1); hi[c] = x0; lo[c] = x1;
+    }
     const size_t plane = (size_t)((Ca + Cb) / 8) * HW;
     uint4* d = dst + (size_t)n * 2 * plane + (size_t)cb * HW + p;
     d[0] = *reinterpret_cast<uint4*>(&hi);
@@ -992,12 +1037,12 @@ __global__ void blend_cat_to_split_kernel(const float* __restrict__ a, int a_cb8
 }
 
 int blend_cat_to_split_f16x3(const float* a, int a_format, int Ca, const float* b, int b_format, int Cb, const float* mask,
-                             int N, int H, int W, void* y_split, hipStream_t st)
+                             int N, int H, int W, void* y_split, const float* next_scale, size_t next_scale_stride, hipStream_t st)
 {
     ProfScope ps(R3D_PROF_LAYOUT, st);
     hipLaunchKernelGGL(blend_cat_to_split_kernel, dim3((H * W + 255) / 256, (Ca + Cb) / 8, N), dim3(256), 0, st,
                        a, a_format == R3D_FMT_CB8 ? 1 : 0, Ca, b, b_format == R3D_FMT_CB8 ? 1 : 0, Cb, mask,
-                       reinterpret_cast<uint4*>(y_split), H * W);
+                       reinterpret_cast<uint4*>(y_split), H * W, next_scale, next_scale_stride);
     return check_launch("blend_cat_to_split");
 }
 
@@ -1059,17 +1104,23 @@ int upsample2x_bilinear_f16x3(const float* x_cb8, int N, int C, int H, int W, vo
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------
+// prepacked = conv0 (plain layout) ++ conv1 ++ conv0 (fused up-conv layout) ++ ConvTail(conv0) ++ ConvTail(conv1)
 int sr_prepack_f16x3(int Cin, int Cout, const float* c0_w, const float* c1_w, void* prepacked, hipStream_t st)
 {
     float* out = reinterpret_cast<float*>(prepacked);
     const size_t m0 = (size_t)9 * (Cin / 8) * Cout, m1 = (size_t)9 * (Cout / 8) * Cout;
+    const ConvTail T = conv_tail_layout(Cout);
+    float* tail0 = out + (size_t)2 * 9 * Cin * Cout + (size_t)9 * Cout * Cout;
+    float* tail1 = tail0 + T.total;
+    hipLaunchKernelGGL(weight_row_stats_kernel, dim3(Cout), dim3(256), 0, st, c0_w, Cin * 9, Cout, Cout, tail0);
+    hipLaunchKernelGGL(weight_row_stats_kernel, dim3(Cout), dim3(256), 0, st, c1_w, Cout * 9, Cout, Cout, tail1);
     hipLaunchKernelGGL(sr_prepack_f16_kernel, dim3((unsigned)((m0 + 255) / 256)), dim3(256), 0, st, c0_w, Cin, Cout, 9, Cin, Cout,
-                       reinterpret_cast<uint4*>(out));
+                       tail0 + T.winv, reinterpret_cast<uint4*>(out));
     hipLaunchKernelGGL(sr_prepack_f16_kernel, dim3((unsigned)((m1 + 255) / 256)), dim3(256), 0, st, c1_w, Cout, Cout, 9, Cout, Cout,
-                       reinterpret_cast<uint4*>(out + (size_t)9 * Cin * Cout));
+                       tail1 + T.winv, reinterpret_cast<uint4*>(out + (size_t)9 * Cin * Cout));
     // conv0 again in the fused up-conv layout (SynthesisBlock; the plain layout above serves SynthesisBlockNoUp)
     const size_t mu = (size_t)9 * (Cin / 8) * Cout * 2;
-    hipLaunchKernelGGL(sr_prepack_up_kernel, dim3((unsigned)((mu + 255) / 256)), dim3(256), 0, st, c0_w, Cin, Cout,
+    hipLaunchKernelGGL(sr_prepack_up_kernel, dim3((unsigned)((mu + 255) / 256)), dim3(256), 0, st, c0_w, Cin, Cout, tail0 + T.winv,
                        reinterpret_cast<uint4*>(out + (size_t)9 * Cin * Cout + (size_t)9 * Cout * Cout));
     return check_launch("sr_block_prepack");
 }
@@ -1095,7 +1146,7 @@ static int tiles_of(int H, int W) { return ((W + F_TILE_W - 1) / F_TILE_W) * ((H
 int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int Cin, int Cout, int Hin, int Win, int up,
                            const void* x, int x_format, const float* img, float clamp,
                            void* x_out, int x_out_format, const float* next_scale, size_t next_scale_stride,
-                           float* img_out, void* workspace, size_t workspace_bytes, hipStream_t st)
+                           float* img_out, uint8_t* img_u8, float* x_absmax, void* workspace, size_t workspace_bytes, hipStream_t st)
 {
     (void)workspace_bytes;
     const SrStyleLayout L = sr_style_layout(Cin, Cout);
@@ -1115,7 +1166,7 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
     if (x_format != R3D_FMT_SPLIT) {
         ProfScope ps(R3D_PROF_LAYOUT, st);
         hipLaunchKernelGGL(to_split_kernel, dim3((Hin * Win + 255) / 256, Cin / 8, N), dim3(256), 0, st,
-                           reinterpret_cast<const float*>(x), x_format == R3D_FMT_CB8 ? 1 : 0, pk + L.s0, L.total, xin, Cin, Cin, Hin * Win);
+                           reinterpret_cast<const float*>(x), x_format == R3D_FMT_CB8 ? 1 : 0, pk + L.s0f, L.total, xin, Cin, Cin, Hin * Win);
         xs = xin;
     }
     static const int fused_up = getenv("R3D_UPCONV") ? atoi(getenv("R3D_UPCONV")) : 1;   // A/B switch: 0 = per-phase T-conv + FIR kernel
@@ -1124,7 +1175,7 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
         UpArgs u = {};
         u.x = xs; u.x_stride_n = (size_t)Cin / 8 * Hin * Win * 2;
         u.wp = reinterpret_cast<const uint4*>(wpk + (size_t)9 * Cin * Cout + (size_t)9 * Cout * Cout);
-        u.out_scale = pk + L.d0; u.bias = pk + L.b0; u.next_scale = pk + L.s1; u.vec_stride_n = L.total;
+        u.out_scale = pk + L.d0f; u.bias = pk + L.b0; u.next_scale = pk + L.s1f; u.vec_stride_n = L.total;
         u.y = y0; u.y_stride_n = (size_t)Cout / 8 * OH * OW * 2;
         u.Cin = Cin; u.Cout = Cout; u.H = Hin; u.W = Win;
         u.tiles_x = (Win + U_TILE - 1) / U_TILE;
@@ -1140,7 +1191,7 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
             Conv2Args a = {};
             a.x = xs; a.x_stride_n = (size_t)Cin / 8 * Hin * Win * 2;
             a.wp = reinterpret_cast<const uint4*>(wpk);
-            a.out_scale = pk + L.d0; a.out_scale_stride_n = L.total;
+            a.out_scale = pk + L.d0f; a.out_scale_stride_n = L.total;
             a.y_f32 = T; a.y_f32_stride_n = 4 * pplane; a.OH = PH; a.OW = PW;
             a.Cin = Cin; a.Cout = Cout; a.CoutReal = Cout; a.H = Hin; a.W = Win; a.nphase = 4; a.act = 0; a.clamp = -1.f;
             sr_fill_tconv_phases(a.ph, Hin, Win);
@@ -1155,15 +1206,15 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
         }
         ProfScope ps(R3D_PROF_UPCONV, st);
         hipLaunchKernelGGL(fir_bias_act_split_kernel, dim3((Hin * Win + 255) / 256, Cout / 8, N), dim3(256), 0, st,
-                           T, 4 * pplane, pk + L.b0, pk + L.s1, L.total, y0, (size_t)Cout / 8 * OH * OW * 2, Cout, Hin, Win, clamp);
+                           T, 4 * pplane, pk + L.b0, pk + L.s1f, L.total, y0, (size_t)Cout / 8 * OH * OW * 2, Cout, Hin, Win, clamp);
     } else {
         // ---- conv0 of SynthesisBlockNoUp (superresolution.py:159-258): plain modulated 3x3 conv -> SPLIT for conv1 ----
         Conv2Args a = {};
         a.x = xs; a.x_stride_n = (size_t)Cin / 8 * Hin * Win * 2;
         a.wp = reinterpret_cast<const uint4*>(wpk);
-        a.out_scale = pk + L.d0; a.out_scale_stride_n = L.total; a.bias = pk + L.b0; a.bias_stride_n = L.total;
+        a.out_scale = pk + L.d0f; a.out_scale_stride_n = L.total; a.bias = pk + L.b0; a.bias_stride_n = L.total;
         a.OH = OH; a.OW = OW;
-        a.y_split = y0; a.y_split_stride_n = (size_t)Cout / 8 * OH * OW * 2; a.next_scale = pk + L.s1; a.next_scale_stride_n = L.total;
+        a.y_split = y0; a.y_split_stride_n = (size_t)Cout / 8 * OH * OW * 2; a.next_scale = pk + L.s1f; a.next_scale_stride_n = L.total;
         a.Cin = Cin; a.Cout = Cout; a.CoutReal = Cout; a.H = Hin; a.W = Win; a.nphase = 1;
         a.act = 1; a.act_slope = 0.2f; a.act_gain = 1.4142135623730951f; a.clamp = clamp;
         sr_fill_conv3x3_phase(a.ph, OH, OW);
@@ -1175,7 +1226,7 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
         Conv2Args a = {};
         a.x = y0; a.x_stride_n = (size_t)Cout / 8 * OH * OW * 2;
         a.wp = reinterpret_cast<const uint4*>(wpk + (size_t)9 * Cin * Cout);
-        a.out_scale = pk + L.d1; a.out_scale_stride_n = L.total; a.bias = pk + L.b1; a.bias_stride_n = L.total;
+        a.out_scale = pk + L.d1f; a.out_scale_stride_n = L.total; a.bias = pk + L.b1; a.bias_stride_n = L.total;
         a.OH = OH; a.OW = OW;
         if (x_out && x_out_format == R3D_FMT_CB8) { a.y_f32 = reinterpret_cast<float*>(x_out); a.y_f32_stride_n = (size_t)Cout * OH * OW; }
         if (x_out && x_out_format == R3D_FMT_NCHW) { a.y_nchw = reinterpret_cast<float*>(x_out); a.y_nchw_stride_n = (size_t)Cout * OH * OW; }
@@ -1183,6 +1234,7 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
             a.y_split = reinterpret_cast<uint4*>(x_out); a.y_split_stride_n = (size_t)Cout / 8 * OH * OW * 2;
             a.next_scale = next_scale; a.next_scale_stride_n = next_scale_stride;
         }
+        a.y_absmax = reinterpret_cast<unsigned*>(x_absmax);
         a.wrgb = pk + L.wrgb; a.wrgb_stride_n = L.total; a.rgb_partial = rgbp; a.rgbp_stride_n = (size_t)(Cout / 64) * 3 * OH * OW;
         a.Cin = Cout; a.Cout = Cout; a.CoutReal = Cout; a.H = OH; a.W = OW; a.nphase = 1;
         a.act = 1; a.act_slope = 0.2f; a.act_gain = 1.4142135623730951f; a.clamp = clamp;
@@ -1194,7 +1246,7 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
     {
         ProfScope ps(R3D_PROF_TORGB, st);
         hipLaunchKernelGGL(rgb_finalize_kernel, dim3((OH * OW + 255) / 256, N), dim3(256), 0, st, img, rgbp,
-                           (size_t)(Cout / 64) * 3 * OH * OW, Cout / 64, pk + L.brgb, L.total, img_out, OH, OW, clamp, up);
+                           (size_t)(Cout / 64) * 3 * OH * OW, Cout / 64, pk + L.brgb, L.total, img_out, img_u8, OH, OW, clamp, up);
     }
     return check_launch("sr_block_forward(f16x3)");
 }
@@ -1205,16 +1257,20 @@ static inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 
 size_t conv_prepacked_bytes_f16x3(int Cin, int Cout, int ksize)
 {
-    return (size_t)(ksize * ksize) * pad_to(Cin, 16) * pad_to(Cout, BLOCK_M) * sizeof(float);
+    const int Co = pad_to(Cout, BLOCK_M);
+    return ((size_t)(ksize * ksize) * pad_to(Cin, 16) * Co + conv_tail_layout(Co).total) * sizeof(float);
 }
 
+// prepacked = split weights (rows pre-scaled by 2^kw[co]) ++ ConvTail {2^-kw[co], sum|w[co]|}
 int conv_prepack_f16x3(const float* w, int Cin, int Cout, int ksize, void* prepacked, hipStream_t st)
 {
     const int Ci = pad_to(Cin, 16), Co = pad_to(Cout, BLOCK_M), nt = ksize * ksize;
     const size_t m = (size_t)nt * (Ci / 8) * Co;
+    float* tail = reinterpret_cast<float*>(prepacked) + (size_t)nt * Ci * Co;
     ProfScope ps(R3D_PROF_PACK, st);
+    hipLaunchKernelGGL(weight_row_stats_kernel, dim3(Co), dim3(256), 0, st, w, Cin * nt, Cout, Co, tail);
     hipLaunchKernelGGL(sr_prepack_f16_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, w, Cin, Cout, nt, Ci, Co,
-                       reinterpret_cast<uint4*>(prepacked));
+                       tail + conv_tail_layout(Co).winv, reinterpret_cast<uint4*>(prepacked));
     return check_launch("conv_prepack");
 }
 
@@ -1223,30 +1279,33 @@ size_t conv_workspace_bytes_f16x3(int N, int Cin, int H, int W)
     return align256((size_t)N * pad_to(Cin, 16) * H * W * 4) + 256;
 }
 
-int conv_forward_f16x3(const void* prepacked, int N, int Cin, int Cout, int H, int W, int ksize,
-                       const void* x, int x_format, const float* in_scale, size_t in_scale_stride,
-                       const float* out_scale, size_t out_scale_stride, const float* bias, size_t bias_stride,
-                       int act, float slope, float gain, float clamp,
-                       void* y, int y_format, const float* next_scale, size_t next_scale_stride,
+// scales: per-sample ConvScales vectors written by r3d_conv_chain_scales (in_vec: multiplier of the fp32 -> SPLIT input
+// conversion; out_vec: epilogue multiplier 2^-kw[co] * 2^-e_in); bias [Cout] shared by the batch (or null)
+int conv_forward_f16x3(const void* prepacked, const float* scales, size_t scales_stride, const float* bias,
+                       int N, int Cin, int Cout, int H, int W, int ksize,
+                       const void* x, int x_format, int act, float slope, float gain, float clamp,
+                       void* y, int y_format, const float* next_scale, size_t next_scale_stride, float* y_absmax,
                        void* workspace, hipStream_t st)
 {
     const int Ci = pad_to(Cin, 16), Co = pad_to(Cout, BLOCK_M);
+    const ConvScales S = conv_scales_layout(Ci, Co);
     const uint4* xs = reinterpret_cast<const uint4*>(x);
     if (x_format != R3D_FMT_SPLIT) {
         uint4* xin = reinterpret_cast<uint4*>(workspace);
         ProfScope ps(R3D_PROF_LAYOUT, st);
         hipLaunchKernelGGL(to_split_kernel, dim3((H * W + 255) / 256, Ci / 8, N), dim3(256), 0, st,
-                           reinterpret_cast<const float*>(x), x_format == R3D_FMT_CB8 ? 1 : 0, in_scale, in_scale_stride, xin, Ci, Cin, H * W);
+                           reinterpret_cast<const float*>(x), x_format == R3D_FMT_CB8 ? 1 : 0, scales + S.in_vec, scales_stride, xin, Ci, Cin, H * W);
         xs = xin;
     }
     Conv2Args a = {};
     a.x = xs; a.x_stride_n = (size_t)Ci / 8 * H * W * 2;
     a.wp = reinterpret_cast<const uint4*>(prepacked);
-    a.out_scale = out_scale; a.out_scale_stride_n = out_scale_stride; a.bias = bias; a.bias_stride_n = bias_stride;
+    a.out_scale = scales + S.out_vec; a.out_scale_stride_n = scales_stride; a.bias = bias; a.bias_stride_n = 0;
     a.OH = H; a.OW = W;
     if (y_format == R3D_FMT_CB8) { a.y_f32 = reinterpret_cast<float*>(y); a.y_f32_stride_n = (size_t)Cout * H * W; }
     else if (y_format == R3D_FMT_NCHW) { a.y_nchw = reinterpret_cast<float*>(y); a.y_nchw_stride_n = (size_t)Cout * H * W; }
     else { a.y_split = reinterpret_cast<uint4*>(y); a.y_split_stride_n = (size_t)Cout / 8 * H * W * 2; a.next_scale = next_scale; a.next_scale_stride_n = next_scale_stride; }
+    a.y_absmax = reinterpret_cast<unsigned*>(y_absmax);
     a.Cin = Ci; a.Cout = Co; a.CoutReal = Cout; a.H = H; a.W = W; a.nphase = 1;
     a.act = act; a.act_slope = slope; a.act_gain = gain; a.clamp = clamp;
     if (ksize == 3) sr_fill_conv3x3_phase(a.ph, H, W);

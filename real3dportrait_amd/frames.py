@@ -97,7 +97,9 @@ class ClipRenderer:
         nhwc._r3d_nhwc = True
         return nhwc
 
-    def render_image(self, t):
+    def _features(self, t):
+        """Frame t up to the 128^2 feature image (the SR input) + its known bound (|x| <= 1.002 by construction)."""
+        from .superresolution import const_bound
         G = self.G
         G.renderer.seed = frame_seed(self.base_seed, t)
         cam = self.cameras[t: t + 1]
@@ -105,16 +107,28 @@ class ClipRenderer:
         feat, depth, wsum, valid = G.renderer(self.planes_for(t), G.decoder, o, d, G.rendering_kwargs)
         R = G.neural_rendering_resolution
         fimg = feat.permute(0, 2, 1).reshape(1, 32, R, R).contiguous()
-        return G.superresolution(fimg[:, :3], fimg, self.ws, noise_mode="none")
+        fimg._r3d_bound = const_bound(1.01, 1, fimg.device)
+        return fimg
+
+    def render_image(self, t):
+        fimg = self._features(t)
+        return self.G.superresolution(fimg[:, :3], fimg, self.ws, noise_mode="none")
 
     def render_u8(self, t, out=None):
+        """Frame t as uint8 [H,W,3] (into `out` [1,H,W,3] if given).  With the f16x3 SR the clamp -> uint8 conversion of
+        real3d_infer.py:472,518-522 is fused into the last block's toRGB kernel (no fp32 image round trip)."""
         lib = self._lib.load()
-        img = self.render_image(t).contiguous()
-        N, _, H, W = img.shape
+        fimg = self._features(t)
+        sr = self.G.superresolution
         if out is None:
-            out = torch.empty(N, H, W, 3, dtype=torch.uint8, device=img.device)
-        self._lib.check(lib.r3d_frames_to_u8(self._lib.ptr(img), N, H, W, self._lib.ptr(out), self._lib.stream_ptr()),
-                        "frames_to_u8")
+            out = torch.empty(1, 512, 512, 3, dtype=torch.uint8, device=fimg.device)
+        if sr.block0.precision == "f16x3":
+            sr(fimg[:, :3], fimg, self.ws, noise_mode="none", _u8_out=out, _need_img=False)
+        else:
+            img = sr(fimg[:, :3], fimg, self.ws, noise_mode="none").contiguous()
+            N, _, H, W = img.shape
+            self._lib.check(lib.r3d_frames_to_u8(self._lib.ptr(img), N, H, W, self._lib.ptr(out), self._lib.stream_ptr()),
+                            "frames_to_u8")
         return out[0] if out.dim() == 4 else out
 
 
@@ -133,10 +147,15 @@ class PipelinedClipRenderer:
         i = self._k % len(self.streams)
         self._k += 1
         st = self.streams[i]
-        if self._k <= len(self.streams):
-            st.wait_stream(torch.cuda.current_stream())       # inputs prepared on the caller's stream
+        cur = torch.cuda.current_stream()
+        # every frame: inputs prepared on / ring slots still being read from the caller's stream (a gather, a consumer) are
+        # ordered before this frame's kernels (an event wait; cheap)
+        st.wait_stream(cur)
         with torch.cuda.stream(st):
-            return self.clips[i].render_u8(t, out=out)
+            res = self.clips[i].render_u8(t, out=out)
+        if out is None:
+            res.record_stream(cur)                            # allocated in the side stream's pool, consumed by the caller
+        return res
 
     def sync(self):
         cur = torch.cuda.current_stream()

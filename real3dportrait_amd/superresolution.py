@@ -4,11 +4,23 @@ Mirrors (same constructor arguments, state_dict keys/shapes, forward signatures)
   * SynthesisLayer / ToRGBLayer parameter containers   modules/eg3ds/models/networks_stylegan2.py:286-373
   * SynthesisBlock.forward(x, img, ws, **kw) -> (x, img)  networks_stylegan2.py:377-476 (architecture 'skip',
     in_channels != 0, fp32, noise_mode in {'none','const' with zero strength})
+  * SynthesisBlockNoUp                                   modules/eg3ds/models/superresolution.py:159-258
   * SuperresolutionHybrid8XDC.forward(rgb, x, ws, **kw) -> rgb   modules/eg3ds/models/superresolution.py:331-359
+  * torch.nn.Conv2d / nn.Sequential stacks of the torso model and to_plane_cnn   (Conv2d, ConvStack)
 
 A checkpoint saved from the reference loads with strict=True (keys: block{0,1}.{conv0,conv1,torgb}.
 {weight,bias,affine.weight,affine.bias}, conv*.noise_strength, buffers noise_const / resample_filter).
+
+Inference only: inputs are detached and no autograd graph is built (the reference runs this path under torch.no_grad(),
+inference/real3d_infer.py:435,479).
+
+fp16 range management (f16x3 precision, see include/r3d_hip.h "fp16 range management"): every activation that travels in
+the SPLIT fp16 hi/lo format is stored times an exact power of two derived from a guaranteed bound on max|x|.  The bound
+of an fp32 input is measured on the device (r3d_absmax) unless the tensor carries `_r3d_bound` (a device float [N]
+tensor); it is propagated through a chain of layers by one r3d_chain_fold launch per forward.  A SPLIT tensor is tagged
+with the module it was scaled for (`_r3d_for`): only that module may consume it.
 """
+import ctypes
 import os
 
 import numpy as np
@@ -19,11 +31,72 @@ import torch.nn.functional as F
 from . import _lib
 from .volumetric_rendering import _FC, _f32c
 
+_SQRT2 = float(np.sqrt(2.0))
+
 
 def _setup_filter():
     f = torch.tensor([1.0, 3.0, 3.0, 1.0])
     f = torch.outer(f, f)
     return f / f.sum()          # upfirdn2d.setup_filter([1,3,3,1]) (ops/upfirdn2d.py:72-116)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# bounds
+# ---------------------------------------------------------------------------------------------------------------------
+class _BoundMeter:
+    """max|x| per sample of an fp32 device tensor (r3d_absmax), two alternating result slots so that no memset launch is
+    needed (each call clears the slot of the next one)."""
+
+    def __init__(self):
+        self._slots = None
+        self._k = 0
+
+    def __call__(self, x):
+        lib = _lib.load()
+        N = x.shape[0]
+        if self._slots is None or self._slots.shape[1] != N or self._slots.device != x.device:
+            self._slots = torch.zeros(2, N, device=x.device, dtype=torch.float32)
+            self._k = 0
+        cur, nxt = self._slots[self._k & 1], self._slots[(self._k + 1) & 1]
+        self._k += 1
+        _lib.check(lib.r3d_absmax(_lib.ptr(x), x.numel() // N, N, cur.data_ptr(), nxt.data_ptr(), _lib.stream_ptr()), "absmax")
+        return cur
+
+
+_CONST_BOUNDS = {}
+
+
+def const_bound(value, N, device):
+    """A constant bound tensor (cached): for inputs whose range is known by construction, e.g. the renderer's feature image
+    (|x| <= 1.002: sigmoid(y) * 1.002 - 0.001 composited with weights summing to <= 1, then * 2 - 1)."""
+    key = (float(value), int(N), str(device))
+    t = _CONST_BOUNDS.get(key)
+    if t is None:
+        t = torch.full((N,), float(value), device=device, dtype=torch.float32)
+        _CONST_BOUNDS[key] = t
+    return t
+
+
+def bound_of(x, meter):
+    """Bound of an fp32 activation: its `_r3d_bound` tag if present, else measured on the device."""
+    b = getattr(x, "_r3d_bound", None)
+    if b is not None:
+        return b
+    return meter(x)
+
+
+def chain_fold(ops, N, ext, zero=()):
+    """One r3d_chain_fold launch: ops = list of _lib.ChainOp, ext = list of device float[N] bound tensors, zero = absmax slots
+    (device float[N]) that kernels launched after this fold will measure into (`_x_absmax` / `_y_absmax`)."""
+    lib = _lib.load()
+    assert 1 <= len(ops) <= _lib.CHAIN_MAX_OPS and len(ext) <= _lib.CHAIN_MAX_EXT and len(zero) <= _lib.CHAIN_MAX_ZERO
+    arr = (_lib.ChainOp * len(ops))(*ops)
+    for t in list(ext) + list(zero):
+        assert t.is_cuda and t.dtype == torch.float32 and t.numel() >= N and t.is_contiguous()
+    ptrs = (ctypes.c_void_p * max(1, len(ext)))(*[t.data_ptr() for t in ext])
+    zptrs = (ctypes.c_void_p * max(1, len(zero)))(*[t.data_ptr() for t in zero])
+    _lib.check(lib.r3d_chain_fold(ctypes.cast(arr, ctypes.c_void_p), len(ops), N, ctypes.cast(ptrs, ctypes.c_void_p), len(ext),
+                                  ctypes.cast(zptrs, ctypes.c_void_p), len(zero), _lib.stream_ptr()), "chain_fold")
 
 
 class SynthesisLayer(nn.Module):
@@ -62,8 +135,8 @@ class SynthesisBlock(nn.Module):
     architecture 'skip', up=2 conv0 + conv1 + toRGB, fp32.
 
     forward(x, img, ws, ...) -> (x, img) like the reference.  `x` may be NCHW (reference layout) or a
-    channel-blocked tensor produced by a previous block (tagged `_r3d_cb8`); the returned x is
-    channel-blocked by default when `self.blocked_output` (used inside SuperresolutionHybrid8XDC) and
+    channel-blocked tensor produced by a previous block (tagged `_r3d_fmt`); the returned x is
+    channel-blocked / SPLIT when `self.out_format` says so (used inside SuperresolutionHybrid8XDC) and
     NCHW otherwise (drop-in use, e.g. sr_with_ref.py:83,124)."""
 
     _UP = 1        # 1: conv0 up=2 + upsample2d RGB skip; 0: SynthesisBlockNoUp
@@ -98,7 +171,10 @@ class SynthesisBlock(nn.Module):
         self._prepacked = None
         self._prepack_key = None
         self._styles = None
+        self._styles_key = None
+        self._styles_ws = None         # keeps the ws tensor of the cached styles alive (its address cannot be recycled)
         self._workspace = None
+        self._meter = _BoundMeter()
 
     def _buf(self, name, nbytes, dev):
         t = getattr(self, name)
@@ -109,21 +185,22 @@ class SynthesisBlock(nn.Module):
 
     _FMT = {"none": -1, "nchw": 0, "cb8": 1, "split": 2}
 
-    def prepare(self, ws, dev=None):
-        """Static weight re-layout (cached on parameter versions) + per-forward style/demodulation vectors for
-        `ws` [N,3,w_dim].  Returns (prepacked, styles) device buffers; styles starts with the conv0 style vector
-        (what a producer needs to emit this block's input in SPLIT format)."""
+    def _clamp(self):
+        return -1.0 if self.conv_clamp is None else float(self.conv_clamp)
+
+    def prepare(self, ws, dev=None, ws_key=None):
+        """Static weight re-layout (cached on parameter versions) + the per-sample style / demodulation vectors for
+        `ws` [N,3,w_dim] (cached on the identity + version of `ws_key`, default `ws` itself, and the parameter versions:
+        a clip renders every frame with the same ws).  Returns (prepacked, styles) device buffers.  The FOLDED vectors the
+        f16x3 kernels read are written by `fold()` / chain_fold, every forward."""
         lib = _lib.load()
-        ws = _f32c(ws)
-        N = ws.shape[0]
-        dev = ws.device if dev is None else dev
         Cin, Cout = self.in_channels, self.out_channels
-        assert ws.shape[1] == self.num_conv + self.num_torgb and ws.shape[2] == self.w_dim, ws.shape
         st = _lib.stream_ptr()
         c0, c1, tr = self.conv0, self.conv1, self.torgb
-        keep = [_f32c(t) for t in (c0.weight, c0.bias, c0.affine.weight, c0.affine.bias,
-                                   c1.weight, c1.bias, c1.affine.weight, c1.affine.bias,
-                                   tr.weight, tr.bias, tr.affine.weight, tr.affine.bias)]
+        params = (c0.weight, c0.bias, c0.affine.weight, c0.affine.bias, c1.weight, c1.bias, c1.affine.weight, c1.affine.bias,
+                  tr.weight, tr.bias, tr.affine.weight, tr.affine.bias)
+        keep = [_f32c(t) for t in params]
+        dev = keep[0].device if dev is None else dev
         prec = {"f32": 0, "f16x3": 1}[self.precision]
         key = (keep[0].data_ptr(), c0.weight._version, keep[4].data_ptr(), c1.weight._version, str(dev), prec)
         if self._prepack_key != key:
@@ -131,16 +208,39 @@ class SynthesisBlock(nn.Module):
             _lib.check(lib.r3d_sr_block_prepack(Cin, Cout, _lib.ptr(keep[0]), _lib.ptr(keep[4]), _lib.ptr(pre), prec, st),
                        "sr_block_prepack")
             self._prepack_key = key
-        styles = self._buf("_styles", int(lib.r3d_sr_block_styles_bytes(N, Cin, Cout)), dev)
-        _lib.check(lib.r3d_sr_block_styles(_lib.ptr(ws), N, self.w_dim, Cin, Cout, *[_lib.ptr(t) for t in keep],
-                                           _lib.ptr(styles), st), "sr_block_styles")
-        return self._prepacked, styles
+        src = ws if ws_key is None else ws_key
+        N = ws.shape[0]
+        skey = (id(src), src._version, tuple(src.shape), N, str(dev)) + tuple((t.data_ptr(), p._version) for t, p in zip(keep, params))
+        if self._styles_key != skey or self._styles_ws is not src:
+            ws = _f32c(ws)
+            assert ws.shape[1] == self.num_conv + self.num_torgb and ws.shape[2] == self.w_dim, ws.shape
+            styles = self._buf("_styles", int(lib.r3d_sr_block_styles_bytes(N, Cin, Cout)), dev)
+            _lib.check(lib.r3d_sr_block_styles(_lib.ptr(ws), N, self.w_dim, Cin, Cout, *[_lib.ptr(t) for t in keep],
+                                               _lib.ptr(styles), st), "sr_block_styles")
+            self._styles_key, self._styles_ws = skey, src
+        return self._prepacked, self._styles
 
     def styles_stride(self):
         return int(_lib.load().r3d_sr_block_styles_bytes(1, self.in_channels, self.out_channels)) // 4
 
+    def in_scale(self):
+        """(device float view, per-sample stride): the folded conv0 style vector = what a producer of this block's SPLIT
+        input multiplies by (start of the styles buffer)."""
+        return self._styles.view(torch.float32), self.styles_stride()
+
+    def chain_op(self, src_a=-1, src_b=_lib.CHAIN_SRC_NONE, tail=False):
+        """tail=True: re-fold only the conv1 operand from a MEASURED max|block input| (R3D_CHAIN_SR_BLOCK_TAIL)."""
+        return _lib.ChainOp(kind=_lib.CHAIN_SR_BLOCK_TAIL if tail else _lib.CHAIN_SR_BLOCK, Cin=self.in_channels, Cout=self.out_channels, ksize=3, act=1, gain=_SQRT2,
+                            clamp=self._clamp(), src_a=src_a, src_b=src_b, scales=self._styles.data_ptr(), prepacked=None, bias=None)
+
+    def bound_out(self, N):
+        """Device view [N] of the bound on this block's output x written by the last fold (valid until the next fold)."""
+        lib = _lib.load()
+        off = int(lib.r3d_sr_block_bound_offset(self.in_channels, self.out_channels))
+        return self._styles.view(torch.float32).as_strided((N,), (self.styles_stride(),), off)
+
     def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, noise_mode="random",
-                _prepared=None, _next=None, **layer_kwargs):
+                _prepared=None, _next=None, _folded=False, _u8_out=None, _need_img=True, _x_absmax=None, **layer_kwargs):
         lib = _lib.load()
         if noise_mode == "random" or (noise_mode == "const" and
                                       (float(self.conv0.noise_strength) != 0 or float(self.conv1.noise_strength) != 0)):
@@ -149,7 +249,16 @@ class SynthesisBlock(nn.Module):
         if img is None:
             raise NotImplementedError("img=None (first block of a synthesis network) is not on the SR path")
         x_fmt = getattr(x, "_r3d_fmt", "nchw")
-        x = x.contiguous() if x_fmt == "split" else _f32c(x)
+        if x_fmt == "split":
+            if getattr(x, "_r3d_for", None) is not self:
+                raise RuntimeError("SPLIT activation was scaled for a different consumer")
+            _folded = True
+            x = x.contiguous()
+        else:
+            bx = getattr(x, "_r3d_bound", None)
+            x = _f32c(x)
+            if bx is not None:
+                x._r3d_bound = bx
         img = _f32c(img)
         N = img.shape[0]
         Hin, Win = img.shape[-2], img.shape[-1]
@@ -158,29 +267,35 @@ class SynthesisBlock(nn.Module):
         st = _lib.stream_ptr()
         prec = {"f32": 0, "f16x3": 1}[self.precision]
         pre, styles = _prepared if _prepared is not None else self.prepare(ws, dev)
+        if prec == 1 and not _folded:
+            chain_fold([self.chain_op(-1)], N, [bound_of(x, self._meter)])
         need = int(lib.r3d_sr_block_workspace_bytes(N, Cin, Cout, Hin, Win))
         work = self._buf("_workspace", need, dev)
         OH, OW = (2 * Hin, 2 * Win) if self._UP else (Hin, Win)
-        img_out = torch.empty(N, 3, OH, OW, device=dev, dtype=torch.float32)
+        img_out = torch.empty(N, 3, OH, OW, device=dev, dtype=torch.float32) if (_need_img or _u8_out is None) else None
         out_fmt = self.out_format if self.return_x else "none"
         next_scale, next_stride = None, 0
         if out_fmt == "none":
             x_out = None
         elif out_fmt == "split":
-            assert _next is not None, "out_format='split' needs the consumer's styles (scaled hand-off)"
-            next_scale, next_stride = _next
+            assert _next is not None, "out_format='split' needs the consumer (its folded in-multiplier)"
+            next_scale, next_stride = _next.in_scale()
             x_out = torch.empty(N, 2, Cout // 8, OH, OW, 8, device=dev, dtype=torch.float16)
         elif out_fmt == "cb8":
             x_out = torch.empty(N, Cout // 8, OH, OW, 8, device=dev, dtype=torch.float32)
         else:
             x_out = torch.empty(N, Cout, OH, OW, device=dev, dtype=torch.float32)
-        clamp = -1.0 if self.conv_clamp is None else float(self.conv_clamp)
         _lib.check(lib.r3d_sr_block_forward(_lib.ptr(pre), _lib.ptr(styles), N, Cin, Cout, Hin, Win, self._UP,
-                                            _lib.ptr(x), self._FMT[x_fmt], _lib.ptr(img), clamp, _lib.ptr(x_out), self._FMT[out_fmt],
-                                            _lib.ptr(next_scale), next_stride, _lib.ptr(img_out), prec,
+                                            _lib.ptr(x), self._FMT[x_fmt], _lib.ptr(img), self._clamp(), _lib.ptr(x_out), self._FMT[out_fmt],
+                                            _lib.ptr(next_scale), next_stride, _lib.ptr(img_out), _lib.ptr(_u8_out), _lib.ptr(_x_absmax), prec,
                                             _lib.ptr(work), need, st), "sr_block_forward")
-        if x_out is not None and out_fmt != "nchw":
-            x_out._r3d_fmt = out_fmt
+        if x_out is not None:
+            if out_fmt != "nchw":
+                x_out._r3d_fmt = out_fmt
+            if out_fmt == "split":
+                x_out._r3d_for = _next
+            elif prec == 1:
+                x_out._r3d_bound = self.bound_out(N)
         return x_out, img_out
 
 
@@ -213,77 +328,141 @@ class Conv2d(nn.Module):
         self._prepacked = None
         self._prepack_key = None
         self._workspace = None
+        self._scales = None
+        self._bias32 = None
+        self._meter = _BoundMeter()
 
     _buf = SynthesisBlock._buf
     _FMT = SynthesisBlock._FMT
 
-    def forward(self, x, negative_slope=None, out_format="nchw"):
-        """negative_slope: fuse a following torch.nn.LeakyReLU(negative_slope); out_format 'nchw' | 'cb8' | 'split'."""
+    def prepare(self, N, dev):
+        """Static weight re-layout (cached on the parameter version) and this call's scales buffer."""
         lib = _lib.load()
-        x_fmt = getattr(x, "_r3d_fmt", "nchw")
-        x = x.contiguous() if x_fmt == "split" else _f32c(x)
         Cin, Cout, k = self.in_channels, self.out_channels, self.kernel_size[0]
-        if x_fmt == "nchw":
-            N, C, H, W = x.shape
-        elif x_fmt == "cb8":
-            N, C, H, W = x.shape[0], x.shape[1] * 8, x.shape[2], x.shape[3]
-        else:
-            N, C, H, W = x.shape[0], x.shape[2] * 8, x.shape[3], x.shape[4]
-        if C != Cin:
-            raise RuntimeError("Conv2d: expected input with %d channels, got %d" % (Cin, C))
-        dev = x.device
-        st = _lib.stream_ptr()
         w = _f32c(self.weight)
         key = (w.data_ptr(), self.weight._version, str(dev))
         if self._prepack_key != key:
             pre = self._buf("_prepacked", int(lib.r3d_conv_prepacked_bytes(Cin, Cout, k)), dev)
-            _lib.check(lib.r3d_conv_prepack(_lib.ptr(w), Cin, Cout, k, _lib.ptr(pre), st), "conv_prepack")
+            _lib.check(lib.r3d_conv_prepack(_lib.ptr(w), Cin, Cout, k, _lib.ptr(pre), _lib.stream_ptr()), "conv_prepack")
             self._prepack_key = key
+        self._bias32 = _f32c(self.bias) if self.bias is not None else None
+        self._buf("_scales", int(lib.r3d_conv_scales_bytes(N, Cin, Cout)), dev)
+
+    def in_scale(self):
+        N1 = int(_lib.load().r3d_conv_scales_bytes(1, self.in_channels, self.out_channels)) // 4
+        return self._scales.view(torch.float32), N1
+
+    def chain_op(self, src_a=-1, src_b=_lib.CHAIN_SRC_NONE, negative_slope=None):
+        return _lib.ChainOp(kind=_lib.CHAIN_CONV, Cin=self.in_channels, Cout=self.out_channels, ksize=self.kernel_size[0],
+                            act=0 if negative_slope is None else 1, gain=1.0, clamp=-1.0, src_a=src_a, src_b=src_b,
+                            scales=self._scales.data_ptr(), prepacked=self._prepacked.data_ptr(),
+                            bias=None if self._bias32 is None else self._bias32.data_ptr())
+
+    def bound_out(self, N):
+        lib = _lib.load()
+        off = int(lib.r3d_conv_scales_bound_offset(self.in_channels, self.out_channels))
+        return self._scales.view(torch.float32).as_strided((N,), (self.in_scale()[1],), off)
+
+    @staticmethod
+    def _shape(x, x_fmt):
+        if x_fmt == "nchw":
+            return x.shape
+        if x_fmt == "cb8":
+            return x.shape[0], x.shape[1] * 8, x.shape[2], x.shape[3]
+        return x.shape[0], x.shape[2] * 8, x.shape[3], x.shape[4]
+
+    def forward(self, x, negative_slope=None, out_format="nchw", _next=None, _folded=False, _y_absmax=None):
+        """negative_slope: fuse a following torch.nn.LeakyReLU(negative_slope); out_format 'nchw' | 'cb8' | 'split'
+        ('split' needs `_next`, the consumer module, folded by the caller in the same chain)."""
+        lib = _lib.load()
+        x_fmt = getattr(x, "_r3d_fmt", "nchw")
+        if x_fmt == "split":
+            if getattr(x, "_r3d_for", None) is not self:
+                raise RuntimeError("SPLIT activation was scaled for a different consumer")
+            _folded = True
+            x = x.contiguous()
+        else:
+            bx = getattr(x, "_r3d_bound", None)
+            x = _f32c(x)
+            if bx is not None:
+                x._r3d_bound = bx
+        Cin, Cout, k = self.in_channels, self.out_channels, self.kernel_size[0]
+        N, C, H, W = self._shape(x, x_fmt)
+        if C != Cin:
+            raise RuntimeError("Conv2d: expected input with %d channels, got %d" % (Cin, C))
+        dev = x.device
+        st = _lib.stream_ptr()
+        if not _folded:
+            self.prepare(N, dev)
+            chain_fold([self.chain_op(-1, negative_slope=negative_slope)], N, [bound_of(x, self._meter)])
         need = int(lib.r3d_conv_workspace_bytes(N, Cin, H, W))
         work = self._buf("_workspace", need, dev) if x_fmt != "split" else None
+        next_scale, next_stride = None, 0
         if out_format == "split":
+            assert _next is not None, "out_format='split' needs the consumer (its folded in-multiplier)"
+            next_scale, next_stride = _next.in_scale()
             y = torch.empty(N, 2, Cout // 8, H, W, 8, device=dev, dtype=torch.float16)
         elif out_format == "cb8":
             y = torch.empty(N, Cout // 8, H, W, 8, device=dev, dtype=torch.float32)
         else:
             y = torch.empty(N, Cout, H, W, device=dev, dtype=torch.float32)
-        b = _f32c(self.bias) if self.bias is not None else None
         act = 0 if negative_slope is None else 1
-        _lib.check(lib.r3d_conv_forward(_lib.ptr(self._prepacked), N, Cin, Cout, H, W, k, _lib.ptr(x), self._FMT[x_fmt],
-                                        None, 0, None, 0, _lib.ptr(b), 0, act, float(negative_slope or 0.0), 1.0, -1.0,
-                                        _lib.ptr(y), self._FMT[out_format], None, 0, _lib.ptr(work), need if work is not None else 0, st),
-                   "conv_forward")
+        _lib.check(lib.r3d_conv_forward(_lib.ptr(self._prepacked), _lib.ptr(self._scales), _lib.ptr(self._bias32), N, Cin, Cout, H, W, k,
+                                        _lib.ptr(x), self._FMT[x_fmt], act, float(negative_slope or 0.0), 1.0, -1.0,
+                                        _lib.ptr(y), self._FMT[out_format], _lib.ptr(next_scale), next_stride, _lib.ptr(_y_absmax),
+                                        _lib.ptr(work), need if work is not None else 0, st), "conv_forward")
         if out_format != "nchw":
             y._r3d_fmt = out_format
+        if out_format == "split":
+            y._r3d_for = _next
+        else:
+            y._r3d_bound = self.bound_out(N)
         return y
 
 
-def upsample2x_bilinear(x, out_format="split"):
+def upsample2x_bilinear(x, out_format="split", _next=None):
     """torch.nn.UpsamplingBilinear2d(scale_factor=2.) (align_corners=True) on a channel-blocked fp32 activation
-    (r3d_upsample2x_bilinear); output 'split' (input of the next conv) or 'cb8'."""
+    (r3d_upsample2x_bilinear); output 'split' (input of the conv `_next`, already folded) or 'cb8'."""
     lib = _lib.load()
     assert getattr(x, "_r3d_fmt", None) == "cb8", "upsample2x_bilinear takes the 'cb8' output of a Conv2d"
+    bx = getattr(x, "_r3d_bound", None)
     x = x.contiguous()
     N, C8, H, W, _ = x.shape
+    next_scale, next_stride = None, 0
     if out_format == "split":
+        assert _next is not None
+        next_scale, next_stride = _next.in_scale()
         y = torch.empty(N, 2, C8, 2 * H, 2 * W, 8, device=x.device, dtype=torch.float16)
     else:
         y = torch.empty(N, C8, 2 * H, 2 * W, 8, device=x.device, dtype=torch.float32)
-    _lib.check(lib.r3d_upsample2x_bilinear(_lib.ptr(x), N, C8 * 8, H, W, _lib.ptr(y), SynthesisBlock._FMT[out_format], None, 0,
-                                           _lib.stream_ptr()), "upsample2x_bilinear")
+    _lib.check(lib.r3d_upsample2x_bilinear(_lib.ptr(x), N, C8 * 8, H, W, _lib.ptr(y), SynthesisBlock._FMT[out_format],
+                                           _lib.ptr(next_scale), next_stride, _lib.stream_ptr()), "upsample2x_bilinear")
     y._r3d_fmt = out_format
+    if out_format == "split":
+        y._r3d_for = _next
+    elif bx is not None:
+        y._r3d_bound = bx          # a convex combination does not raise the bound
     return y
 
 
-def blend_cat(a, b, mask):
-    """cat([a * mask, b * (1 - mask)], dim=1) (sr_with_ref.py:104,114,126,136) written directly as the SPLIT input of the
-    next Conv2d / ConvStack (r3d_blend_cat_to_split).  a, b: NCHW fp32 or 'cb8'-tagged tensors; mask [N,1,H,W]."""
+_BLEND_METERS = {}
+
+
+def blend_cat(a, b, mask, consumer, ws=None, _folded_head=None):
+    """cat([a * mask, b * (1 - mask)], dim=1) (sr_with_ref.py:104,114,126,136) written directly as the SPLIT input of
+    `consumer` (a ConvStack / Conv2d / SynthesisBlock[NoUp]; for a block pass its `ws` [N,3,w_dim]): the consumer chain is folded
+    here from max(bound(a), bound(b)) (mask in [0,1]), then r3d_blend_cat_to_split multiplies by its in-multiplier.
+    a, b: NCHW fp32 or 'cb8'-tagged tensors; mask [N,1,H,W].  _folded_head: the consumer's first module when the caller has
+    already folded it (inside a larger chain)."""
     lib = _lib.load()
 
     def desc(t):
         fmt = getattr(t, "_r3d_fmt", "nchw")
         assert fmt in ("nchw", "cb8"), fmt
+        bt = getattr(t, "_r3d_bound", None)
         t = _f32c(t)
+        if bt is not None:
+            t._r3d_bound = bt
         if fmt == "nchw":
             return t, 0, t.shape[1], t.shape[0], t.shape[2], t.shape[3]
         return t, 1, t.shape[1] * 8, t.shape[0], t.shape[2], t.shape[3]
@@ -291,11 +470,38 @@ def blend_cat(a, b, mask):
     b, fb, Cb, Nb, Hb, Wb = desc(b)
     mask = _f32c(mask)
     assert (N, H, W) == (Nb, Hb, Wb) and tuple(mask.shape) == (N, 1, H, W), (a.shape, b.shape, mask.shape)
+    if _folded_head is not None:
+        head = _folded_head
+    else:
+        meters = _BLEND_METERS.setdefault(id(consumer), (_BoundMeter(), _BoundMeter()))
+        head = consumer.fold_for_input(N, a.device, [bound_of(a, meters[0]), bound_of(b, meters[1])], ws=ws)
+    ns, stride = head.in_scale()
     y = torch.empty(N, 2, (Ca + Cb) // 8, H, W, 8, device=a.device, dtype=torch.float16)
     _lib.check(lib.r3d_blend_cat_to_split(_lib.ptr(a), fa, Ca, _lib.ptr(b), fb, Cb, _lib.ptr(mask), N, H, W, _lib.ptr(y),
-                                          _lib.stream_ptr()), "blend_cat_to_split")
+                                          _lib.ptr(ns), stride, _lib.stream_ptr()), "blend_cat_to_split")
     y._r3d_fmt = "split"
+    y._r3d_for = head
     return y
+
+
+def _fold_single(module, N, dev, bounds, ws=None, negative_slope=None):
+    """Fold one module (Conv2d or SynthesisBlock) whose input bound is the max of `bounds` (1 or 2 device tensors)."""
+    if isinstance(module, SynthesisBlock):
+        module.prepare(ws, dev)
+        op = module.chain_op(-1, -2 if len(bounds) > 1 else _lib.CHAIN_SRC_NONE)
+    else:
+        module.prepare(N, dev)
+        op = module.chain_op(-1, -2 if len(bounds) > 1 else _lib.CHAIN_SRC_NONE, negative_slope=negative_slope)
+    chain_fold([op], N, bounds)
+    return module
+
+
+def _block_fold_for_input(self, N, dev, bounds, ws=None):
+    assert ws is not None, "folding a SynthesisBlock needs its ws"
+    return _fold_single(self, N, dev, bounds, ws=ws)
+
+
+SynthesisBlock.fold_for_input = _block_fold_for_input
 
 
 class ConvStack(nn.Sequential):
@@ -323,9 +529,10 @@ class ConvStack(nn.Sequential):
                 raise NotImplementedError("ConvStack: unsupported module %s" % type(m).__name__)
         return cls(*mods)
 
-    def forward(self, x):
+    def _plan(self):
+        """[(conv, negative_slope, upsample_after)] in execution order."""
         mods = list(self)
-        i = 0
+        plan, i = [], 0
         while i < len(mods):
             m = mods[i]
             if not isinstance(m, Conv2d):
@@ -333,17 +540,66 @@ class ConvStack(nn.Sequential):
             slope, step = None, 1
             if i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU):
                 slope, step = mods[i + 1].negative_slope, 2
-            nxt = mods[i + step] if i + step < len(mods) else None
-            if isinstance(nxt, nn.UpsamplingBilinear2d):
+            up = i + step < len(mods) and isinstance(mods[i + step], nn.UpsamplingBilinear2d)
+            if up:
                 if m.out_channels % 16 or i + step + 1 >= len(mods):
                     raise NotImplementedError("ConvStack: UpsamplingBilinear2d must sit between two convs with C % 16 == 0")
-                x = upsample2x_bilinear(m(x, negative_slope=slope, out_format="cb8"), "split")
                 step += 1
-            else:
-                fmt = "split" if (nxt is not None and m.out_channels % 16 == 0) else "nchw"
-                x = m(x, negative_slope=slope, out_format=fmt)
+            plan.append((m, slope, up))
             i += step
+        return plan
+
+    def chain_ops(self, N, dev, src_a=-1, src_b=_lib.CHAIN_SRC_NONE, base=0):
+        """The stack's layers as r3d_chain_fold ops: the first reads (src_a, src_b), layer k reads op base + k - 1.  Returns
+        (ops, first conv, index of the last op)."""
+        plan = self._plan()
+        ops = []
+        for k, (m, slope, _) in enumerate(plan):
+            m.prepare(N, dev)
+            ops.append(m.chain_op(src_a, src_b, negative_slope=slope) if k == 0 else m.chain_op(base + k - 1, negative_slope=slope))
+        return ops, plan[0][0], base + len(plan) - 1
+
+    def fold_for_input(self, N, dev, bounds, ws=None):
+        """Fold the whole stack (one launch) for an input whose bound is the max of `bounds`; returns the first conv (the module a
+        producer of the stack's SPLIT input scales for)."""
+        ops, head, _ = self.chain_ops(N, dev, -1, -2 if len(bounds) > 1 else _lib.CHAIN_SRC_NONE)
+        chain_fold(ops, N, bounds)
+        return head
+
+    def forward(self, x, out_format="nchw", _next=None, _y_absmax=None):
+        """out_format of the LAST conv: 'nchw' (default, reference layout) | 'cb8' | 'split' (scaled for `_next`, already folded);
+        _y_absmax: device float[N] slot the last conv measures max|y| into (zeroed by a preceding fold)."""
+        plan = self._plan()
+        x_fmt = getattr(x, "_r3d_fmt", "nchw")
+        if x_fmt == "split":
+            if getattr(x, "_r3d_for", None) is not plan[0][0]:
+                raise RuntimeError("SPLIT activation was scaled for a different consumer")
+        else:
+            if not hasattr(self, "_meter_obj"):
+                object.__setattr__(self, "_meter_obj", _BoundMeter())
+            bx = getattr(x, "_r3d_bound", None)
+            x = _f32c(x)
+            if bx is not None:
+                x._r3d_bound = bx
+            self.fold_for_input(x.shape[0], x.device, [bound_of(x, self._meter_obj)])
+        for k, (m, slope, up) in enumerate(plan):
+            nxt = plan[k + 1][0] if k + 1 < len(plan) else None
+            if up:
+                x = upsample2x_bilinear(m(x, negative_slope=slope, out_format="cb8", _folded=True), "split", _next=nxt)
+            elif nxt is not None and m.out_channels % 16 == 0:
+                x = m(x, negative_slope=slope, out_format="split", _next=nxt, _folded=True)
+            elif nxt is not None:
+                raise NotImplementedError("ConvStack: inner layers need out_channels % 16 == 0")
+            else:
+                x = m(x, negative_slope=slope, out_format=out_format, _next=_next, _folded=True, _y_absmax=_y_absmax)
         return x
+
+
+def _conv_fold_for_input(self, N, dev, bounds, ws=None):
+    return _fold_single(self, N, dev, bounds)
+
+
+Conv2d.fold_for_input = _conv_fold_for_input
 
 
 class SuperresolutionHybrid8XDC(nn.Module):
@@ -364,23 +620,40 @@ class SuperresolutionHybrid8XDC(nn.Module):
         self.block1 = SynthesisBlock(256, 128, w_dim=512, resolution=512, img_channels=3, is_last=True,
                                      use_fp16=False, conv_clamp=None, **block_kwargs)
         self.block1.return_x = False           # forward() only returns rgb (:359)
+        self._meter = _BoundMeter()
+        self._ws3 = None                       # (ws, version, ws[:, -1:].repeat(1, 3, 1)): a clip renders every frame with one ws
 
-    def forward(self, rgb, x, ws, **block_kwargs):
-        ws = ws[:, -1:, :].repeat(1, 3, 1)
+    def _ws_last3(self, ws):
+        c = self._ws3
+        if c is not None and c[0] is ws and c[1] == ws._version:
+            return c[2]
+        ws3 = ws[:, -1:, :].repeat(1, 3, 1)          # :349
+        self._ws3 = (ws, ws._version, ws3)
+        return ws3
+
+    def forward(self, rgb, x, ws, _u8_out=None, _need_img=True, **block_kwargs):
+        """_u8_out: optional uint8 [N,512,512,3] tensor that receives clamp(-1,1) -> ((x+1)/2*255).int() of the result, fused
+        into the last block's toRGB kernel (the conversion real3d_infer.py:472,518-522 does per frame); with
+        _need_img=False the fp32 image is not materialised and None is returned."""
+        ws3 = self._ws_last3(ws)
         if x.shape[-1] != self.input_resolution:      # cold path, same ATen op as the reference (:351-355)
             x = F.interpolate(x, size=(self.input_resolution, self.input_resolution), mode="bilinear",
                               align_corners=False, antialias=self.sr_antialias)
             rgb = F.interpolate(rgb, size=(self.input_resolution, self.input_resolution), mode="bilinear",
                                 align_corners=False, antialias=self.sr_antialias)
-        # block1's style vectors first: block0's conv1 epilogue emits its output already scaled by block1.conv0's
-        # styles and split into fp16 hi/lo planes (f16x3), so block1 stages its input with plain copies
-        self.block1.precision = self.block0.precision
-        prep1 = self.block1.prepare(ws)
-        if self.block0.precision == "f16x3":
-            self.block0.out_format = "split"
-            nxt = (prep1[1].view(torch.float32), self.block1.styles_stride())
+        b0, b1 = self.block0, self.block1
+        b1.precision = b0.precision
+        prep0 = b0.prepare(ws3, x.device, ws_key=ws)
+        prep1 = b1.prepare(ws3, x.device, ws_key=ws)
+        if b0.precision == "f16x3":
+            # one fold launch for both blocks; block0's conv1 epilogue then emits its output already multiplied by block1.conv0's
+            # folded styles and split into fp16 hi/lo planes, so block1 stages its input with plain copies
+            bx = getattr(x, "_r3d_bound", None)
+            x = _f32c(x)
+            chain_fold([b0.chain_op(-1), b1.chain_op(0)], x.shape[0], [bx if bx is not None else self._meter(x)])
+            b0.out_format, nxt = "split", b1
         else:
-            self.block0.out_format, nxt = "cb8", None
-        x, rgb = self.block0(x, rgb, ws, _next=nxt, **block_kwargs)
-        x, rgb = self.block1(x, rgb, ws, _prepared=prep1, **block_kwargs)
+            b0.out_format, nxt = "cb8", None
+        x, rgb = b0(x, rgb, ws3, _prepared=prep0, _next=nxt, _folded=True, **block_kwargs)
+        x, rgb = b1(x, rgb, ws3, _prepared=prep1, _folded=True, _u8_out=_u8_out, _need_img=_need_img, **block_kwargs)
         return rgb

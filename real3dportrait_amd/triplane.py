@@ -17,7 +17,7 @@ import copy
 import torch
 import torch.nn as nn
 
-from .superresolution import SuperresolutionHybrid8XDC, SynthesisBlock
+from .superresolution import SuperresolutionHybrid8XDC, SynthesisBlock, const_bound
 from .volumetric_rendering import ImportanceRenderer, OSGDecoder, RaySampler
 
 DEFAULT_HPARAMS = {           # egs/egs_bases/eg3d/base.yaml:20-44 (+ 'auto' limits as every os_avatar config sets)
@@ -57,56 +57,88 @@ class TriPlaneGenerator(nn.Module):
             channel_base=hparams["base_channel"], channel_max=hparams["max_channel"],
             fused_modconv_default="inference_only")
         self._last_planes = None
+        self._ones_ws = None
 
-    def synthesis(self, ws, camera, cond=None, update_emas=False, cache_backbone=False, use_cached_backbone=False,
-                  **synthesis_kwargs):
-        hparams = self.hparams
-        ret = {}
-        cam2world_matrix = camera[:, :16].view(-1, 4, 4)
-        intrinsics = camera[:, 16:25].view(-1, 3, 3)
-        R = self.neural_rendering_resolution
-        ray_origins, ray_directions = self.ray_sampler(cam2world_matrix, intrinsics, R)
-        N, M, _ = ray_origins.shape
+    # -- the reference's public surface (modules/eg3ds/models/triplane.py:73-163) -------------------------------------
+    def mapping(self, z, camera, cond=None, truncation_psi=0.7, truncation_cutoff=None, update_emas=False):
+        """triplane.py:73-88: the mapping network lives in the (cold, PyTorch) tri-plane producer."""
+        if self.backbone is None or not hasattr(self.backbone, "mapping"):
+            raise RuntimeError("mapping() needs a backbone with a mapping network (the StyleGAN2 producer is a cold encoder, out of scope)")
+        return self.backbone.mapping(z, camera * self.rendering_kwargs.get("c_scale", 0), truncation_psi=truncation_psi,
+                                     truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+
+    def _planes(self, ws, update_emas, cache_backbone, use_cached_backbone, synthesis_kwargs):
         if use_cached_backbone and self._last_planes is not None:
             planes = self._last_planes
+        elif self.backbone is None:
+            raise RuntimeError("no tri-plane producer: pass backbone=... or set _last_planes and use_cached_backbone=True")
         else:
-            if self.backbone is None:
-                raise RuntimeError("no tri-plane producer: pass backbone=... or set _last_planes and "
-                                   "use_cached_backbone=True")
             planes = self.backbone.synthesis(ws, update_emas=update_emas, **synthesis_kwargs)
         if cache_backbone:
             self._last_planes = planes
-        planes = planes.view(len(planes), 3, -1, planes.shape[-2], planes.shape[-1])
+        return planes.view(len(planes), 3, -1, planes.shape[-2], planes.shape[-1])
 
-        feature_samples, depth_samples, weights_samples, is_ray_valid = self.renderer(
-            planes, self.decoder, ray_origins, ray_directions, self.rendering_kwargs)
+    def _ray_images(self, planes, camera):
+        """Rays -> fused HIP renderer -> the 'raw' neural-rendered images [N,C,R,R] (triplane.py:96-127 / secc_img2plane.py:99-130)."""
+        R = self.neural_rendering_resolution
+        origins, directions = self.ray_sampler(camera[:, :16].view(-1, 4, 4), camera[:, 16:25].view(-1, 3, 3), R)
+        feat, depth, wsum, valid = self.renderer(planes, self.decoder, origins, directions, self.rendering_kwargs)   # [N, R*R, C]
+        N = feat.shape[0]
+        to_img = lambda t: t.transpose(1, 2).reshape(N, t.shape[-1], R, R)
+        images = {"feature": to_img(feat).contiguous(), "depth": to_img(depth), "weights": to_img(wsum).contiguous()}
+        if self.hparams.get("mask_invalid_rays", False):
+            # feature <- -1 and depth <- min valid depth on rays that miss the box (triplane.py:123-126), without the
+            # reference's host sync (.item()) and boolean indexing
+            keep = valid.reshape(N, 1, R, R)
+            d = images["depth"]
+            dmin = torch.where(keep, d, torch.full_like(d, float("inf"))).amin()
+            images["feature"] = torch.where(keep, images["feature"], torch.full_like(images["feature"], -1.0))
+            images["depth"] = torch.where(keep, d, dmin)
+        return images
 
-        feature_image = feature_samples.permute(0, 2, 1).reshape(N, feature_samples.shape[-1], R, R).contiguous()
-        depth_image = depth_samples.permute(0, 2, 1).reshape(N, 1, R, R)
-        if hparams.get("mask_invalid_rays", False):
-            mask = is_ray_valid.reshape(N, 1, R, R)
-            feature_image[~mask.repeat(1, feature_image.shape[1], 1, 1)] = -1
-            depth_image[~mask] = depth_image[mask].min().item()
-        rgb_image = feature_image[:, :3]
-        ws_to_sr = torch.ones_like(ws) if hparams["ones_ws_for_sr"] else ws
-        sr_image = self.superresolution(
-            rgb_image, feature_image, ws_to_sr, noise_mode=self.rendering_kwargs["superresolution_noise_mode"],
-            **{k: synthesis_kwargs[k] for k in synthesis_kwargs if k != "noise_mode"})
-        rgb_image = rgb_image.clamp(-1, 1)
-        sr_image = sr_image.clamp(-1, 1)
-        ret.update({"image": sr_image, "image_raw": rgb_image, "image_depth": depth_image,
-                    "image_feature": feature_image[:, 3:], "plane": planes, "weights_image":
-                    weights_samples.permute(0, 2, 1).reshape(N, 1, R, R)})
-        return ret
+    def _ws_for_sr(self, ws):
+        if not self.hparams["ones_ws_for_sr"]:
+            return ws
+        c = self._ones_ws
+        if c is None or c.shape != ws.shape or c.device != ws.device:
+            c = self._ones_ws = torch.ones_like(ws)       # one persistent tensor: the SR blocks cache their style vectors on it
+        return c
+
+    def synthesis(self, ws, camera, cond=None, update_emas=False, cache_backbone=False, use_cached_backbone=False,
+                  **synthesis_kwargs):
+        """triplane.py:90-138.  Returns the reference's keys plus 'weights_img' (the name the Real3D shells use,
+        secc_img2plane.py:132)."""
+        planes = self._planes(ws, update_emas, cache_backbone, use_cached_backbone, synthesis_kwargs)
+        im = self._ray_images(planes, camera)
+        feature = im["feature"]
+        # |feature| <= 1.002 by construction (sigmoid * 1.002 - 0.001 composited with weights summing to <= 1, then * 2 - 1):
+        # the SR's fp16 range fold uses this bound instead of measuring it
+        feature._r3d_bound = const_bound(1.01, feature.shape[0], feature.device)
+        sr_kwargs = {k: v for k, v in synthesis_kwargs.items() if k != "noise_mode"}
+        sr_image = self.superresolution(feature[:, :3], feature, self._ws_for_sr(ws),
+                                        noise_mode=self.rendering_kwargs["superresolution_noise_mode"], **sr_kwargs)
+        return {"image": sr_image.clamp(-1, 1), "image_raw": feature[:, :3].clamp(-1, 1), "image_depth": im["depth"],
+                "image_feature": feature[:, 3:], "plane": planes, "weights_img": im["weights"]}
+
+    def sample(self, coordinates, directions, z, camera, cond=None, truncation_psi=1, truncation_cutoff=None, update_emas=False,
+               **synthesis_kwargs):
+        """triplane.py:140-148."""
+        ws = self.mapping(z, camera, cond=cond, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+        return self.sample_mixed(coordinates, directions, ws, update_emas=update_emas, **synthesis_kwargs)
 
     def sample_mixed(self, coordinates, directions, ws, truncation_psi=1, truncation_cutoff=None, update_emas=False,
                      **synthesis_kwargs):
+        """triplane.py:150-156."""
         planes = self.backbone.synthesis(ws, update_emas=update_emas, **synthesis_kwargs)
-        planes = planes.view(len(planes), 3, 32, planes.shape[-2], planes.shape[-1])
+        planes = planes.view(len(planes), 3, -1, planes.shape[-2], planes.shape[-1])
         return self.renderer.run_model(planes, self.decoder, coordinates, directions, self.rendering_kwargs)
 
-    def forward(self, ws, camera, **kw):
-        return self.synthesis(ws, camera, **kw)
+    def forward(self, z, camera, cond=None, truncation_psi=1, truncation_cutoff=None, neural_rendering_resolution=None,
+                update_emas=False, cache_backbone=False, use_cached_backbone=False, **synthesis_kwargs):
+        """triplane.py:158-163: mapping -> synthesis."""
+        ws = self.mapping(z, camera, cond=cond, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+        return self.synthesis(ws, camera, cond=cond, update_emas=update_emas, cache_backbone=cache_backbone,
+                              use_cached_backbone=use_cached_backbone, **synthesis_kwargs)
 
 
 def _copy_sr_block(dst, src):
@@ -114,19 +146,38 @@ def _copy_sr_block(dst, src):
     return missing
 
 
-def patch_model(model):
-    """Swap the hot-path operators of a constructed reference model for the HIP ones (in place).
+def _reference_hparams(model):
+    """The reference keeps its configuration in one global dict (utils/commons/hparams.py) that its modules read at call time;
+    some shells also keep a copy as `self.hparams`."""
+    import sys
+    hp = {}
+    mod = sys.modules.get("utils.commons.hparams")
+    if mod is not None and isinstance(getattr(mod, "hparams", None), dict):
+        hp.update(mod.hparams)
+    if isinstance(getattr(model, "hparams", None), dict):
+        hp.update(model.hparams)
+    return hp
+
+
+def patch_model(model, fuse_warp_sr=True):
+    """Swap the hot-path operators of a constructed reference model for the HIP ones (in place).  INFERENCE ONLY: the HIP modules
+    detach their inputs and build no autograd graph (the reference runs this path under torch.no_grad(), real3d_infer.py:435,479).
 
     * model.ray_sampler  -> RaySampler            (created at img2plane_baseline.py:106 / triplane.py:38)
     * model.renderer     -> ImportanceRenderer    (img2plane_baseline.py:104-105 / triplane.py:36-37)
     * model.superresolution (vanilla SuperresolutionHybrid8XDC) -> HIP SuperresolutionHybrid8XDC, or, for the
       torso model whose superresolution is SuperresolutionHybrid8XDC_Warp (secc_img2plane_torso.py:10-11),
       its .block0 / .block1 (called at sr_with_ref.py:83,124 as block(x, img, ws, **kw) -> (x, img)), its torso / background
-      fusion stacks (nn.Sequential -> ConvStack, :24-63) and head_torso_block (-> SynthesisBlockNoUp).
+      fusion stacks (nn.Sequential -> ConvStack, :24-63) and head_torso_block (-> SynthesisBlockNoUp); with fuse mode 'v2' and
+      fuse_warp_sr=True its forward is replaced by the fused HIP evaluation (real3dportrait_amd/sr_with_ref.py).
+      With hparams weight_fuse=False the reference calls block1(x, None, ws) (sr_with_ref.py:161), which the HIP block does not
+      cover: block1 is then left untouched.
     * <backbone>.to_plane_cnn (segformer.py:691-700) -> ConvStack.
     Parameters are copied with strict key matching; the decoder module is left untouched (the renderer reads
     decoder.net[0|2].{weight,bias} directly)."""
+    import types
     dev = next(model.parameters()).device
+    hp = _reference_hparams(model)
     old_r = model.renderer
     new_r = ImportanceRenderer(hp=getattr(old_r, "hparams", None))
     new_r.triplane_feature_type = getattr(old_r, "triplane_feature_type", "triplane")
@@ -139,9 +190,10 @@ def patch_model(model):
         new_sr.load_state_dict(sr.state_dict(), strict=True)
         model.superresolution = new_sr
     else:
+        weight_fuse = bool(hp.get("weight_fuse", True))
         for name in ("block0", "block1"):
             old = getattr(sr, name, None)
-            if old is None or type(old).__name__ != "SynthesisBlock":
+            if old is None or type(old).__name__ != "SynthesisBlock" or (name == "block1" and not weight_fuse):
                 continue
             new = SynthesisBlock(old.in_channels, old.conv1.out_channels, w_dim=old.w_dim, resolution=old.resolution,
                                  img_channels=old.img_channels, is_last=old.is_last, use_fp16=False,
@@ -149,6 +201,13 @@ def patch_model(model):
             new.load_state_dict(old.state_dict(), strict=True)
             setattr(sr, name, new)
         _patch_fusion_stacks(sr, dev)
+        if (fuse_warp_sr and weight_fuse and hp.get("htbsr_head_weight_fuse_mode") == "v2" and hasattr(sr, "torso_model")
+                and type(getattr(sr, "head_torso_block", None)).__name__ == "SynthesisBlockNoUp"
+                and type(sr.head_torso_block).__module__.startswith("real3dportrait_amd")):
+            from . import sr_with_ref
+            sr._r3d_state = sr_with_ref.WarpSRState(
+                {k: hp.get(k) for k in ("weight_fuse", "htbsr_head_weight_fuse_mode", "htbsr_head_threshold", "torso_model_version")})
+            sr.forward = types.MethodType(sr_with_ref.forward_v2, sr)
     for owner in (getattr(model, "secc_img2plane_backbone", None), getattr(model, "img2plane_backbone", None)):
         _patch_sequential(owner, "to_plane_cnn", dev)       # per-frame plane producer tail (segformer.py:691-700)
     return model

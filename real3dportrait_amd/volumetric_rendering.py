@@ -115,7 +115,7 @@ class ImportanceRenderer(nn.Module):
         self.noise_mode = "torch"
         self.noise_override = None
         self.seed = 0
-        self._plane_cache = None       # (key, nhwc tensor)
+        self._plane_cache = None       # (source tensor, version, nhwc tensor)
         self._workspace = None
 
     # -- plane layout ---------------------------------------------------------------------------------
@@ -141,13 +141,16 @@ class ImportanceRenderer(nn.Module):
         return out
 
     def _planes_nhwc(self, planes):
+        """Channel-last copy of `planes`, cached for static planes.  The cache entry holds the SOURCE tensor itself and is valid
+        only for that very object at the same version: a freed tensor's address (and a fresh tensor's version 0) can be handed
+        to the next frame's planes by the caching allocator, so an address/version key alone would render stale planes."""
         if getattr(planes, "_r3d_nhwc", False):
             return planes
-        key = (planes.data_ptr(), planes._version, tuple(planes.shape), planes.device)
-        if self._plane_cache is not None and self._plane_cache[0] == key:
-            return self._plane_cache[1]
+        c = self._plane_cache
+        if c is not None and c[0] is planes and c[1] == planes._version:
+            return c[2]
         out = self.prepare_planes(planes)
-        self._plane_cache = (key, out)
+        self._plane_cache = (planes, planes._version, out)
         return out
 
     def _check_options(self, opts):

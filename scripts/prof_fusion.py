@@ -29,9 +29,9 @@ def step():
     x_torso = stacks["torso_encoder"](hid)
     x_bg = stacks["bg_encoder"](bg)
     rgb1 = rgb * alpha + rgb_t * (1 - alpha)
-    x1 = stacks["fuse_head_torso_convs"](blend_cat(x_head, x_torso, alpha))
+    x1 = stacks["fuse_head_torso_convs"](blend_cat(x_head, x_torso, alpha, stacks["fuse_head_torso_convs"]))
     x2, rgb2 = blk(x1, rgb1, ws, noise_mode="none")
-    return stacks["fuse_fg_bg_convs"](blend_cat(x2, x_bg, occ)), rgb2
+    return stacks["fuse_fg_bg_convs"](blend_cat(x2, x_bg, occ, stacks["fuse_fg_bg_convs"])), rgb2
 
 
 for _ in range(3):

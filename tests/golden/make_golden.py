@@ -295,8 +295,164 @@ def toplane_case(name, r=24):
     print(name, out.shape, float(secc.abs().mean()))
 
 
+def sr_cfg5_case(name):
+    """BASELINE config 5 (stress): the SR at 2x spatial size, 256^2 -> 512^2 -> 1024^2.  SuperresolutionHybrid8XDC itself asserts a
+    512 output (superresolution.py:334) and SynthesisBlock checks its input size against `resolution` (networks_stylegan2.py:447), so
+    the same two reference SynthesisBlocks are built with resolution 512 / 1024 (the convolutions are resolution-agnostic with
+    noise_mode='none'; SURVEY 8d cfg 5) and chained exactly like superresolution.py:348-359 does."""
+    seed = 45
+    params = synth.synth_sr_params(seed)
+    kw = dict(w_dim=512, img_channels=3, use_fp16=False, conv_clamp=None, channel_base=32768, channel_max=512,
+              fused_modconv_default="inference_only")
+    b0 = SynthesisBlock(32, 256, resolution=512, is_last=False, **kw).eval()
+    b1 = SynthesisBlock(256, 128, resolution=1024, is_last=True, **kw).eval()
+    load_block(b0, params[0])
+    load_block(b1, params[1])
+    x = synth.hash_unitvar(seed, (1, 32, 256, 256), stream=1)
+    rgb = x[:, :3].copy()
+    ws = torch.ones(1, 14, 512)[:, -1:, :].repeat(1, 3, 1)
+    with torch.no_grad():
+        x0, r0 = b0(torch.from_numpy(x), torch.from_numpy(rgb), ws, noise_mode="none")
+        x1, out = b1(x0, r0, ws, noise_mode="none")
+    out = out.numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=seed, strided=out[:, :, ::8, ::8], corner=out[:, :, :64, :64],
+                        tail=out[:, :, -48:, -48:], mid=out[:, :, 480:544, 480:544], absmean=np.float64(np.abs(out).mean()))
+    print(name, out.shape, float(np.abs(out).mean()))
+
+
+def fusion_full_case(name):
+    """fusion_case at the reference size 256 x 256 (sr_with_ref.py:101-123, fuse mode v2): exercises the multi-tile / Cin = 512
+    multi-stage paths.  Only strided slices and crops are stored."""
+    from modules.eg3ds.models.superresolution import SynthesisBlockNoUp
+    seed, R = 59, 256
+    stacks = {k: torch_stack(plan, synth.synth_conv_stack(seed, plan, 300 + 20 * i))
+              for i, (k, plan) in enumerate(synth.FUSION_STACKS.items())}
+    blk = SynthesisBlockNoUp(256, 256, w_dim=512, resolution=R, img_channels=3, is_last=False, use_fp16=False,
+                             conv_clamp=None, channel_base=32768, channel_max=512,
+                             fused_modconv_default="inference_only").eval()
+    load_block(blk, synth.synth_sr_block(seed, 256, 256, 512, 400))
+    t = lambda shape, s, g=1.0: torch.from_numpy(synth.hash_unitvar(seed, shape, stream=s) * np.float32(g))
+    x_head, hid, bg, rgb, rgb_torso = t((1, 256, R, R), 1), t((1, 64, R, R), 2), t((1, 3, R, R), 3, 0.5), t((1, 3, R, R), 4, 0.5), t((1, 3, R, R), 5, 0.5)
+    alpha = torch.from_numpy(synth.synth_noise(seed, (1, 1, R, R), stream=6))
+    occ = torch.from_numpy(synth.synth_noise(seed, (1, 1, R, R), stream=8))
+    ws = torch.from_numpy(np.ones((1, 3, 512), np.float32) + synth.hash_unitvar(seed, (1, 3, 512), stream=9) * np.float32(0.1))
+    with torch.no_grad():
+        x_torso = stacks["torso_encoder"](hid)
+        x_bg = stacks["bg_encoder"](bg)
+        rgb1 = rgb * alpha + rgb_torso * (1 - alpha)
+        x1 = stacks["fuse_head_torso_convs"](torch.cat([x_head * alpha, x_torso * (1 - alpha)], dim=1))
+        x2, rgb2 = blk(x1, rgb1.clone(), ws, noise_mode="none")
+        x3 = stacks["fuse_fg_bg_convs"](torch.cat([x2 * occ, x_bg * (1 - occ)], dim=1))
+    sl = lambda v: v.numpy()[:, ::16, ::8, ::8]
+    cr = lambda v: v.numpy()[:, ::32, 120:152, 232:]           # a crop that straddles tile borders and the right image edge
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=seed, R=R,
+                        x_torso=sl(x_torso), x_bg=sl(x_bg), x1=sl(x1), x2=sl(x2), x3=sl(x3), rgb2=rgb2.numpy()[:, :, ::4, ::4],
+                        x1_crop=cr(x1), x3_crop=cr(x3))
+    print(name, x3.shape, float(x3.abs().mean()), float(rgb2.abs().mean()))
+
+
+def toplane_full_case(name):
+    """toplane_case at the reference size 128^2 -> 256^2 (segformer.py:691-700,721-729 + secc_img2plane.py:76-77)."""
+    seed, r = 73, 128
+    plan = synth.TO_PLANE_CNN
+    params = synth.synth_conv_stack(seed, plan, 500)
+    mods = []
+    for i, ((ci, co, k, lrelu), (w, b)) in enumerate(zip(plan, params)):
+        if i == synth.TO_PLANE_CNN_UP_BEFORE:
+            mods.append(torch.nn.UpsamplingBilinear2d(scale_factor=2.))
+        conv = torch.nn.Conv2d(ci, co, k, 1, padding=1)
+        with torch.no_grad():
+            conv.weight.copy_(torch.from_numpy(w)); conv.bias.copy_(torch.from_numpy(b))
+        mods.append(conv)
+        if lrelu:
+            mods.append(torch.nn.LeakyReLU(negative_slope=0.01, inplace=True))
+    cnn = torch.nn.Sequential(*mods).eval()
+    feat = torch.from_numpy(synth.hash_unitvar(seed, (1, 256, r, r), stream=1))
+    cano = torch.from_numpy(synth.hash_unitvar(seed, (1, 3, 32, 2 * r, 2 * r), stream=2))
+    with torch.no_grad():
+        planes = cnn(feat)
+        planes = planes.view(len(planes), 3, -1, planes.shape[-2], planes.shape[-1])
+        pxy, pxz, pzy = torch.flip(planes[:, 0], [2]), torch.flip(planes[:, 1], [2]), torch.flip(planes[:, 2], [2, 3])
+        out = (cano + torch.stack([pxy, pxz, pzy], dim=1)).numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=seed, r=r, strided=out[:, :, :, ::8, ::8], corner=out[:, :, ::4, :40, :40],
+                        tail=out[:, :, ::4, -40:, -40:])
+    print(name, out.shape, float(np.abs(out).mean()))
+
+
+def synthesis_mask_case(name):
+    """TriPlaneGenerator.synthesis with hparams['mask_invalid_rays'] = True (triplane.py:123-126) and a camera pushed sideways so that a
+    large share of the rays misses the box."""
+    from utils.commons.hparams import set_hparams, hparams
+    set_hparams(os.path.join(REF, "egs/egs_bases/eg3d/base.yaml"), print_hparams=False)
+    hparams.update(ray_near="auto", ray_far="auto", ones_ws_for_sr=True, enable_rescale_plane_regulation=False, mask_invalid_rays=True)
+    G = TriPlaneGenerator().eval()
+    seed = 53
+    dec_np = synth.synth_decoder(seed, sigma_bias=4.0)
+    with torch.no_grad():
+        G.decoder.net[0].weight.copy_(torch.from_numpy(dec_np[0])); G.decoder.net[0].bias.copy_(torch.from_numpy(dec_np[1]))
+        G.decoder.net[2].weight.copy_(torch.from_numpy(dec_np[2])); G.decoder.net[2].bias.copy_(torch.from_numpy(dec_np[3]))
+    params = synth.synth_sr_params(seed)
+    load_block(G.superresolution.block0, params[0])
+    load_block(G.superresolution.block1, params[1])
+    G._last_planes = torch.from_numpy(synth.synth_planes(seed, N=1)).view(1, 96, 256, 256)
+    cam = synth.look_at_camera(0.1, 0.05)
+    cam[3] += 0.45
+    cam = cam[None]
+    R, Nc, Nf = 128, 48, 48
+    noise_c = synth.synth_noise(seed, (1, R * R, Nc, 1), stream=7)
+    u_f = synth.synth_noise(seed, (R * R, Nf), stream=8)
+    with torch.no_grad(), injected_noise(noise_c, u_f):
+        out = G.synthesis(torch.ones(1, G.backbone.num_ws, 512), torch.from_numpy(cam), use_cached_backbone=True, noise_mode="none")
+    hparams.update(mask_invalid_rays=False)
+    img = out["image"].numpy()
+    raw = out["image_raw"].numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=seed, cam=cam, R=R, Nc=Nc, Nf=Nf,
+                        image_strided=img[:, :, ::4, ::4], image_raw=raw, image_depth=out["image_depth"].numpy(),
+                        image_feature_strided=out["image_feature"].numpy()[:, ::4],
+                        masked_frac=np.float64((raw == -1).mean()))
+    print(name, img.shape, "masked frac", float((raw == -1).mean()))
+
+
+def warp_sr_case(name):
+    """The reference's SuperresolutionHybrid8XDC_Warp.forward (sr_with_ref.py:67-137, fuse mode v2, the shipped torso configuration
+    egs/os_avatar/real3d_orig/secc_img2plane_torso_orig.yaml) at full size, with its face-vid2vid `torso_model` replaced by the
+    deterministic stand-in of tests/warp_mock.py (that network is out of scope and needs .cuda())."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import ref_stubs
+    import warp_mock
+    ref_stubs.install()
+    from utils.commons.hparams import set_hparams, hparams
+    set_hparams(os.path.join(REF, "egs/os_avatar/real3d_orig/secc_img2plane_torso_orig.yaml"), print_hparams=False)
+    assert hparams["htbsr_head_weight_fuse_mode"] == "v2" and hparams["torso_model_version"] == "v2"
+    from modules.real3d.super_resolution.sr_with_ref import SuperresolutionHybrid8XDC_Warp
+    sr = SuperresolutionHybrid8XDC_Warp(channels=32, img_resolution=512, sr_num_fp16_res=0, sr_antialias=True, channel_base=32768,
+                                        channel_max=512, fused_modconv_default="inference_only").eval()
+    sr.torso_model = warp_mock.MockTorso()
+    warp_mock.load_warp_params(sr, load_block)
+    i = {k: torch.from_numpy(v) for k, v in warp_mock.warp_inputs().items()}
+    with torch.no_grad():
+        out, ret = sr(i["x"][:, :3].contiguous(), i["x"], i["ws"], i["ref_torso_rgb"], i["ref_bg_rgb"], i["weights_img"], None, None, None,
+                      noise_mode="none")
+    out = out.numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=warp_mock.SEED, threshold=np.float64(hparams["htbsr_head_threshold"]),
+                        strided=out[:, :, ::4, ::4], corner=out[:, :, :96, :96], tail=out[:, :, -64:, -64:],
+                        absmean=np.float64(np.abs(out).mean()))
+    print(name, out.shape, float(np.abs(out).mean()))
+
+
 def main():
-    which = sys.argv[1:] or ["render", "run_model", "sr_small", "sr_full", "synthesis", "fusion", "toplane"]
+    which = sys.argv[1:] or ["render", "run_model", "sr_small", "sr_full", "synthesis", "fusion", "toplane", "sr_cfg5", "fusion_full",
+                             "toplane_full", "synthesis_mask", "warp_sr"]
+    if "warp_sr" in which:
+        warp_sr_case("warp_sr_a")
+    if "sr_cfg5" in which:
+        sr_cfg5_case("sr_cfg5_a")
+    if "fusion_full" in which:
+        fusion_full_case("fusion_full_a")
+    if "toplane_full" in which:
+        toplane_full_case("toplane_full_a")
+    if "synthesis_mask" in which:
+        synthesis_mask_case("synthesis_mask_a")
     if "render" in which:
         small = synth.synth_planes(1, N=1, H=32, W=32)
         render_case("render_a_r16_16p16", small, [synth.look_at_camera(0.0, 0.0)], 16, 16, 16, 2, 3)

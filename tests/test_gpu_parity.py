@@ -163,9 +163,9 @@ def test_fusion_stacks_golden(torch_cuda):
         assert np.abs(got.cpu().numpy() - ref).max() <= SR_TOL * max(1.0, np.abs(ref).max()), key
     # the same flow with the blends + concatenations fused into the convs' input conversion (r3d_blend_cat_to_split)
     from real3dportrait_amd.superresolution import blend_cat
-    y1 = stacks["fuse_head_torso_convs"](blend_cat(i["x_head"], x_torso, a))
+    y1 = stacks["fuse_head_torso_convs"](blend_cat(i["x_head"], x_torso, a, stacks["fuse_head_torso_convs"]))
     y2, _ = blk(y1, rgb1, i["ws"], noise_mode="none")
-    y3 = stacks["fuse_fg_bg_convs"](blend_cat(y2, x_bg, occ))
+    y3 = stacks["fuse_fg_bg_convs"](blend_cat(y2, x_bg, occ, stacks["fuse_fg_bg_convs"]))
     for got, ref in ((y1, x1), (y2, x2), (y3, x3)):
         assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
 

@@ -1,0 +1,60 @@
+"""GPU parity (`-m gpu`): the fused HIP SuperresolutionHybrid8XDC_Warp.forward (fuse mode v2) against the reference's own forward
+run on CPU with the same stand-in torso network (tests/golden/warp_sr_a.npz, tests/warp_mock.py)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from test_gpu_parity import SR_TOL, T, load_block
+
+pytestmark = pytest.mark.gpu
+
+
+def test_warp_sr_forward_v2_golden():
+    import torch
+    assert torch.cuda.is_available()
+    import warp_mock
+    from real3dportrait_amd.sr_with_ref import SuperresolutionHybrid8XDC_Warp
+    g = load_golden("warp_sr_a")
+    sr = SuperresolutionHybrid8XDC_Warp(32, 512, 0, True, torso_model=warp_mock.MockTorso(),
+                                        hparams={"htbsr_head_threshold": float(g["threshold"])}).cuda()
+    warp_mock.load_warp_params(sr, lambda blk, p: load_block(torch, blk, p), to=lambda a: T(torch, a))
+    i = {k: T(torch, v) for k, v in warp_mock.warp_inputs().items()}
+    outs = []
+    for _ in range(2):          # second call: clip constants (resized references, bg_encoder output, styles) come from the caches
+        out, ret = sr(i["x"][:, :3].contiguous(), i["x"], i["ws"], i["ref_torso_rgb"], i["ref_bg_rgb"], i["weights_img"], None, None, None,
+                      noise_mode="none")
+        outs.append(out)
+    assert torch.equal(outs[0], outs[1])
+    assert set(ret) == {"deformed_torso_hid", "occlusion_2"}
+    out = outs[0].cpu().numpy()
+    tol = SR_TOL * max(1.0, np.abs(g["strided"]).max())
+    assert out.shape == (1, 3, 512, 512)
+    assert np.abs(out[:, :, ::4, ::4] - g["strided"]).max() <= tol
+    assert np.abs(out[:, :, :96, :96] - g["corner"]).max() <= tol
+    assert np.abs(out[:, :, -64:, -64:] - g["tail"]).max() <= tol
+    assert abs(float(np.abs(out).mean()) - float(g["absmean"])) <= 1e-4
+    # a new background image must invalidate the cached bg_encoder output
+    bg2 = i["ref_bg_rgb"] * 0.5
+    out2, _ = sr(i["x"][:, :3].contiguous(), i["x"], i["ws"], i["ref_torso_rgb"], bg2, i["weights_img"], None, None, None, noise_mode="none")
+    assert not torch.equal(out2, outs[0])
+
+
+def test_resize_blend_kernels_vs_torch():
+    """r3d_resize_bilinear vs F.interpolate(bilinear, align_corners=False, antialias) for the three shapes of sr_with_ref.py:77-82,110
+    and odd sizes; r3d_blend / r3d_person_occlusion vs the torch expressions."""
+    import torch
+    import torch.nn.functional as F
+    from real3dportrait_amd.sr_with_ref import blend, person_occlusion, resize_bilinear
+    torch.manual_seed(3)
+    for (C, H, W, OH, OW) in [(3, 128, 128, 256, 256), (3, 512, 512, 256, 256), (1, 64, 64, 256, 256), (2, 37, 53, 80, 21), (1, 300, 200, 128, 128)]:
+        x = torch.randn(2, C, H, W, device="cuda")
+        for aa in (True, False):
+            ref = F.interpolate(x, size=(OH, OW), mode="bilinear", align_corners=False, antialias=aa)
+            got = resize_bilinear(x, (OH, OW), aa)
+            assert (got - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item()), (C, H, W, OH, OW, aa)
+    a, b = torch.randn(2, 3, 40, 50, device="cuda"), torch.randn(2, 3, 40, 50, device="cuda")
+    m = torch.rand(2, 1, 40, 50, device="cuda")
+    assert (blend(a, b, m) - (a * m + b * (1 - m))).abs().max().item() <= 1e-6
+    occ = torch.rand(2, 1, 40, 50, device="cuda")
+    head = m.clone(); head[head > 0.9] = 1.0
+    assert torch.equal(person_occlusion(m, occ, 0.9), (occ + head).clamp_(0, 1))
