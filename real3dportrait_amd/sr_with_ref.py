@@ -19,7 +19,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib
-from .superresolution import (_BoundMeter, _f32c, blend_cat, bound_of, chain_fold, const_bound)
+from .superresolution import (_BoundMeter, _f32c, _keep_tags, _tag, blend_cat, bound_of, chain_fold, const_bound)
 
 
 def resize_bilinear(x, size, antialias=True):
@@ -53,6 +53,11 @@ def person_occlusion(alpha, torso_occlusion, head_threshold):
     _lib.check(lib.r3d_person_occlusion(_lib.ptr(alpha), _lib.ptr(torso_occlusion), float(head_threshold), alpha.numel(), _lib.ptr(out),
                                         _lib.stream_ptr()), "person_occlusion")
     return out
+
+
+def _measured(t, S):
+    """Tag a (clip-constant) fp32 activation with its MEASURED max|x| (its own tensor, not a meter slot that later calls reuse)."""
+    return _tag(t, _BoundMeter()(t).clone(), 0)
 
 
 class _Cached:
@@ -110,9 +115,9 @@ def forward_v2(self, rgb, x, ws, ref_torso_rgb, ref_bg_rgb, weights_img, segmap,
 
     # ---- block0: 128^2 head features -> 256^2 (:83); its conv1 epilogue measures max|x0| ------------------------------------------
     prep0 = b0.prepare(ws3, dev, ws_key=ws)
-    bx = getattr(x, "_r3d_bound", None)
-    x = _f32c(x)
-    chain_fold([b0.chain_op(-1)], N, [bx if bx is not None else S.meter_x(x)], zero=[m_x0])
+    x = _keep_tags(x)
+    bx, _ = bound_of(x, S.meter_x, layers=2)
+    chain_fold([b0.chain_op(-1)], N, [bx], zero=[m_x0])
     b0.out_format, b0.return_x = "cb8", True
     x0, rgb0 = b0(x, rgb, ws3, _prepared=prep0, _folded=True, _x_absmax=m_x0, **kw)
 
@@ -124,14 +129,14 @@ def forward_v2(self, rgb, x, ws, ref_torso_rgb, ref_bg_rgb, weights_img, segmap,
         rgb_torso, ret = self.torso_model.forward(ref_torso_rgb_256, segmap, kp_s, kp_d, rgb_256.detach(), weights_256.detach(),
                                                   cal_loss=True, target_torso_mask=target_torso_mask)
     x_torso = self.torso_encoder(ret["deformed_torso_hid"], out_format="cb8")                          # :88 (1x1 conv, measured input)
-    x_bg = S.c_xbg.get(ref_bg_rgb, lambda _: self.bg_encoder(ref_bg_rgb_256, out_format="cb8"))        # :90 (clip constant)
+    x_bg = S.c_xbg.get(ref_bg_rgb, lambda _: _measured(self.bg_encoder(ref_bg_rgb_256, out_format="cb8"), S))   # :90 (clip constant)
 
     # ---- head / torso fusion (:99-105) -----------------------------------------------------------------------------------------------
     alpha = weights_256                                   # `head_torso_alpha[head_torso_alpha > weights_256] = ...` (:101-102) is a no-op
     rgb1 = blend(rgb0, rgb_torso, alpha)                                                                # :103
     preph = hb.prepare(ws3, dev, ws_key=ws)
     ops, head, last = fuse_ht.chain_ops(N, dev, -1, -2, base=0)
-    chain_fold(ops + [hb.chain_op(last)], N, [m_x0, bound_of(x_torso, S.meter_hid)], zero=[m_y])
+    chain_fold(ops + [hb.chain_op(last)], N, [m_x0, bound_of(x_torso, S.meter_hid, 3)[0]], zero=[m_y])
     xs = blend_cat(x0, x_torso, alpha, fuse_ht, _folded_head=head)                                      # :104
     y = fuse_ht(xs, out_format="split", _next=hb, _y_absmax=m_y)                                        # :105
     chain_fold([hb.chain_op(-1, tail=True)], N, [m_y], zero=[m_x2])
@@ -144,7 +149,7 @@ def forward_v2(self, rgb, x, ws, ref_torso_rgb, ref_bg_rgb, weights_img, segmap,
     rgb3 = blend(rgb2, ref_bg_rgb_256, pocc)                                                            # :112
     prep1 = b1.prepare(ws3, dev, ws_key=ws)
     ops, head, last = fuse_fg.chain_ops(N, dev, -1, -2, base=0)
-    chain_fold(ops + [b1.chain_op(last)], N, [m_x2, bound_of(x_bg, S.meter_hid)], zero=[m_z])
+    chain_fold(ops + [b1.chain_op(last)], N, [m_x2, x_bg._r3d_bound], zero=[m_z])
     xs2 = blend_cat(x2, x_bg, pocc, fuse_fg, _folded_head=head)                                         # :113
     z = fuse_fg(xs2, out_format="split", _next=b1, _y_absmax=m_z)                                       # :114
     chain_fold([b1.chain_op(-1, tail=True)], N, [m_z])

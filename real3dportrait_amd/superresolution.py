@@ -77,12 +77,33 @@ def const_bound(value, N, device):
     return t
 
 
-def bound_of(x, meter):
-    """Bound of an fp32 activation: its `_r3d_bound` tag if present, else measured on the device."""
+MAX_DEPTH = 3      # a stored fp16 operand may be at most this many conv layers away from a measured / known max|x|
+
+
+def bound_of(x, meter, layers=1):
+    """(bound, depth) of an fp32 activation that is about to enter a chain of `layers` conv layers folded together.  The propagated
+    bound loosens ~5 binades per layer and the fp16 window has ~16, so a tag (`_r3d_bound`, `_r3d_depth` = layers since the last
+    measurement) is only trusted while the deepest operand of the chain stays within MAX_DEPTH layers of a measurement; otherwise
+    max|x| is measured on the device (depth 0)."""
     b = getattr(x, "_r3d_bound", None)
-    if b is not None:
-        return b
-    return meter(x)
+    d = int(getattr(x, "_r3d_depth", 0))
+    if b is not None and d + layers - 1 <= MAX_DEPTH:
+        return b, d
+    return meter(x), 0
+
+
+def _tag(y, bound, depth):
+    y._r3d_bound, y._r3d_depth = bound, depth
+    return y
+
+
+def _keep_tags(x):
+    """_f32c (detach) drops python attributes: carry the range tags over."""
+    y = _f32c(x)
+    b = getattr(x, "_r3d_bound", None)
+    if b is not None and y is not x:
+        _tag(y, b, int(getattr(x, "_r3d_depth", 0)))
+    return y
 
 
 def chain_fold(ops, N, ext, zero=()):
@@ -175,6 +196,7 @@ class SynthesisBlock(nn.Module):
         self._styles_ws = None         # keeps the ws tensor of the cached styles alive (its address cannot be recycled)
         self._workspace = None
         self._meter = _BoundMeter()
+        self._depth_in = 0             # layers between the last measurement and this block's input (set by whoever folds it)
 
     def _buf(self, name, nbytes, dev):
         t = getattr(self, name)
@@ -255,10 +277,7 @@ class SynthesisBlock(nn.Module):
             _folded = True
             x = x.contiguous()
         else:
-            bx = getattr(x, "_r3d_bound", None)
-            x = _f32c(x)
-            if bx is not None:
-                x._r3d_bound = bx
+            x = _keep_tags(x)
         img = _f32c(img)
         N = img.shape[0]
         Hin, Win = img.shape[-2], img.shape[-1]
@@ -268,7 +287,8 @@ class SynthesisBlock(nn.Module):
         prec = {"f32": 0, "f16x3": 1}[self.precision]
         pre, styles = _prepared if _prepared is not None else self.prepare(ws, dev)
         if prec == 1 and not _folded:
-            chain_fold([self.chain_op(-1)], N, [bound_of(x, self._meter)])
+            bx, self._depth_in = bound_of(x, self._meter, layers=2)
+            chain_fold([self.chain_op(-1)], N, [bx])
         need = int(lib.r3d_sr_block_workspace_bytes(N, Cin, Cout, Hin, Win))
         work = self._buf("_workspace", need, dev)
         OH, OW = (2 * Hin, 2 * Win) if self._UP else (Hin, Win)
@@ -295,7 +315,7 @@ class SynthesisBlock(nn.Module):
             if out_fmt == "split":
                 x_out._r3d_for = _next
             elif prec == 1:
-                x_out._r3d_bound = self.bound_out(N)
+                _tag(x_out, self.bound_out(N), self._depth_in + 2)
         return x_out, img_out
 
 
@@ -331,6 +351,7 @@ class Conv2d(nn.Module):
         self._scales = None
         self._bias32 = None
         self._meter = _BoundMeter()
+        self._depth_in = 0
 
     _buf = SynthesisBlock._buf
     _FMT = SynthesisBlock._FMT
@@ -382,10 +403,7 @@ class Conv2d(nn.Module):
             _folded = True
             x = x.contiguous()
         else:
-            bx = getattr(x, "_r3d_bound", None)
-            x = _f32c(x)
-            if bx is not None:
-                x._r3d_bound = bx
+            x = _keep_tags(x)
         Cin, Cout, k = self.in_channels, self.out_channels, self.kernel_size[0]
         N, C, H, W = self._shape(x, x_fmt)
         if C != Cin:
@@ -394,7 +412,8 @@ class Conv2d(nn.Module):
         st = _lib.stream_ptr()
         if not _folded:
             self.prepare(N, dev)
-            chain_fold([self.chain_op(-1, negative_slope=negative_slope)], N, [bound_of(x, self._meter)])
+            bx, self._depth_in = bound_of(x, self._meter, layers=1)
+            chain_fold([self.chain_op(-1, negative_slope=negative_slope)], N, [bx])
         need = int(lib.r3d_conv_workspace_bytes(N, Cin, H, W))
         work = self._buf("_workspace", need, dev) if x_fmt != "split" else None
         next_scale, next_stride = None, 0
@@ -416,7 +435,7 @@ class Conv2d(nn.Module):
         if out_format == "split":
             y._r3d_for = _next
         else:
-            y._r3d_bound = self.bound_out(N)
+            _tag(y, self.bound_out(N), self._depth_in + 1)
         return y
 
 
@@ -425,7 +444,7 @@ def upsample2x_bilinear(x, out_format="split", _next=None):
     (r3d_upsample2x_bilinear); output 'split' (input of the conv `_next`, already folded) or 'cb8'."""
     lib = _lib.load()
     assert getattr(x, "_r3d_fmt", None) == "cb8", "upsample2x_bilinear takes the 'cb8' output of a Conv2d"
-    bx = getattr(x, "_r3d_bound", None)
+    bx, dx = getattr(x, "_r3d_bound", None), int(getattr(x, "_r3d_depth", 0))
     x = x.contiguous()
     N, C8, H, W, _ = x.shape
     next_scale, next_stride = None, 0
@@ -441,7 +460,7 @@ def upsample2x_bilinear(x, out_format="split", _next=None):
     if out_format == "split":
         y._r3d_for = _next
     elif bx is not None:
-        y._r3d_bound = bx          # a convex combination does not raise the bound
+        _tag(y, bx, dx)            # a convex combination does not raise the bound
     return y
 
 
@@ -459,10 +478,7 @@ def blend_cat(a, b, mask, consumer, ws=None, _folded_head=None):
     def desc(t):
         fmt = getattr(t, "_r3d_fmt", "nchw")
         assert fmt in ("nchw", "cb8"), fmt
-        bt = getattr(t, "_r3d_bound", None)
-        t = _f32c(t)
-        if bt is not None:
-            t._r3d_bound = bt
+        t = _keep_tags(t)
         if fmt == "nchw":
             return t, 0, t.shape[1], t.shape[0], t.shape[2], t.shape[3]
         return t, 1, t.shape[1] * 8, t.shape[0], t.shape[2], t.shape[3]
@@ -474,7 +490,9 @@ def blend_cat(a, b, mask, consumer, ws=None, _folded_head=None):
         head = _folded_head
     else:
         meters = _BLEND_METERS.setdefault(id(consumer), (_BoundMeter(), _BoundMeter()))
-        head = consumer.fold_for_input(N, a.device, [bound_of(a, meters[0]), bound_of(b, meters[1])], ws=ws)
+        L = consumer.num_layers()
+        (ba, da), (bb, db) = bound_of(a, meters[0], L), bound_of(b, meters[1], L)
+        head = consumer.fold_for_input(N, a.device, [ba, bb], ws=ws, depth=max(da, db))
     ns, stride = head.in_scale()
     y = torch.empty(N, 2, (Ca + Cb) // 8, H, W, 8, device=a.device, dtype=torch.float16)
     _lib.check(lib.r3d_blend_cat_to_split(_lib.ptr(a), fa, Ca, _lib.ptr(b), fb, Cb, _lib.ptr(mask), N, H, W, _lib.ptr(y),
@@ -484,8 +502,9 @@ def blend_cat(a, b, mask, consumer, ws=None, _folded_head=None):
     return y
 
 
-def _fold_single(module, N, dev, bounds, ws=None, negative_slope=None):
+def _fold_single(module, N, dev, bounds, ws=None, negative_slope=None, depth=0):
     """Fold one module (Conv2d or SynthesisBlock) whose input bound is the max of `bounds` (1 or 2 device tensors)."""
+    module._depth_in = depth
     if isinstance(module, SynthesisBlock):
         module.prepare(ws, dev)
         op = module.chain_op(-1, -2 if len(bounds) > 1 else _lib.CHAIN_SRC_NONE)
@@ -496,12 +515,13 @@ def _fold_single(module, N, dev, bounds, ws=None, negative_slope=None):
     return module
 
 
-def _block_fold_for_input(self, N, dev, bounds, ws=None):
+def _block_fold_for_input(self, N, dev, bounds, ws=None, depth=0):
     assert ws is not None, "folding a SynthesisBlock needs its ws"
-    return _fold_single(self, N, dev, bounds, ws=ws)
+    return _fold_single(self, N, dev, bounds, ws=ws, depth=depth)
 
 
 SynthesisBlock.fold_for_input = _block_fold_for_input
+SynthesisBlock.num_layers = lambda self: 2
 
 
 class ConvStack(nn.Sequential):
@@ -549,20 +569,24 @@ class ConvStack(nn.Sequential):
             i += step
         return plan
 
-    def chain_ops(self, N, dev, src_a=-1, src_b=_lib.CHAIN_SRC_NONE, base=0):
+    def num_layers(self):
+        return len(self._plan())
+
+    def chain_ops(self, N, dev, src_a=-1, src_b=_lib.CHAIN_SRC_NONE, base=0, depth=0):
         """The stack's layers as r3d_chain_fold ops: the first reads (src_a, src_b), layer k reads op base + k - 1.  Returns
-        (ops, first conv, index of the last op)."""
+        (ops, first conv, index of the last op).  depth: layers between the last measurement and the stack's input."""
         plan = self._plan()
         ops = []
         for k, (m, slope, _) in enumerate(plan):
             m.prepare(N, dev)
+            m._depth_in = depth + k
             ops.append(m.chain_op(src_a, src_b, negative_slope=slope) if k == 0 else m.chain_op(base + k - 1, negative_slope=slope))
         return ops, plan[0][0], base + len(plan) - 1
 
-    def fold_for_input(self, N, dev, bounds, ws=None):
+    def fold_for_input(self, N, dev, bounds, ws=None, depth=0):
         """Fold the whole stack (one launch) for an input whose bound is the max of `bounds`; returns the first conv (the module a
         producer of the stack's SPLIT input scales for)."""
-        ops, head, _ = self.chain_ops(N, dev, -1, -2 if len(bounds) > 1 else _lib.CHAIN_SRC_NONE)
+        ops, head, _ = self.chain_ops(N, dev, -1, -2 if len(bounds) > 1 else _lib.CHAIN_SRC_NONE, depth=depth)
         chain_fold(ops, N, bounds)
         return head
 
@@ -577,11 +601,9 @@ class ConvStack(nn.Sequential):
         else:
             if not hasattr(self, "_meter_obj"):
                 object.__setattr__(self, "_meter_obj", _BoundMeter())
-            bx = getattr(x, "_r3d_bound", None)
-            x = _f32c(x)
-            if bx is not None:
-                x._r3d_bound = bx
-            self.fold_for_input(x.shape[0], x.device, [bound_of(x, self._meter_obj)])
+            x = _keep_tags(x)
+            bx, dx = bound_of(x, self._meter_obj, len(plan))
+            self.fold_for_input(x.shape[0], x.device, [bx], depth=dx)
         for k, (m, slope, up) in enumerate(plan):
             nxt = plan[k + 1][0] if k + 1 < len(plan) else None
             if up:
@@ -595,11 +617,12 @@ class ConvStack(nn.Sequential):
         return x
 
 
-def _conv_fold_for_input(self, N, dev, bounds, ws=None):
-    return _fold_single(self, N, dev, bounds)
+def _conv_fold_for_input(self, N, dev, bounds, ws=None, depth=0):
+    return _fold_single(self, N, dev, bounds, depth=depth)
 
 
 Conv2d.fold_for_input = _conv_fold_for_input
+Conv2d.num_layers = lambda self: 1
 
 
 class SuperresolutionHybrid8XDC(nn.Module):
@@ -648,9 +671,10 @@ class SuperresolutionHybrid8XDC(nn.Module):
         if b0.precision == "f16x3":
             # one fold launch for both blocks; block0's conv1 epilogue then emits its output already multiplied by block1.conv0's
             # folded styles and split into fp16 hi/lo planes, so block1 stages its input with plain copies
-            bx = getattr(x, "_r3d_bound", None)
-            x = _f32c(x)
-            chain_fold([b0.chain_op(-1), b1.chain_op(0)], x.shape[0], [bx if bx is not None else self._meter(x)])
+            x = _keep_tags(x)
+            bx, dx = bound_of(x, self._meter, layers=4)
+            b0._depth_in, b1._depth_in = dx, dx + 2
+            chain_fold([b0.chain_op(-1), b1.chain_op(0)], x.shape[0], [bx])
             b0.out_format, nxt = "split", b1
         else:
             b0.out_format, nxt = "cb8", None

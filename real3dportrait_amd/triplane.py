@@ -113,7 +113,7 @@ class TriPlaneGenerator(nn.Module):
         feature = im["feature"]
         # |feature| <= 1.002 by construction (sigmoid * 1.002 - 0.001 composited with weights summing to <= 1, then * 2 - 1):
         # the SR's fp16 range fold uses this bound instead of measuring it
-        feature._r3d_bound = const_bound(1.01, feature.shape[0], feature.device)
+        feature._r3d_bound, feature._r3d_depth = const_bound(1.01, feature.shape[0], feature.device), 0
         sr_kwargs = {k: v for k, v in synthesis_kwargs.items() if k != "noise_mode"}
         sr_image = self.superresolution(feature[:, :3], feature, self._ws_for_sr(ws),
                                         noise_mode=self.rendering_kwargs["superresolution_noise_mode"], **sr_kwargs)

@@ -51,7 +51,7 @@ def test_resize_blend_kernels_vs_torch():
         for aa in (True, False):
             ref = F.interpolate(x, size=(OH, OW), mode="bilinear", align_corners=False, antialias=aa)
             got = resize_bilinear(x, (OH, OW), aa)
-            assert (got - ref).abs().max().item() <= 2e-6 * max(1.0, ref.abs().max().item()), (C, H, W, OH, OW, aa)
+            assert (got - ref).abs().max().item() <= 5e-6 * max(1.0, ref.abs().max().item()), (C, H, W, OH, OW, aa)
     a, b = torch.randn(2, 3, 40, 50, device="cuda"), torch.randn(2, 3, 40, 50, device="cuda")
     m = torch.rand(2, 1, 40, 50, device="cuda")
     assert (blend(a, b, m) - (a * m + b * (1 - m))).abs().max().item() <= 1e-6
