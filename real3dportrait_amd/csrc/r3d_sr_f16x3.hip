@@ -146,17 +146,37 @@ struct Conv2Args {
 // Epilogue of a 128-cout x 16x16-pixel block held as acc[2][NT] per wave: demodulation * acc (+ bias -> lrelu * gain ->
 // clamp) -> any of {fp32 channel-blocked, fp32 NCHW, SPLIT scaled by the next layer's styles} + toRGB partial sums.
 // toRGB partials: one plane per 64-cout half (index 2 * blockIdx.y + wm); rgb_finalize_kernel adds them up.
+// The per-cout vectors (out_scale, bias, next_scale, 3 toRGB weight rows) of the block's 128 couts are staged in LDS ONCE, after
+// the main loop: loaded from global inside the group loop they put an `s_waitcnt vmcnt(0)` -- which on gfx9 also waits for every
+// store issued before it -- in front of each of the 16 groups (48 serialised memory round trips = the 29 k-cycle epilogue that
+// round 1 measured); from LDS the loop has no global loads, so its stores stream out back to back.
+// The caller has passed a __syncthreads() after its last LDS read; `ev` may alias the main loop's buffers.
+static constexpr int EV_STRIDE = BLOCK_M;              // floats per staged vector
 template <bool FULL_EPI, int WN, int NT>
 __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhase& ph, int n, f32x16 (&acc)[2][NT],
-                                              int i0, int j0, int m0)
+                                              int i0, int j0, int m0, float* ev)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
     const int li = lane & 31, h = lane >> 5;
     const int prow = li >> 4, pcol = ((li & 15) - 2 * prow) & 15;
     const int row0 = wn * 2 * NT;
-    // ---- epilogue ------------------------------------------------------------------------------------------------
     const bool do_rgb = FULL_EPI && a.rgb_partial != nullptr;
+    {   // stage: vector v of cout c -> ev[v * EV_STRIDE + c]; v = 0 out_scale (1), 1 bias (0), 2 next_scale (1), 3..5 toRGB rows (0)
+        constexpr int NTHR = 128 * WN;
+        for (int e = threadIdx.x; e < 6 * BLOCK_M; e += NTHR) {
+            const int v = e / BLOCK_M, c = e - v * BLOCK_M, co = m0 + c;
+            float val = (v == 0 || v == 2) ? 1.f : 0.f;
+            if (co < a.CoutReal) {
+                if (v == 0) { if (a.out_scale) val = a.out_scale[(size_t)n * a.out_scale_stride_n + co]; }
+                else if (v == 1) { if (FULL_EPI && a.bias) val = a.bias[(size_t)n * a.bias_stride_n + co]; }
+                else if (v == 2) { if (FULL_EPI && a.y_split && a.next_scale) val = a.next_scale[(size_t)n * a.next_scale_stride_n + co]; }
+                else if (do_rgb) val = a.wrgb[(size_t)n * a.wrgb_stride_n + (size_t)(v - 3) * a.CoutReal + co];
+            }
+            ev[e] = val;
+        }
+        __syncthreads();
+    }
     float vmax = 0.f;
     float rgbp[NT][3];
 #pragma unroll
@@ -164,21 +184,26 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
     const size_t oplane = (size_t)(a.CoutReal >> 3) * a.OH * a.OW;
     float* Yf = a.y_f32 ? a.y_f32 + (size_t)n * a.y_f32_stride_n + ph.out_off : nullptr;
     float* Yn = (FULL_EPI && a.y_nchw) ? a.y_nchw + (size_t)n * a.y_nchw_stride_n : nullptr;
+    uint4* Ys = (FULL_EPI && a.y_split) ? a.y_split + (size_t)n * a.y_split_stride_n : nullptr;
+    const bool want_max = FULL_EPI && a.y_absmax != nullptr;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int i = i0 + row0 + nt * 2 + prow, j = j0 + pcol;
-        const bool inside = i < ph.outH && j < ph.outW;
-        const int oy = i * ph.oy_mul + ph.oy_add, ox = j * ph.ox_mul + ph.ox_add;
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int g = 0; g < 4; ++g) {
+            const int cl = 64 * wm + 32 * mt + 8 * g + 4 * h, co = m0 + cl;
+            if (co >= a.CoutReal) continue;                           // channels that only exist as weight padding
+            const float4 d4 = *reinterpret_cast<const float4*>(ev + cl);
+            const float4 b4 = *reinterpret_cast<const float4*>(ev + EV_STRIDE + cl);
+            const float4 s4 = *reinterpret_cast<const float4*>(ev + 2 * EV_STRIDE + cl);
+            const float4 w0 = *reinterpret_cast<const float4*>(ev + 3 * EV_STRIDE + cl);
+            const float4 w1 = *reinterpret_cast<const float4*>(ev + 4 * EV_STRIDE + cl);
+            const float4 w2 = *reinterpret_cast<const float4*>(ev + 5 * EV_STRIDE + cl);
+            const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w}, sv[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int co = m0 + 64 * wm + 32 * mt + 8 * g + 4 * h;
-                if (co >= a.CoutReal) continue;                       // channels that only exist as weight padding
-                float4 d4 = make_float4(1.f, 1.f, 1.f, 1.f), b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (a.out_scale) d4 = *reinterpret_cast<const float4*>(a.out_scale + (size_t)n * a.out_scale_stride_n + co);
-                if (FULL_EPI && a.bias) b4 = *reinterpret_cast<const float4*>(a.bias + (size_t)n * a.bias_stride_n + co);
-                const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+            for (int nt = 0; nt < NT; ++nt) {
+                const int i = i0 + row0 + nt * 2 + prow, j = j0 + pcol;
+                const bool inside = i < ph.outH && j < ph.outW;
+                const int oy = i * ph.oy_mul + ph.oy_add, ox = j * ph.ox_mul + ph.ox_add;
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -191,16 +216,12 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
                     v[r] = t;
                 }
                 if (do_rgb) {
-                    const float* wr = a.wrgb + (size_t)n * a.wrgb_stride_n;
-                    const float4 w0 = *reinterpret_cast<const float4*>(wr + co);
-                    const float4 w1 = *reinterpret_cast<const float4*>(wr + a.CoutReal + co);
-                    const float4 w2 = *reinterpret_cast<const float4*>(wr + 2 * a.CoutReal + co);
                     rgbp[nt][0] += v[0] * w0.x + v[1] * w0.y + v[2] * w0.z + v[3] * w0.w;
                     rgbp[nt][1] += v[0] * w1.x + v[1] * w1.y + v[2] * w1.z + v[3] * w1.w;
                     rgbp[nt][2] += v[0] * w2.x + v[1] * w2.y + v[2] * w2.z + v[3] * w2.w;
                 }
                 if (!inside) continue;
-                if (FULL_EPI && a.y_absmax) vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
+                if (want_max) vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
                 const size_t pix = ((size_t)(co >> 3) * a.OH + oy) * a.OW + ox;
                 if (Yf) *reinterpret_cast<float4*>(Yf + pix * 8 + (co & 7)) = make_float4(v[0], v[1], v[2], v[3]);
                 if (Yn) {
@@ -208,20 +229,17 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
 #pragma unroll
                     for (int r = 0; r < 4; ++r) Yn[(size_t)(co + r) * hw + p0] = v[r];
                 }
-                if (FULL_EPI && a.y_split) {
-                    float4 s4 = make_float4(1.f, 1.f, 1.f, 1.f);
-                    if (a.next_scale) s4 = *reinterpret_cast<const float4*>(a.next_scale + (size_t)n * a.next_scale_stride_n + co);
-                    const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
+                if (Ys) {
                     h4 hi, lo;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { _Float16 x0, x1; split1(v[r] * sv[r], x0, x1); hi[r] = x0; lo[r] = x1; }
-                    uint2* dst = reinterpret_cast<uint2*>(a.y_split + (size_t)n * a.y_split_stride_n + pix) + ((co & 7) >> 2);
+                    uint2* dst = reinterpret_cast<uint2*>(Ys + pix) + ((co & 7) >> 2);
                     dst[0] = *reinterpret_cast<uint2*>(&hi);
                     dst[2 * oplane] = *reinterpret_cast<uint2*>(&lo);
                 }
             }
-    }
-    if (FULL_EPI && a.y_absmax) {
+        }
+    if (want_max) {
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, d));
         if (lane == 0 && vmax > 0.f) atomicMax(a.y_absmax + n, __float_as_uint(vmax));
@@ -411,7 +429,7 @@ __device__ __forceinline__ void conv2_block(const Conv2Args& a, const ConvPhase&
         }
     }
     __syncthreads();
-    conv_epilogue<FULL_EPI, WN, NT>(a, ph, n, acc, i0, j0, m0);
+    conv_epilogue<FULL_EPI, WN, NT>(a, ph, n, acc, i0, j0, m0, reinterpret_cast<float*>(lds));
 }
 
 // ---- plain 3x3 conv, LDS-DMA pipeline ------------------------------------------------------------------------------
@@ -556,7 +574,7 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
         }
     }
     __syncthreads();
-    conv_epilogue<FULL_EPI, WN, NT>(a, ph, n, acc, i0, j0, m0);
+    conv_epilogue<FULL_EPI, WN, NT>(a, ph, n, acc, i0, j0, m0, reinterpret_cast<float*>(lds));
 }
 
 static constexpr int F_LDS_UINT4 = 2 * 2 * F_PATCH_PIX + 2 * 3 * 2 * 256;      // patch (20.7 KB) + 2 x 3-tap weight sub-stage (2 x 24.6 KB)
