@@ -251,6 +251,20 @@ int r3d_person_occlusion(const float* alpha, const float* torso_occlusion, float
  * img [N,3,H,W] fp32 -> out [N,H,W,3] uint8. */
 int r3d_frames_to_u8(const float* img, int N, int H, int W, uint8_t* out, r3d_stream_t stream);
 
+/* --- frame gather over RCCL / xGMI ---------------------------------------------------------------------------
+ * One process per GPU renders a contiguous chunk of the clip into a device-resident uint8 ring; r3d_gather_frames re-assembles the
+ * clip on `root`: every rank sends `bytes_per_rank` bytes of `local`, the root receives world x bytes_per_rank into root_buf in rank
+ * order (grouped ncclSend / ncclRecv on `stream`; no reduction, each peer uses its own xGMI link to the root).  The reference has
+ * no counterpart: its frame loop is serial (inference/real3d_infer.py:480-492).
+ *   r3d_comm_unique_id: rank 0 fills a 128-byte id that the caller ships to the other ranks (any side channel);
+ *   r3d_comm_init: collective, on the calling thread's current HIP device.  RCCL is resolved with dlopen at first use (a copy that
+ *   is already mapped, e.g. torch's, is reused); R3D_ERR_UNSUPPORTED if no librccl.so can be found. */
+#define R3D_COMM_ID_BYTES 128
+int r3d_comm_unique_id(void* id128);
+int r3d_comm_init(const void* id128, int rank, int world, void** comm);
+int r3d_comm_destroy(void* comm);
+int r3d_gather_frames(void* comm, const uint8_t* local, size_t bytes_per_rank, uint8_t* root_buf, int root, r3d_stream_t stream);
+
 /* Time a region with HIP events ON THE GIVEN STREAM (bench.py's roofline leg): returns elapsed ms
  * between two events; handles are opaque. */
 int r3d_event_create(void** ev);

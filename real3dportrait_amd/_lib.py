@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libr3d_hip.so")
+LIB_PATH = os.environ.get("R3D_LIB") or os.path.join(_HERE, "lib", "libr3d_hip.so")     # R3D_LIB: an experiment build (scripts/)
 CSRC = os.path.join(_HERE, "csrc")
 
 c_void_p, c_int, c_float, c_size_t, c_uint64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
@@ -49,6 +49,10 @@ SIGNATURES = {
     "r3d_resize_bilinear": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, c_int, P]),
     "r3d_blend": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P, P]),
     "r3d_person_occlusion": (c_int, [P, P, c_float, c_size_t, P, P]),
+    "r3d_comm_unique_id": (c_int, [P]),
+    "r3d_comm_init": (c_int, [P, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "r3d_comm_destroy": (c_int, [P]),
+    "r3d_gather_frames": (c_int, [P, P, c_size_t, P, c_int, P]),
     "r3d_profile_configure": (c_int, [ctypes.c_uint32]),
     "r3d_profile_reset": (c_int, []),
     "r3d_profile_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),

@@ -1,7 +1,7 @@
 // Fused tri-plane NeRF volume renderer for gfx950 (MI355X).
 //
 // One wavefront renders one ray end-to-end: stratified depths -> tri-plane gather -> decoder MLP on
-// f32 MFMA -> coarse ray-march weights -> importance resampling -> second gather/MLP pass ->
+// the f16 matrix pipe (fp32-accurate 3-term split) -> coarse ray-march weights -> importance resampling -> second gather/MLP pass ->
 // sorted merge -> wavefront-level alpha composite.  Nothing per-sample ever goes to HBM: the 48+48
 // decoded colours of a ray stay in the wave's MFMA accumulator registers until the composite weights
 // are known, and the composite  sum_k w_k (c_k+c_{k+1})/2  is evaluated as  sum_i omega_i c_i  with
@@ -11,7 +11,7 @@
 // Lane mapping (wave64): lane = (q = lane>>4, s = lane&15).  A "tile" is 16 samples; lane (q,s) owns
 // channels 8q..8q+7 of sample s of each tile, so the four lanes of a sample read one 128-byte
 // channel-last tap as 4 x 32 B and the gathered features ARE the B operand of
-// v_mfma_f32_16x16x4_f32 (k-slot q <-> channel 8q+kk).  The MLP is evaluated transposed
+// v_mfma_f32_16x16x32_f16 (fp16 hi/lo split, 3-term products; k-slot q <-> channels 8q..8q+7).  The MLP is evaluated transposed
 // (H^T = W1 X^T, Y^T = W2 H^T) so layer-1 accumulators feed layer 2 as B operands directly
 // (k-slot q <-> hidden unit 16mt+4q+reg): no LDS round trip between gather, layer 1, softplus, layer 2.
 //
@@ -102,20 +102,19 @@ __global__ void raygen_kernel(const float* __restrict__ c2w, const float* __rest
 
 // -------------------------------------------------------------------------------------------------
 // A2 ray/box limits (math_utils.py:46-98) + global min/max of valid ray starts (renderer.py:123-126)
-// gstate: [0] ord(min tmin over valid), [1] ord(max tmin over valid), [2] any valid,
-//         [3] ord(min depth), [4] ord(max depth)   (depth range for ray_marcher.py:50)
+// gstate: [3] ord(min depth), [4] ord(max depth) (depth range for ray_marcher.py:50; initialised here by block 0, accumulated by the
+// render kernel's atomics); [8 + 3 b .. 8 + 3 b + 2] = block b's {ord(min tmin over valid), ord(max tmin over valid), any valid}:
+// per-block partials instead of atomics on three shared words (no init kernel, no serialised atomics); the render kernel reduces them.
 // -------------------------------------------------------------------------------------------------
-__global__ void init_state_kernel(int* gstate)
-{
-    gstate[0] = 0x7fffffff; gstate[1] = (int)0x80000000; gstate[2] = 0;
-    gstate[3] = 0x7fffffff; gstate[4] = (int)0x80000000;
-}
+static constexpr int kLimitsBlock = 256;
+static constexpr int kStateHeader = 8;                  // ints in front of the per-block partials
 
-__global__ void ray_limits_kernel(const float* __restrict__ origins, const float* __restrict__ dirs,
+__global__ __launch_bounds__(kLimitsBlock) void ray_limits_kernel(const float* __restrict__ origins, const float* __restrict__ dirs,
                                   int nrays, float half, float* __restrict__ ray_start,
                                   float* __restrict__ ray_end, uint8_t* __restrict__ valid, int* gstate)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { gstate[3] = 0x7fffffff; gstate[4] = (int)0x80000000; }
     float tmin = 0.f, tmax = 0.f;
     bool v = false;
     if (r < nrays) {
@@ -138,7 +137,6 @@ __global__ void ray_limits_kernel(const float* __restrict__ origins, const float
         v = tmax > tmin;
         ray_start[r] = tmin; ray_end[r] = tmax; valid[r] = v ? 1 : 0;
     }
-    // wave reduce then one atomic per wave
     int kmin = v ? f2ord(tmin) : 0x7fffffff;
     int kmax = v ? f2ord(tmin) : (int)0x80000000;
 #pragma unroll
@@ -147,10 +145,14 @@ __global__ void ray_limits_kernel(const float* __restrict__ origins, const float
         kmax = max(kmax, __shfl_xor(kmax, d));
     }
     const unsigned long long any = __ballot(v);
-    if ((threadIdx.x & 63) == 0 && any) {
-        atomicMin(&gstate[0], kmin);
-        atomicMax(&gstate[1], kmax);
-        atomicOr(&gstate[2], 1);
+    __shared__ int red[3][kLimitsBlock / 64];
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = kmin; red[1][threadIdx.x >> 6] = kmax; red[2][threadIdx.x >> 6] = any ? 1 : 0; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int* p = gstate + kStateHeader + 3 * blockIdx.x;
+        p[0] = min(min(red[0][0], red[0][1]), min(red[0][2], red[0][3]));
+        p[1] = max(max(red[1][0], red[1][1]), max(red[1][2], red[1][3]));
+        p[2] = red[2][0] | red[2][1] | red[2][2] | red[2][3];
     }
 }
 
@@ -493,7 +495,7 @@ struct RenderArgs {
     const float* w1; const float* b1; const float* w2; const float* b2;
     const float* origins; const float* dirs;
     const float* ray_start; const float* ray_end; const uint8_t* valid;
-    int* gstate;
+    int* gstate; int nlimit_blocks;
     int Nc, Nf; float scale; int white_back;
     const float* noise_c; const float* u_f; unsigned long long seed;
     float* rgb; float* depth; float* wsum;
@@ -539,8 +541,16 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
     const int q = lane >> 4, s = lane & 15;
     RayLds& L = rl[wave];
     const int Nc = a.Nc, Nf = a.Nf, S = Nc + Nf;
-    const float gmin_start = ord2f(a.gstate[0]), gmax_start = ord2f(a.gstate[1]);
-    const bool any_valid = a.gstate[2] != 0;
+    // min / max of the valid rays' starts (renderer.py:123-126): reduce the per-block partials of ray_limits_kernel
+    int pmin = 0x7fffffff, pmax = (int)0x80000000, pany = 0;
+    for (int b = lane; b < a.nlimit_blocks; b += 64) {
+        const int* p = a.gstate + kStateHeader + 3 * b;
+        pmin = min(pmin, p[0]); pmax = max(pmax, p[1]); pany |= p[2];
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { pmin = min(pmin, __shfl_xor(pmin, d)); pmax = max(pmax, __shfl_xor(pmax, d)); pany |= __shfl_xor(pany, d); }
+    const float gmin_start = ord2f(pmin), gmax_start = ord2f(pmax);
+    const bool any_valid = pany != 0;
     float run_min = INFINITY, run_max = -INFINITY;
 
     for (int iter = 0;; ++iter) {
@@ -882,7 +892,8 @@ __global__ __launch_bounds__(256, 2) void run_model_kernel(const float4* __restr
 // -------------------------------------------------------------------------------------------------
 // host side
 // -------------------------------------------------------------------------------------------------
-struct RenderWs { int gstate[8]; };   // followed by ray_start[nrays], ray_end[nrays]
+// workspace: gstate header (8 ints) + 3 ints per ray_limits block, then ray_start[nrays], ray_end[nrays]
+static inline size_t render_state_bytes(size_t nrays) { return ((kStateHeader + 3 * ((nrays + kLimitsBlock - 1) / kLimitsBlock)) * sizeof(int) + 63) & ~(size_t)63; }
 
 template <int NTC, int NTF>
 static void launch_render(const RenderArgs& a, int R, int grid, hipStream_t st)
@@ -930,7 +941,7 @@ extern "C" size_t r3d_render_workspace_bytes(int N, int M, int Nc, int Nf)
 {
     (void)Nc; (void)Nf;
     const size_t nrays = (size_t)N * M;
-    return sizeof(RenderWs) + 2 * nrays * sizeof(float) + 64;
+    return render_state_bytes(nrays) + 2 * nrays * sizeof(float) + 64;
 }
 
 extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W, int triplane_depth,
@@ -954,13 +965,12 @@ extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
     hipStream_t st = (hipStream_t)stream;
     const int nrays = N * M;
     int* gstate = reinterpret_cast<int*>(workspace);
-    float* ray_start = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + sizeof(RenderWs));
+    float* ray_start = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + render_state_bytes(nrays));
     float* ray_end = ray_start + nrays;
 
     {
         ProfScope ps(R3D_PROF_MISC, st);
-        hipLaunchKernelGGL(init_state_kernel, dim3(1), dim3(1), 0, st, gstate);
-        hipLaunchKernelGGL(ray_limits_kernel, dim3((nrays + 255) / 256), dim3(256), 0, st, origins, dirs, nrays,
+        hipLaunchKernelGGL(ray_limits_kernel, dim3((nrays + kLimitsBlock - 1) / kLimitsBlock), dim3(kLimitsBlock), 0, st, origins, dirs, nrays,
                            box_warp * 0.5f, ray_start, ray_end, valid, gstate);
     }
 
@@ -968,7 +978,7 @@ extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
     a.planes4 = reinterpret_cast<const float4*>(planes_nhwc); a.N = N; a.H = H; a.W = W; a.M = M; a.D = triplane_depth;
     a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
     a.origins = origins; a.dirs = dirs; a.ray_start = ray_start; a.ray_end = ray_end; a.valid = valid;
-    a.gstate = gstate; a.Nc = Nc; a.Nf = Nf; a.scale = 2.0f / box_warp; a.white_back = white_back;
+    a.gstate = gstate; a.nlimit_blocks = (nrays + kLimitsBlock - 1) / kLimitsBlock; a.Nc = Nc; a.Nf = Nf; a.scale = 2.0f / box_warp; a.white_back = white_back;
     a.noise_c = noise_c; a.u_f = u_f; a.seed = seed;
     a.rgb = rgb; a.depth = depth; a.wsum = wsum;
 

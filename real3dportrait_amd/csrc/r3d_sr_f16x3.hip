@@ -564,9 +564,13 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
                         const h8 bh = *reinterpret_cast<h8*>(&r0), bl = *reinterpret_cast<h8*>(&r1);
 #pragma unroll
                         for (int mt = 0; mt < 2; ++mt) {
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 1)     // experiment build: operands are still read, no MFMAs
+                            acc[mt][nt][0] += (float)bh[0] + (float)al[mt][0] + (float)ah[mt][0] + (float)bl[0];
+#else
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[mt][nt], 0, 0, 0);
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
+#endif
                         }
                     }
                 }
@@ -574,6 +578,10 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
         }
     }
     __syncthreads();
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 2)             // experiment build: no epilogue (the store keeps the accumulators alive)
+    if (acc[0][0][0] == 123.456f) a.rgb_partial[0] = acc[1][1][3] + acc[0][1][5] + acc[1][0][9];
+    return;
+#endif
     conv_epilogue<FULL_EPI, WN, NT>(a, ph, n, acc, i0, j0, m0, reinterpret_cast<float*>(lds));
 }
 
@@ -1145,6 +1153,7 @@ int sr_prepack_f16x3(int Cin, int Cout, const float* c0_w, const float* c1_w, vo
 
 static void launch_conv2(Conv2Args& a, int tiles, int N, hipStream_t st)
 {
+
     dim3 grid(tiles, a.Cout / BLOCK_M, N * a.nphase);
     static const int shape = getenv("R3D_CONV_SHAPE") ? atoi(getenv("R3D_CONV_SHAPE")) : 0;   // tuning switch, default 0
     const int kind = a.nphase > 1 ? 2 : (a.ph[0].ntaps == 9 ? 0 : 1);      // 0: 3x3 conv, 1: 1x1 conv, 2: transposed-conv phases

@@ -161,3 +161,52 @@ class PipelinedClipRenderer:
         cur = torch.cuda.current_stream()
         for st in self.streams:
             cur.wait_stream(st)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# frame writer: the reference hands uint8 HWC frames to imageio / ffmpeg (inference/real3d_infer.py:472-473,
+# 520-525); there is no ffmpeg in this image, so the clip is written as raw frames a maintainer can pipe into it.
+# ---------------------------------------------------------------------------------------------------------------------
+def _png_bytes(frame):
+    """Minimal PNG encoder (8-bit RGB, filter 0, one IDAT) on zlib + struct: enough for lossless frame dumps without imageio / PIL."""
+    import struct
+    import zlib
+    h, w, _ = frame.shape
+    raw = b"".join(b"\x00" + frame[y].tobytes() for y in range(h))
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+    return (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) +
+            chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
+def write_frames(frames, path, fmt="raw"):
+    """frames: uint8 [T,H,W,3] (torch tensor on any device, or numpy).  fmt:
+      'raw'  one file of packed rgb24 frames (`ffmpeg -f rawvideo -pix_fmt rgb24 -s WxH -r 25 -i clip.raw out.mp4` is the
+             imageio.get_writer(..., format='FFMPEG', codec='h264') of real3d_infer.py:522)
+      'npy'  numpy array file
+      'ppm' / 'png'  one image per frame under the directory `path` (frame_00000.ppm, ...)
+    Returns the list of files written."""
+    import os
+    import numpy as np
+    if hasattr(frames, "detach"):
+        frames = frames.detach().cpu().numpy()
+    frames = np.ascontiguousarray(frames)
+    assert frames.dtype == np.uint8 and frames.ndim == 4 and frames.shape[-1] == 3, (frames.dtype, frames.shape)
+    T, H, W, _ = frames.shape
+    if fmt == "raw":
+        frames.tofile(path)
+        return [path]
+    if fmt == "npy":
+        np.save(path, frames)
+        return [path if path.endswith(".npy") else path + ".npy"]
+    if fmt not in ("ppm", "png"):
+        raise ValueError("fmt must be 'raw', 'npy', 'ppm' or 'png'")
+    os.makedirs(path, exist_ok=True)
+    out = []
+    for t in range(T):
+        fn = os.path.join(path, "frame_%05d.%s" % (t, fmt))
+        with open(fn, "wb") as f:
+            f.write(b"P6\n%d %d\n255\n" % (W, H) + frames[t].tobytes() if fmt == "ppm" else _png_bytes(frames[t]))
+        out.append(fn)
+    return out

@@ -1,5 +1,5 @@
 """BASELINE configs[2]: a 5 s driving clip at 25 fps (125 frames), frame-sharded over the ranks of one node, gathered to
-rank 0 over RCCL and written as raw uint8 frames (.npy; there is no ffmpeg in the image).  Synthetic per-frame inputs of
+rank 0 over RCCL and written by frames.write_frames as packed rgb24 (there is no ffmpeg in the image; R3D_CLIP_FMT = raw | npy | ppm | png).  Synthetic per-frame inputs of
 the reference's shapes: planes_t = cano + secc_t (seeded per frame index), cameras from a smoothed yaw sweep.
 
     python scripts/render_clip.py                     # 1 GPU
@@ -9,7 +9,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch, torch.distributed as dist
 from real3dportrait_amd import TriPlaneGenerator, synth
-from real3dportrait_amd.frames import PipelinedClipRenderer, gather_frames, shard_frames
+from real3dportrait_amd.frames import PipelinedClipRenderer, gather_frames, shard_frames, write_frames
 
 T_FRAMES = int(os.environ.get("R3D_CLIP_FRAMES", 125))
 rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
@@ -43,8 +43,8 @@ clip.sync()
 frames = gather_frames(ring, T_FRAMES)
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 if rank == 0:
-    out = os.environ.get("R3D_CLIP_OUT", "/tmp/clip_u8.npy")
-    np.save(out, frames.cpu().numpy())
+    out = os.environ.get("R3D_CLIP_OUT", "/tmp/clip_u8.raw")          # rgb24: ffmpeg -f rawvideo -pix_fmt rgb24 -s 512x512 -r 25 -i clip_u8.raw ...
+    write_frames(frames, out, os.environ.get("R3D_CLIP_FMT", "raw"))
     print("clip: %d frames on %d GPU(s) in %.1f ms = %.1f frames/s (%.1fx real time at 25 fps) -> %s %s" %
           (T_FRAMES, world, dt * 1e3, T_FRAMES / dt, T_FRAMES / dt / 25.0, out, tuple(frames.shape)))
 if world > 1:

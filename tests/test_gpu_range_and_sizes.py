@@ -413,3 +413,23 @@ def test_plane_cache_is_keyed_on_the_tensor_not_its_address(torch_cuda):
     assert ren._planes_nhwc(p2) is c1
     p2.mul_(2.0)
     assert ren._planes_nhwc(p2) is not c1
+
+
+def test_rccl_gather_frames_single_rank(torch_cuda):
+    """r3d_comm_* / r3d_gather_frames (grouped ncclSend / ncclRecv) on a 1-rank communicator: the root receives its own ring.  (The
+    multi-rank path cannot run on a 1-GPU box; the sharding arithmetic is covered by the gloo tests.)"""
+    import ctypes
+    torch = torch_cuda
+    from real3dportrait_amd import _lib
+    lib = _lib.load()
+    uid = ctypes.create_string_buffer(128)
+    _lib.check(lib.r3d_comm_unique_id(uid), "comm_unique_id")
+    comm = ctypes.c_void_p()
+    _lib.check(lib.r3d_comm_init(uid, 0, 1, ctypes.byref(comm)), "comm_init")
+    local = (torch.arange(3 * 64 * 64 * 3, device="cuda") % 251).to(torch.uint8)
+    root = torch.zeros_like(local)
+    _lib.check(lib.r3d_gather_frames(comm, _lib.ptr(local), local.numel(), _lib.ptr(root), 0, _lib.stream_ptr()), "gather_frames")
+    torch.cuda.synchronize()
+    assert torch.equal(root, local)
+    assert lib.r3d_gather_frames(comm, _lib.ptr(local), local.numel(), None, 0, _lib.stream_ptr()) == -1     # root without a buffer
+    _lib.check(lib.r3d_comm_destroy(comm), "comm_destroy")

@@ -281,3 +281,35 @@ def test_full_size_goldens_are_present_and_consistent():
     assert 0.2 < float(g["masked_frac"]) < 0.6 and g["image_raw"].shape == (1, 3, 128, 128)
     g = load_golden("warp_sr_a")
     assert g["strided"].shape == (1, 3, 128, 128) and float(g["threshold"]) == 0.9
+
+
+def test_write_frames_round_trips(tmp_path):
+    """frames.write_frames: raw rgb24 / npy / ppm / png dumps of a uint8 clip decode back to the same bytes."""
+    import struct, zlib
+    from real3dportrait_amd.frames import write_frames
+    rng = np.random.RandomState(3)
+    clip = rng.randint(0, 256, size=(3, 20, 28, 3)).astype(np.uint8)
+    (raw,) = write_frames(torch.from_numpy(clip), str(tmp_path / "clip.raw"), "raw")
+    assert np.array_equal(np.fromfile(raw, np.uint8).reshape(clip.shape), clip)
+    (npy,) = write_frames(clip, str(tmp_path / "clip"), "npy")
+    assert np.array_equal(np.load(npy), clip)
+    ppm = write_frames(clip, str(tmp_path / "ppm"), "ppm")
+    data = open(ppm[1], "rb").read()
+    assert data.startswith(b"P6\n28 20\n255\n") and np.array_equal(np.frombuffer(data[len(b"P6\n28 20\n255\n"):], np.uint8).reshape(20, 28, 3), clip[1])
+    png = write_frames(clip, str(tmp_path / "png"), "png")
+    data = open(png[2], "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, ihdr = 8, b"", None
+    while pos < len(data):
+        (n,), tag = struct.unpack(">I", data[pos:pos + 4]), data[pos + 4:pos + 8]
+        body = data[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(tag + body) & 0xFFFFFFFF
+        if tag == b"IHDR": ihdr = struct.unpack(">IIBBBBB", body)
+        if tag == b"IDAT": idat += body
+        pos += 12 + n
+    assert ihdr == (28, 20, 8, 2, 0, 0, 0)
+    rows = zlib.decompress(idat)
+    img = np.frombuffer(rows, np.uint8).reshape(20, 1 + 28 * 3)
+    assert (img[:, 0] == 0).all() and np.array_equal(img[:, 1:].reshape(20, 28, 3), clip[2])
+    with pytest.raises(ValueError):
+        write_frames(clip, str(tmp_path / "x"), "gif")
