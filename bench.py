@@ -418,6 +418,36 @@ def main():
                                            "unit": "TFLOP/s", "frac": round(tf_flops / (conv_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
                                            "note": "all conv kernels of the frame (algorithmic FLOPs / summed conv time)"}}
 
+    # ---- the opt-in R3D_SR_F16MX precision (fp8 block-scaled MFMA for the conv correction products): same frames, own parity tier ----
+    if rank == 0 and world == 1 and not args.no_extras and prec == "f16x3":
+        from real3dportrait_amd.frames import PipelinedClipRenderer
+        cano, residuals, cams = scene
+        for b in (G.superresolution.block0, G.superresolution.block1):
+            b.precision = "f16mx"
+        pipe2 = PipelinedClipRenderer(G, cano, residuals, cams, clip.ws, base_seed=clip.base_seed, n_streams=max(1, args.streams))
+        for i in range(2 * max(1, args.streams)):
+            pipe2.render_u8(i % K, out=ring[(i % K):(i % K) + 1])
+        pipe2.sync(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(K):
+            pipe2.render_u8(i, out=ring[i:i + 1])
+        pipe2.sync(); torch.cuda.synchronize()
+        t_mx = (time.perf_counter() - t1) / K
+        lib.r3d_profile_configure(1 << 1); lib.r3d_profile_reset()
+        for i in range(10):
+            clip.render_u8(i % K, out=ring[(i % K):(i % K) + 1])
+        torch.cuda.synchronize()
+        _lib.check(lib.r3d_profile_read(1, ctypes.byref(ms), ctypes.byref(cnt)), "profile_read")
+        lib.r3d_profile_configure(0)
+        mx_ms = ms.value / max(1, cnt.value)
+        out["opt_in_f16mx"] = {"what": "SR precision 'f16mx' (R3D_SR_F16MX): f16x3 with each block's 3x3-conv correction products on the block-scaled "
+                                       "fp8 MFMA; parity tier 5e-5 * max|ref| (tests/test_gpu_mx.py); NOT the default, not `value`",
+                               "value": round(1.0 / t_mx, 2), "ms_per_step": round(t_mx * 1e3, 4), "conv_avg_launch_ms": round(mx_ms, 4),
+                               "conv_algorithmic_tflops": round((flops[1] + flops[3]) / 2 / (mx_ms * 1e-3) / 1e12, 1),
+                               "conv_frac_of_f16_peak": round((flops[1] + flops[3]) / 2 / (mx_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4)}
+        for b in (G.superresolution.block0, G.superresolution.block1):
+            b.precision = "f16x3"
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

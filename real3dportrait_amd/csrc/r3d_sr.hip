@@ -571,13 +571,13 @@ static int sr_check_dims(const char* what, int Cin, int Cout)
 extern "C" int r3d_sr_block_prepack(int Cin, int Cout, const float* c0_w, const float* c1_w, void* prepacked,
                                     int precision, r3d_stream_t stream)
 {
-    if (precision != R3D_SR_F32 && precision != R3D_SR_F16X3) { set_error("sr_block_prepack: unknown precision %d", precision); return R3D_ERR_INVALID_ARG; }
+    if (precision < R3D_SR_F32 || precision > R3D_SR_F16MX) { set_error("sr_block_prepack: unknown precision %d", precision); return R3D_ERR_INVALID_ARG; }
     if (!c0_w || !c1_w || !prepacked) { set_error("sr_block_prepack: NULL pointer"); return R3D_ERR_INVALID_ARG; }
     if (int rc = sr_check_dims("sr_block_prepack", Cin, Cout)) return rc;
     hipStream_t st = (hipStream_t)stream;
     float* out = reinterpret_cast<float*>(prepacked);
     ProfScope ps(R3D_PROF_PACK, st);
-    if (precision == R3D_SR_F16X3) return sr_prepack_f16x3(Cin, Cout, c0_w, c1_w, prepacked, st);
+    if (precision != R3D_SR_F32) return sr_prepack_f16x3(Cin, Cout, c0_w, c1_w, prepacked, st, precision == R3D_SR_F16MX);
     const size_t n0 = (size_t)9 * (Cin / 8) * Cout * 2, n1 = (size_t)9 * (Cout / 8) * Cout * 2;
     hipLaunchKernelGGL(sr_prepack_kernel, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, st, c0_w, Cin, Cout, out);
     hipLaunchKernelGGL(sr_prepack_kernel, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, st, c1_w, Cout, Cout,
@@ -611,17 +611,18 @@ extern "C" int r3d_sr_block_forward(const void* prepacked, const void* styles, i
                                     float* img_out, uint8_t* img_u8, float* x_absmax, int precision,
                                     void* workspace, size_t workspace_bytes, r3d_stream_t stream)
 {
-    if (precision != R3D_SR_F32 && precision != R3D_SR_F16X3) { set_error("sr_block_forward: unknown precision %d", precision); return R3D_ERR_INVALID_ARG; }
-    if ((img_u8 || x_absmax) && precision != R3D_SR_F16X3) { set_error("sr_block_forward: the fused uint8 output / x_absmax need R3D_SR_F16X3"); return R3D_ERR_INVALID_ARG; }
+    if (precision < R3D_SR_F32 || precision > R3D_SR_F16MX) { set_error("sr_block_forward: unknown precision %d", precision); return R3D_ERR_INVALID_ARG; }
+    if (precision == R3D_SR_F16MX && !up) { set_error("sr_block_forward: R3D_SR_F16MX covers up=1 blocks (SynthesisBlockNoUp: use R3D_SR_F16X3)"); return R3D_ERR_UNSUPPORTED; }
+    if ((img_u8 || x_absmax) && precision == R3D_SR_F32) { set_error("sr_block_forward: the fused uint8 output / x_absmax need R3D_SR_F16X3"); return R3D_ERR_INVALID_ARG; }
     if (!prepacked || !styles || !x || !img || (!img_out && !img_u8) || N <= 0 || Hin <= 0 || Win <= 0 || (Cin & 15) || (Cout % BLOCK_M) || (up != 0 && up != 1)) {
         set_error("sr_block_forward: bad argument"); return R3D_ERR_INVALID_ARG;
     }
-    if (!up && precision != R3D_SR_F16X3) { set_error("sr_block_forward: up=0 (SynthesisBlockNoUp) needs R3D_SR_F16X3"); return R3D_ERR_INVALID_ARG; }
+    if (!up && precision == R3D_SR_F32) { set_error("sr_block_forward: up=0 (SynthesisBlockNoUp) needs R3D_SR_F16X3"); return R3D_ERR_INVALID_ARG; }
     if (!workspace || workspace_bytes < r3d_sr_block_workspace_bytes(N, Cin, Cout, Hin, Win)) {
         set_error("sr_block_forward: workspace too small"); return R3D_ERR_WORKSPACE;
     }
     if (!x_out) x_out_format = R3D_FMT_NONE;
-    const bool f16 = precision == R3D_SR_F16X3;
+    const bool f16 = precision != R3D_SR_F32;
     if (x_format < R3D_FMT_NCHW || x_format > R3D_FMT_SPLIT || x_out_format < R3D_FMT_NONE || x_out_format > R3D_FMT_SPLIT ||
         (!f16 && (x_format == R3D_FMT_SPLIT || x_out_format == R3D_FMT_SPLIT)) ||
         (x_out_format == R3D_FMT_SPLIT && !next_scale)) {
@@ -631,7 +632,7 @@ extern "C" int r3d_sr_block_forward(const void* prepacked, const void* styles, i
     hipStream_t st = (hipStream_t)stream;
     if (f16)
         return sr_block_forward_f16x3(prepacked, styles, N, Cin, Cout, Hin, Win, up, x, x_format, img, clamp, x_out, x_out_format,
-                                      next_scale, next_scale_stride, img_out, img_u8, x_absmax, workspace, workspace_bytes, st);
+                                      next_scale, next_scale_stride, img_out, img_u8, x_absmax, workspace, workspace_bytes, st, precision == R3D_SR_F16MX);
 
     const SrStyleLayout L = sr_style_layout(Cin, Cout);
     const float* pk = reinterpret_cast<const float*>(styles);

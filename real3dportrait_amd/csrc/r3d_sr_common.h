@@ -96,11 +96,11 @@ void sr_fill_tconv_phases(ConvPhase* ph, int Hin, int Win);
 void sr_fill_conv3x3_phase(ConvPhase* ph, int H, int W);
 
 // f16x3 implementation (r3d_sr_f16x3.hip)
-int sr_prepack_f16x3(int Cin, int Cout, const float* c0_w, const float* c1_w, void* prepacked, hipStream_t st);
+int sr_prepack_f16x3(int Cin, int Cout, const float* c0_w, const float* c1_w, void* prepacked, hipStream_t st, bool mx);
 int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int Cin, int Cout, int Hin, int Win, int up,
                            const void* x, int x_format, const float* img, float clamp,
                            void* x_out, int x_out_format, const float* next_scale, size_t next_scale_stride,
-                           float* img_out, uint8_t* img_u8, float* x_absmax, void* workspace, size_t workspace_bytes, hipStream_t st);
+                           float* img_out, uint8_t* img_u8, float* x_absmax, void* workspace, size_t workspace_bytes, hipStream_t st, bool mx);
 
 size_t conv_prepacked_bytes_f16x3(int Cin, int Cout, int ksize);
 int conv_prepack_f16x3(const float* w, int Cin, int Cout, int ksize, void* prepacked, hipStream_t st);

@@ -40,6 +40,29 @@ __device__ __forceinline__ void split1(float v, _Float16& hi, _Float16& lo)
     lo = (_Float16)(v - (float)hi);
 }
 
+// ---- "f16mx": the two 2^-11-sized correction products on the block-scaled fp8 MFMA (R3D_SR_F16MX) -------------------------------------
+// A product is x*w = xh*wh + (xh*wl + xl*wh) (+ xl*wl ~ 2^-22, dropped as in f16x3).  f16x3 spends two f16 MFMAs per K = 16 on the bracket;
+// here the bracket of TWO taps x 16 channels is ONE v_mfma_scale_f32_32x32x64_f8f6f4 (OCP e4m3, 2x the f16 rate):
+//     B lane (pixel, h):  32 bytes  [ xh8 (16 ch) | xl8 (16 ch) ]  of tap h        xh8 = fp8(hi * 2^-7),  xl8 = fp8(lo * 2^4)
+//     A lane (cout,  h):  32 bytes  [ wl8 (16 ch) | wh8 (16 ch) ]  of tap h        wl8 = fp8(wl * 2^8),   wh8 = fp8(wh * 2^-3)
+// (operand layout probed on the GPU: lane l holds row / column l % 32 and k = 32 * (l / 32) + byte, scripts/probes/mx_correction_probe.hip);
+// the E8M0 scale operands supply the common factor 2^-1.  The stored operands obey the range fold of r3d_sr_common.h (|hi| < 2^15,
+// |w| < 2^11), so every fp8 value is below 2^8 < 448; the correction is accurate to fp8 rounding (2^-4), i.e. ~2^-16 of the product:
+// between fp32 (2^-24) and TF32 (2^-11).  It needs the conv1 operand to sit within ~6 binades of its bound (a bound at most one layer
+// from a measurement), which is what the block's range fold provides (see SuperresolutionHybrid8XDC.forward).
+// In memory the fp8 records take the place of the fp16 lo plane with the SAME addressing: "lo" chunk 2G holds xh8 (wl8) of the 16
+// channels 16G..16G+15, chunk 2G+1 holds xl8 (wh8) -- so every DMA of the f16x3 kernels is unchanged.
+static constexpr int kMxScaleA = 127, kMxScaleB = 126;     // E8M0 bytes: 2^0 * 2^-1
+static constexpr float kMxXh = 0.0078125f /* 2^-7 */, kMxXl = 16.0f /* 2^4 */, kMxWl = 256.0f /* 2^8 */, kMxWh = 0.125f /* 2^-3 */;
+
+__device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d)
+{
+    int v = 0;
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return (unsigned)v;
+}
+
 // ---- per-cout statistics of a weight tensor [CoutReal][row_len]: tail = {2^-kw[co], sum|w[co]|} (ConvTail), padded couts -> {1, 0}.
 // kw[co] = weight_row_exp(max|w[co]|): the row is stored as w * 2^kw (max in [2^10, 2^11)) and the conv epilogue multiplies by
 // 2^-kw -- exact, and it makes the fp16 hi/lo split independent of the overall magnitude of the trained weights.
@@ -63,6 +86,42 @@ __global__ void weight_row_stats_kernel(const float* __restrict__ w, int row_len
 }
 
 // ---- weights: [tap][ci/8][hi|lo][cout] x 8 halfs (hi and lo in separate 16-byte planes: conflict-free ds_read_b128) ----
+// MX variant of the same layout (R3D_SR_F16MX): the hi rows are unchanged; the "lo" row of chunk 2G holds wl8 of the 16 channels of
+// group G, the "lo" row of chunk 2G+1 their wh8 (one thread per (tap, 16-channel group, cout)).
+__global__ void sr_prepack_mx_kernel(const float* __restrict__ w, int CiReal, int CoutReal, int ntaps, int Ci, int Cout,
+                                     const float* __restrict__ winv, uint4* __restrict__ out)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;      // (tap, group, cout)
+    const size_t total = (size_t)ntaps * (Ci / 16) * Cout;
+    if (e >= total) return;
+    const int co = e % Cout;
+    const int grp = (e / Cout) % (Ci / 16);
+    const int tap = (int)(e / Cout / (Ci / 16));
+    const float ws = 1.0f / winv[co];
+    float hi[16], lo[16];
+    h8 h0, h1;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int ci = grp * 16 + j;
+        const float v = (co < CoutReal && ci < CiReal) ? w[((size_t)co * CiReal + ci) * ntaps + tap] * ws : 0.f;
+        _Float16 a, b; split1(v, a, b);
+        hi[j] = (float)a; lo[j] = v - (float)a;
+        if (j < 8) h0[j] = a; else h1[j - 8] = a;
+    }
+    uint4 wl8, wh8;
+    unsigned* pl = reinterpret_cast<unsigned*>(&wl8); unsigned* ph = reinterpret_cast<unsigned*>(&wh8);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        pl[q] = pack4_fp8(lo[4 * q] * kMxWl, lo[4 * q + 1] * kMxWl, lo[4 * q + 2] * kMxWl, lo[4 * q + 3] * kMxWl);
+        ph[q] = pack4_fp8(hi[4 * q] * kMxWh, hi[4 * q + 1] * kMxWh, hi[4 * q + 2] * kMxWh, hi[4 * q + 3] * kMxWh);
+    }
+    const size_t base = ((size_t)tap * (Ci / 8) + 2 * grp) * 2 * Cout + co;      // [tap][chunk][hi|lo][cout]
+    out[base] = *reinterpret_cast<uint4*>(&h0);
+    out[base + Cout] = wl8;
+    out[base + 2 * Cout] = *reinterpret_cast<uint4*>(&h1);
+    out[base + 3 * Cout] = wh8;
+}
+
 __global__ void sr_prepack_f16_kernel(const float* __restrict__ w, int CiReal, int CoutReal, int ntaps, int Ci, int Cout,
                                       const float* __restrict__ winv, uint4* __restrict__ out)
 {
@@ -124,6 +183,24 @@ __device__ __forceinline__ void dma64(const uint4* gsrc, uint4* lds_dst_uniform)
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(d) : "memory");
+}
+
+// saddr form: 64 lanes x 16 B from (wave-uniform base + per-lane 32-bit byte offset): one VGPR per distinct lane pattern instead of a
+// 64-bit address pair per source.  The masked variant skips the lanes whose bit in `mask` is clear (their LDS slots keep what they
+// hold: the caller zero-fills halo slots once per block).
+__device__ __forceinline__ void dma64s(const void* base_uniform, unsigned voff_bytes, uint4* lds_dst_uniform)
+{
+    const unsigned d = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) uint4*)lds_dst_uniform);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff_bytes), "s"(base_uniform), "s"(d) : "memory");
+}
+__device__ __forceinline__ void dma64s_masked(const void* base_uniform, unsigned voff_bytes, unsigned long long mask, uint4* lds_dst_uniform)
+{
+    const unsigned d = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) uint4*)lds_dst_uniform);
+    unsigned keep; unsigned long long save;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_and_saveexec_b64 %1, %5\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b64 exec, %1\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep), "=&s"(save) : "v"(voff_bytes), "s"(base_uniform), "s"(d), "s"(mask) : "memory", "scc");
 }
 
 // ---- conv ----------------------------------------------------------------------------------------------------
@@ -448,7 +525,9 @@ static constexpr int P_SEGS = 21, P_BUF = P_SEGS * 64;               // 1344 uin
 static constexpr int W2_BUF = 2 * 2 * 2 * 128;                        // 1024 uint4 per 2-tap weight sub-stage
 static constexpr int F3_LDS_UINT4 = 2 * P_BUF + 2 * W2_BUF;           // 4736 uint4 = 75.8 KB
 
-template <bool FULL_EPI>
+typedef int i8v __attribute__((ext_vector_type(8)));
+
+template <bool FULL_EPI, bool MX = false>
 __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const ConvPhase& ph, int n, uint4* lds)
 {
     constexpr int WN = 4, NT = 2;
@@ -504,11 +583,36 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
         pf_off[k] = off;
     }
     const bool three = wave_u < P_SEGS - 16;                          // waves 0..4 issue three patch DMAs, the others two
+    // MX (register budget: 16 more operand VGPRs than f16x3): saddr-form DMAs -- no per-source 64-bit address pairs -- with the
+    // out-of-image slots zero-filled ONCE here (both buffers) and skipped by every stage's DMA (exec mask) instead of reading a zero block
+    unsigned long long pmask[3] = {0, 0, 0};
+    unsigned pf_boff[3] = {0, 0, 0};
+    const unsigned lane16 = (unsigned)lane * 16u;
+    if constexpr (MX) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            pmask[k] = __ballot((pf_valid >> k) & 1u);
+            pf_boff[k] = pf_off[k] * 16u;
+            if ((k < 2 || three) && !((pf_valid >> k) & 1u)) {
+                pbuf[64 * (8 * k + wave_u) + lane] = make_uint4(0, 0, 0, 0);
+                pbuf[P_BUF + 64 * (8 * k + wave_u) + lane] = make_uint4(0, 0, 0, 0);
+            }
+        }
+        __syncthreads();                                              // zero fill done before any DMA is in flight
+    }
     auto dma_patch = [&](int st, uint4* dst) {
         const uint4* Xs = X + (size_t)(2 * st) * chunk_stride;
 #pragma unroll
         for (int k = 0; k < 3; ++k)
-            if (k < 2 || three) dma64((pf_valid & (1u << k)) ? Xs + pf_off[k] : g_zero16, dst + 64 * (8 * k + wave_u));
+            if (k < 2 || three) {
+                if constexpr (MX) {
+                    // (a fully out-of-image segment still issues one DMA -- of the zero block -- so that the counted vmcnt waits hold)
+                    if (pmask[k]) dma64s_masked(Xs, pf_boff[k], pmask[k], dst + 64 * (8 * k + wave_u));
+                    else dma64(g_zero16, dst + 64 * (8 * k + wave_u));
+                } else {
+                    dma64((pf_valid & (1u << k)) ? Xs + pf_off[k] : g_zero16, dst + 64 * (8 * k + wave_u));
+                }
+            }
     };
     // weights of linear tap T (stage T / 9, tap T % 9) -> slot ts of a sub-stage buffer; wave w moves (chunk, hi|lo, cout half)
     // = bits (2, 1, 0) of w for both taps of the sub-stage
@@ -519,7 +623,13 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
             if (T < 9 * nst) {
                 const int st = T / 9, t = T - 9 * st;
                 const int hc = (wave_u >> 2) & 1, hl = (wave_u >> 1) & 1;
-                dma64(WP + (((size_t)ph.widx[t] * nchunks + (2 * st + hc)) * 2 + hl) * a.Cout, dst + ts * 512 + wave_u * 64);
+                if constexpr (MX)
+                    dma64s(a.wp + m0 + (wave_u & 1) * 64 + (((size_t)ph.widx[t] * nchunks + (2 * st + hc)) * 2 + hl) * a.Cout, lane16,
+                           dst + ts * 512 + wave_u * 64);
+                else
+                    dma64(WP + (((size_t)ph.widx[t] * nchunks + (2 * st + hc)) * 2 + hl) * a.Cout, dst + ts * 512 + wave_u * 64);
+            } else if (MX && ts == 1 && T0 < 9 * nst) {
+                dma64(g_zero16, dst + ts * 512 + wave_u * 64);       // the fp8 pair-MFMA reads both taps: a missing second tap contributes 0
             }
         }
     };
@@ -533,7 +643,9 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
             const int T0 = 9 * sp + 2 * uu;                           // first linear tap of this sub-stage
             if (T0 >= 9 * nst) break;
             // a patch DMA was issued AFTER the weights this sub-stage needs (at the top of uu = 0 / 5): leave it in flight
-            const bool patch_behind = (uu == 1 && sp + 1 < nst) || (uu == 6 && sp + 2 < nst);
+            // (MX: the register allocator spills a few loop invariants to scratch, and scratch traffic shares vmcnt: the counted wait
+            // would no longer name the right instruction, so that instantiation always drains -- the patch DMA has had a full sub-stage)
+            const bool patch_behind = !MX && ((uu == 1 && sp + 1 < nst) || (uu == 6 && sp + 2 < nst));
             if (patch_behind) {
                 if (three) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -553,27 +665,67 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
                     h8 ah[2], al[2];
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
-                        uint4 q0 = curW[ts * 512 + aoff + mt * 32], q1 = curW[ts * 512 + aoff + mt * 32 + 128];
-                        ah[mt] = *reinterpret_cast<h8*>(&q0); al[mt] = *reinterpret_cast<h8*>(&q1);
+                        uint4 q0 = curW[ts * 512 + aoff + mt * 32];
+                        ah[mt] = *reinterpret_cast<h8*>(&q0);
+                        if (!MX) { uint4 q1 = curW[ts * 512 + aoff + mt * 32 + 128]; al[mt] = *reinterpret_cast<h8*>(&q1); }
                     }
                     const int toff = ph.dy[t] * F_PATCH_W + ph.dx[t];
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         uint4 r0 = curP[boff[nt] + toff];
-                        uint4 r1 = curP[boff[nt] + toff + 2 * F_PATCH_PIX];
-                        const h8 bh = *reinterpret_cast<h8*>(&r0), bl = *reinterpret_cast<h8*>(&r1);
+                        const h8 bh = *reinterpret_cast<h8*>(&r0);
+                        h8 bl;
+                        if (!MX) { uint4 r1 = curP[boff[nt] + toff + 2 * F_PATCH_PIX]; bl = *reinterpret_cast<h8*>(&r1); }
 #pragma unroll
                         for (int mt = 0; mt < 2; ++mt) {
-#if defined(R3D_ABLATE) && (R3D_ABLATE & 1)     // experiment build: operands are still read, no MFMAs
-                            acc[mt][nt][0] += (float)bh[0] + (float)al[mt][0] + (float)ah[mt][0] + (float)bl[0];
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 1)     // experiment build: operands are still read (kept alive), no MFMAs
+                            asm volatile("" :: "v"(bh), "v"(ah[mt]));
+                            if (!MX) asm volatile("" :: "v"(bl), "v"(al[mt]));
 #else
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[mt][nt], 0, 0, 0);
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
+                            if (!MX) {
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[mt][nt], 0, 0, 0);
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
+                            }
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
 #endif
                         }
                     }
                 }
+            }
+            if constexpr (MX) {
+                // the correction products of BOTH taps of this sub-stage in one K = 64 fp8 MFMA per tile: lane half h <-> tap ts = h.
+                // (a missing second tap -- last sub-stage of an odd stage count -- has all-zero weight rows, see dma_weights2.)
+                // One B record and one A record live at a time (8 + 8 VGPRs): the kernel has 64 registers besides its accumulators.
+                const int Tl0 = 2 * uu, Tl1 = 2 * uu + 1;
+                const int sl0 = Tl0 / 9, t0 = Tl0 - 9 * sl0, sl1 = Tl1 / 9, t1 = Tl1 - 9 * sl1;
+                const int toffa = ph.dy[t0] * F_PATCH_W + ph.dx[t0], toffb = ph.dy[t1] * F_PATCH_W + ph.dx[t1];
+                __builtin_amdgcn_sched_barrier(0);                  // fp8 operand loads stay behind this sub-stage's f16 MFMAs (register budget)
+                int hh = h;
+                asm volatile("" : "+v"(hh));                        // keep the per-sub-stage address arithmetic inside the loop (9 hoisted VGPRs spill)
+                // this lane half's tap: its stage's "lo" plane, pixel slot without the f16 chunk offset h * F_PATCH_PIX
+                const int p8 = 2 * F_PATCH_PIX + sl0 * P_BUF + toffa + hh * ((sl1 - sl0) * P_BUF + toffb - toffa - F_PATCH_PIX);
+                const uint4* P8 = pbuf + p8;
+                const uint4* W8 = curW + 128 + aoff + hh * 256;                                           // [ts = h][chunk][lo row][cout]: aoff has h * 256
+                i8v a8[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const uint4 q0 = W8[mt * 32], q1 = W8[mt * 32 + 256];
+                    a8[mt] = (i8v){(int)q0.x, (int)q0.y, (int)q0.z, (int)q0.w, (int)q1.x, (int)q1.y, (int)q1.z, (int)q1.w};
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const uint4 r0 = P8[boff[nt]], r1 = P8[boff[nt] + F_PATCH_PIX];
+                    const i8v b8 = (i8v){(int)r0.x, (int)r0.y, (int)r0.z, (int)r0.w, (int)r1.x, (int)r1.y, (int)r1.z, (int)r1.w};
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 4)     // experiment build: no fp8 MFMAs
+                        asm volatile("" :: "v"(a8[mt]), "v"(b8));
+#else
+                        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[mt], b8, acc[mt][nt], 0, 0, 0, kMxScaleA, 0, kMxScaleB);
+#endif
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -588,12 +740,12 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
 static constexpr int F_LDS_UINT4 = 2 * 2 * F_PATCH_PIX + 2 * 3 * 2 * 256;      // patch (20.7 KB) + 2 x 3-tap weight sub-stage (2 x 24.6 KB)
 
 // plain 3x3 conv (9 taps)
-template <int WN, int NT, int OCC>
+template <int WN, int NT, int OCC, bool MX = false>
 __global__ __launch_bounds__(128 * WN, OCC) void conv_mfma_f16x3_kernel(Conv2Args a)
 {
     if constexpr (WN == 4 && NT == 2) {
         __shared__ uint4 lds[F3_LDS_UINT4];
-        conv3x3_dma_block<true>(a, a.ph[0], blockIdx.z, lds);
+        conv3x3_dma_block<true, MX>(a, a.ph[0], blockIdx.z, lds);
     } else {
         __shared__ uint4 lds[F_LDS_UINT4];
         conv2_block<9, true, WN, NT>(a, a.ph[0], blockIdx.z, lds);
@@ -673,7 +825,9 @@ __global__ void sr_prepack_up_kernel(const float* __restrict__ w, int Cin, int C
     out[e] = *reinterpret_cast<uint4*>(&v8);
 }
 
-template <bool CLAMP>
+// MX = true (R3D_SR_F16MX): the output feeds the f16mx 3x3 conv: hi plane as usual, and in place of the fp16 lo words the fp8 records
+// (lo chunk 2G <- xh8 of channels 16G..16G+15, lo chunk 2G+1 <- xl8): slice g (8 couts) owns bytes [8 (g & 1), +8) of both words.
+template <bool CLAMP, bool MX = false>
 __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
 {
     __shared__ uint4 lds[U_LDS_UINT4];
@@ -876,12 +1030,27 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
                     // lanes 2j (couts 0-3) and 2j+1 (couts 4-7) hold the same pixel: each stores its 8-byte half of the 16-byte
                     // hi word and of the lo word (a wave store covers 32 pixels x 16 contiguous bytes per plane)
                     const uint2 hw = make_uint2(*reinterpret_cast<const unsigned*>(&hia), *reinterpret_cast<const unsigned*>(&hib));
-                    const uint2 lw = make_uint2(*reinterpret_cast<const unsigned*>(&loa), *reinterpret_cast<const unsigned*>(&lob));
                     const int oy = 2 * (i0 + rp) + dy, ox = 2 * j0 + oc;
-                    if (live && oy < OH && ox < OW) {
-                        uint2* d2 = reinterpret_cast<uint2*>(d + (size_t)oy * OW + ox) + half;
-                        d2[0] = hw;
-                        d2[2 * oplane] = lw;
+                    if constexpr (MX) {
+                        const f2 fha = __builtin_convertvector(hia, f2), fhb = __builtin_convertvector(hib, f2);
+                        const f2 fla = va - fha, flb = vb - fhb;
+                        const unsigned xh8 = pack4_fp8(fha.x * kMxXh, fha.y * kMxXh, fhb.x * kMxXh, fhb.y * kMxXh);
+                        const unsigned xl8 = pack4_fp8(fla.x * kMxXl, fla.y * kMxXl, flb.x * kMxXl, flb.y * kMxXl);
+                        if (live && oy < OH && ox < OW) {
+                            const size_t pix = (size_t)oy * OW + ox;
+                            reinterpret_cast<uint2*>(d + pix)[half] = hw;
+                            // fp8 records of the 16-channel group (cg * 2 + (g >> 1)): even lo chunk = xh8, odd lo chunk = xl8
+                            uint4* rec = a.y + (size_t)n * a.y_stride_n + oplane + (size_t)((co0 >> 3) + (g & ~1)) * OH * OW + pix;    // lo plane
+                            reinterpret_cast<unsigned*>(rec)[2 * (g & 1) + half] = xh8;
+                            reinterpret_cast<unsigned*>(rec + (size_t)OH * OW)[2 * (g & 1) + half] = xl8;
+                        }
+                    } else {
+                        const uint2 lw = make_uint2(*reinterpret_cast<const unsigned*>(&loa), *reinterpret_cast<const unsigned*>(&lob));
+                        if (live && oy < OH && ox < OW) {
+                            uint2* d2 = reinterpret_cast<uint2*>(d + (size_t)oy * OW + ox) + half;
+                            d2[0] = hw;
+                            d2[2 * oplane] = lw;
+                        }
                     }
                 }
             }
@@ -1131,7 +1300,7 @@ int upsample2x_bilinear_f16x3(const float* x_cb8, int N, int C, int H, int W, vo
 
 // ---- host ------------------------------------------------------------------------------------------------------
 // prepacked = conv0 (plain layout) ++ conv1 ++ conv0 (fused up-conv layout) ++ ConvTail(conv0) ++ ConvTail(conv1)
-int sr_prepack_f16x3(int Cin, int Cout, const float* c0_w, const float* c1_w, void* prepacked, hipStream_t st)
+int sr_prepack_f16x3(int Cin, int Cout, const float* c0_w, const float* c1_w, void* prepacked, hipStream_t st, bool mx)
 {
     float* out = reinterpret_cast<float*>(prepacked);
     const size_t m0 = (size_t)9 * (Cin / 8) * Cout, m1 = (size_t)9 * (Cout / 8) * Cout;
@@ -1142,8 +1311,12 @@ int sr_prepack_f16x3(int Cin, int Cout, const float* c0_w, const float* c1_w, vo
     hipLaunchKernelGGL(weight_row_stats_kernel, dim3(Cout), dim3(256), 0, st, c1_w, Cout * 9, Cout, Cout, tail1);
     hipLaunchKernelGGL(sr_prepack_f16_kernel, dim3((unsigned)((m0 + 255) / 256)), dim3(256), 0, st, c0_w, Cin, Cout, 9, Cin, Cout,
                        tail0 + T.winv, reinterpret_cast<uint4*>(out));
-    hipLaunchKernelGGL(sr_prepack_f16_kernel, dim3((unsigned)((m1 + 255) / 256)), dim3(256), 0, st, c1_w, Cout, Cout, 9, Cout, Cout,
-                       tail1 + T.winv, reinterpret_cast<uint4*>(out + (size_t)9 * Cin * Cout));
+    if (mx)         // conv1 consumes the fp8 records of the up-sampling conv's epilogue (R3D_SR_F16MX)
+        hipLaunchKernelGGL(sr_prepack_mx_kernel, dim3((unsigned)((m1 / 2 + 255) / 256)), dim3(256), 0, st, c1_w, Cout, Cout, 9, Cout, Cout,
+                           tail1 + T.winv, reinterpret_cast<uint4*>(out + (size_t)9 * Cin * Cout));
+    else
+        hipLaunchKernelGGL(sr_prepack_f16_kernel, dim3((unsigned)((m1 + 255) / 256)), dim3(256), 0, st, c1_w, Cout, Cout, 9, Cout, Cout,
+                           tail1 + T.winv, reinterpret_cast<uint4*>(out + (size_t)9 * Cin * Cout));
     // conv0 again in the fused up-conv layout (SynthesisBlock; the plain layout above serves SynthesisBlockNoUp)
     const size_t mu = (size_t)9 * (Cin / 8) * Cout * 2;
     hipLaunchKernelGGL(sr_prepack_up_kernel, dim3((unsigned)((mu + 255) / 256)), dim3(256), 0, st, c0_w, Cin, Cout, tail0 + T.winv,
@@ -1151,7 +1324,7 @@ int sr_prepack_f16x3(int Cin, int Cout, const float* c0_w, const float* c1_w, vo
     return check_launch("sr_block_prepack");
 }
 
-static void launch_conv2(Conv2Args& a, int tiles, int N, hipStream_t st)
+static void launch_conv2(Conv2Args& a, int tiles, int N, hipStream_t st, bool mx = false)
 {
 
     dim3 grid(tiles, a.Cout / BLOCK_M, N * a.nphase);
@@ -1162,7 +1335,8 @@ static void launch_conv2(Conv2Args& a, int tiles, int N, hipStream_t st)
         else if (kind == 1) hipLaunchKernelGGL((conv1x1_mfma_f16x3_kernel<2, 4, 2>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((tconv_mfma_f16x3_kernel<2, 4, 2>), grid, dim3(256), 0, st, a);
     } else {                    // 8 waves x (64 couts x 64 px): 4 waves/SIMD at 2 blocks/CU
-        if (kind == 0) hipLaunchKernelGGL((conv_mfma_f16x3_kernel<4, 2, 4>), grid, dim3(512), 0, st, a);
+        if (kind == 0 && mx) hipLaunchKernelGGL((conv_mfma_f16x3_kernel<4, 2, 4, true>), grid, dim3(512), 0, st, a);
+        else if (kind == 0) hipLaunchKernelGGL((conv_mfma_f16x3_kernel<4, 2, 4>), grid, dim3(512), 0, st, a);
         else if (kind == 1) hipLaunchKernelGGL((conv1x1_mfma_f16x3_kernel<4, 2, 4>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((tconv_mfma_f16x3_kernel<4, 2, 4>), grid, dim3(512), 0, st, a);
     }
@@ -1173,7 +1347,7 @@ static int tiles_of(int H, int W) { return ((W + F_TILE_W - 1) / F_TILE_W) * ((H
 int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int Cin, int Cout, int Hin, int Win, int up,
                            const void* x, int x_format, const float* img, float clamp,
                            void* x_out, int x_out_format, const float* next_scale, size_t next_scale_stride,
-                           float* img_out, uint8_t* img_u8, float* x_absmax, void* workspace, size_t workspace_bytes, hipStream_t st)
+                           float* img_out, uint8_t* img_u8, float* x_absmax, void* workspace, size_t workspace_bytes, hipStream_t st, bool mx)
 {
     (void)workspace_bytes;
     const SrStyleLayout L = sr_style_layout(Cin, Cout);
@@ -1210,8 +1384,11 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
         u.tiles_per_xcd = (u.ntiles + 7) / 8;
         u.clamp = clamp;
         ProfScope ps(R3D_PROF_UPCONV, st);
-        if (clamp >= 0.f) hipLaunchKernelGGL(upconv_fir_f16x3_kernel<true>, dim3(8 * u.tiles_per_xcd * (Cout / 32), N), dim3(256), 0, st, u);
-        else hipLaunchKernelGGL(upconv_fir_f16x3_kernel<false>, dim3(8 * u.tiles_per_xcd * (Cout / 32), N), dim3(256), 0, st, u);
+        const dim3 ugrid(8 * u.tiles_per_xcd * (Cout / 32), N);
+        if (mx && clamp >= 0.f) hipLaunchKernelGGL((upconv_fir_f16x3_kernel<true, true>), ugrid, dim3(256), 0, st, u);
+        else if (mx) hipLaunchKernelGGL((upconv_fir_f16x3_kernel<false, true>), ugrid, dim3(256), 0, st, u);
+        else if (clamp >= 0.f) hipLaunchKernelGGL(upconv_fir_f16x3_kernel<true>, ugrid, dim3(256), 0, st, u);
+        else hipLaunchKernelGGL(upconv_fir_f16x3_kernel<false>, ugrid, dim3(256), 0, st, u);
     } else if (up) {
         // ---- conv0: stride-2 transposed conv as 4 phases -> T (demodulated, fp32), then FIR + bias + lrelu -> SPLIT ----
         {
@@ -1267,7 +1444,7 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
         a.act = 1; a.act_slope = 0.2f; a.act_gain = 1.4142135623730951f; a.clamp = clamp;
         sr_fill_conv3x3_phase(a.ph, OH, OW);
         ProfScope ps(R3D_PROF_CONV, st);
-        launch_conv2(a, tiles_of(OH, OW), N, st);
+        launch_conv2(a, tiles_of(OH, OW), N, st, mx);
     }
     (void)xo;
     {

@@ -187,7 +187,8 @@ class SynthesisBlock(nn.Module):
         self.out_format = "nchw"       # 'nchw' (reference layout) | 'cb8' | 'split' (f16x3 hand-off, needs _next)
         self.return_x = True           # False: skip materialising x (last block of SuperresolutionHybrid8XDC)
         # 'f16x3': fp32-accurate 3-term fp16 split on the f16 matrix pipe (default, ~5x faster);
-        # 'f32': exact fp32 MFMA.  Override per module or with R3D_SR_PRECISION.
+        # 'f32': exact fp32 MFMA;  'f16mx' (opt-in): f16x3 with conv1's correction products on the block-scaled fp8 MFMA
+        # (~2^-16 per product, 1.5x fewer matrix cycles; SynthesisBlock only).  Override per module or with R3D_SR_PRECISION.
         self.precision = os.environ.get("R3D_SR_PRECISION", "f16x3")
         self._prepacked = None
         self._prepack_key = None
@@ -206,6 +207,11 @@ class SynthesisBlock(nn.Module):
         return t
 
     _FMT = {"none": -1, "nchw": 0, "cb8": 1, "split": 2}
+    _PREC = {"f32": 0, "f16x3": 1, "f16mx": 2}
+
+    def _prec(self):
+        p = self._PREC[self.precision]
+        return 1 if (p == 2 and not self._UP) else p          # SynthesisBlockNoUp has no fp8 path: f16x3
 
     def _clamp(self):
         return -1.0 if self.conv_clamp is None else float(self.conv_clamp)
@@ -223,7 +229,7 @@ class SynthesisBlock(nn.Module):
                   tr.weight, tr.bias, tr.affine.weight, tr.affine.bias)
         keep = [_f32c(t) for t in params]
         dev = keep[0].device if dev is None else dev
-        prec = {"f32": 0, "f16x3": 1}[self.precision]
+        prec = self._prec()
         key = (keep[0].data_ptr(), c0.weight._version, keep[4].data_ptr(), c1.weight._version, str(dev), prec)
         if self._prepack_key != key:
             pre = self._buf("_prepacked", int(lib.r3d_sr_block_prepacked_bytes(Cin, Cout)), dev)
@@ -284,10 +290,11 @@ class SynthesisBlock(nn.Module):
         Cin, Cout = self.in_channels, self.out_channels
         dev = img.device
         st = _lib.stream_ptr()
-        prec = {"f32": 0, "f16x3": 1}[self.precision]
+        prec = self._prec()
         pre, styles = _prepared if _prepared is not None else self.prepare(ws, dev)
-        if prec == 1 and not _folded:
-            bx, self._depth_in = bound_of(x, self._meter, layers=2)
+        if prec >= 1 and not _folded:
+            # f16mx wants the conv1 operand within one layer of a measurement: only a measured / known input bound will do
+            bx, self._depth_in = bound_of(x, self._meter, layers=2 if prec == 1 else MAX_DEPTH + 1)
             chain_fold([self.chain_op(-1)], N, [bx])
         need = int(lib.r3d_sr_block_workspace_bytes(N, Cin, Cout, Hin, Win))
         work = self._buf("_workspace", need, dev)
@@ -314,7 +321,7 @@ class SynthesisBlock(nn.Module):
                 x_out._r3d_fmt = out_fmt
             if out_fmt == "split":
                 x_out._r3d_for = _next
-            elif prec == 1:
+            elif prec >= 1:
                 _tag(x_out, self.bound_out(N), self._depth_in + 2)
         return x_out, img_out
 
@@ -645,6 +652,7 @@ class SuperresolutionHybrid8XDC(nn.Module):
         self.block1.return_x = False           # forward() only returns rgb (:359)
         self._meter = _BoundMeter()
         self._ws3 = None                       # (ws, version, ws[:, -1:].repeat(1, 3, 1)): a clip renders every frame with one ws
+        self._mx_slot = None                   # f16mx: max|block0 output| measured in its conv1 epilogue
 
     def _ws_last3(self, ws):
         c = self._ws3
@@ -668,16 +676,24 @@ class SuperresolutionHybrid8XDC(nn.Module):
         b1.precision = b0.precision
         prep0 = b0.prepare(ws3, x.device, ws_key=ws)
         prep1 = b1.prepare(ws3, x.device, ws_key=ws)
-        if b0.precision == "f16x3":
+        mx = b0.precision == "f16mx"
+        x_absmax = None
+        if b0.precision in ("f16x3", "f16mx"):
             # one fold launch for both blocks; block0's conv1 epilogue then emits its output already multiplied by block1.conv0's
             # folded styles and split into fp16 hi/lo planes, so block1 stages its input with plain copies
             x = _keep_tags(x)
-            bx, dx = bound_of(x, self._meter, layers=4)
+            bx, dx = bound_of(x, self._meter, layers=4 if not mx else MAX_DEPTH + 1)
             b0._depth_in, b1._depth_in = dx, dx + 2
-            chain_fold([b0.chain_op(-1), b1.chain_op(0)], x.shape[0], [bx])
+            if mx:      # block1's conv1 operand must sit within one layer of a measurement: block0 measures max|x0| in its epilogue
+                if self._mx_slot is None or self._mx_slot.shape[0] != x.shape[0] or self._mx_slot.device != x.device:
+                    self._mx_slot = torch.zeros(x.shape[0], device=x.device, dtype=torch.float32)
+                x_absmax = self._mx_slot
+            chain_fold([b0.chain_op(-1), b1.chain_op(0)], x.shape[0], [bx], zero=[x_absmax] if mx else ())
             b0.out_format, nxt = "split", b1
         else:
             b0.out_format, nxt = "cb8", None
-        x, rgb = b0(x, rgb, ws3, _prepared=prep0, _next=nxt, _folded=True, **block_kwargs)
+        x, rgb = b0(x, rgb, ws3, _prepared=prep0, _next=nxt, _folded=True, _x_absmax=x_absmax, **block_kwargs)
+        if mx:
+            chain_fold([b1.chain_op(-1, tail=True)], x.shape[0], [x_absmax])
         x, rgb = b1(x, rgb, ws3, _prepared=prep1, _folded=True, _u8_out=_u8_out, _need_img=_need_img, **block_kwargs)
         return rgb

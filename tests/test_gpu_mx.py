@@ -1,0 +1,110 @@
+"""GPU parity (`-m gpu`) of the opt-in R3D_SR_F16MX precision: f16x3 with the correction products of each block's 3x3 conv on the
+block-scaled fp8 MFMA.  Own tolerance tier: the correction is accurate to fp8 rounding (~2^-16 of each product), so
+
+    SR outputs   <= 5e-5 * max(1, max|ref|)        (f16x3 / f32 tier: 2e-4 with ~4e-6 measured; TF32 would be ~2e-4 measured)
+    final image  <= 1e-3 abs after the clamp       (unchanged)
+
+against the same reference goldens, plus the dynamic-range sweep (inputs / weights / styles / biases scaled by 2^k, k in [-20, 14])
+at <= 1e-4 * max|ref| vs torch fp64."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from test_gpu_parity import RGB_TOL, DEPTH_TOL, T, load_block
+from test_gpu_range_and_sizes import SWEEP, _block_fp64, _generator
+
+pytestmark = pytest.mark.gpu
+MX_TOL = 5e-5
+
+
+def test_sr_full_golden_f16mx():
+    import torch
+    from real3dportrait_amd import SuperresolutionHybrid8XDC, synth
+    g = load_golden("sr_full_a")
+    seed = int(g["seed"])
+    params = synth.synth_sr_params(seed)
+    sr = SuperresolutionHybrid8XDC(channels=32, img_resolution=512, sr_num_fp16_res=0, sr_antialias=True).cuda()
+    load_block(torch, sr.block0, params[0]); load_block(torch, sr.block1, params[1])
+    x = T(torch, synth.hash_unitvar(seed, (1, 32, 128, 128), stream=1))
+    ws = torch.ones(1, 14, 512, device="cuda")
+    outs = {}
+    for prec in ("f16x3", "f16mx"):
+        sr.block0.precision = sr.block1.precision = prec
+        outs[prec] = sr(x[:, :3].contiguous(), x, ws, noise_mode="none").cpu().numpy()
+    out = outs["f16mx"]
+    scale = max(1.0, np.abs(g["strided"]).max())
+    errs = [np.abs(out[:, :, ::4, ::4] - g["strided"]).max(), np.abs(out[:, :, :96, :96] - g["corner"]).max(),
+            np.abs(out[:, :, -64:, -64:] - g["tail"]).max()]
+    print("sr_full f16mx max err %.3e (tier %.1e x %.2f); f16x3 %.3e; f16mx vs f16x3 %.3e" %
+          (max(errs), MX_TOL, scale, np.abs(outs["f16x3"][:, :, ::4, ::4] - g["strided"]).max(), np.abs(out - outs["f16x3"]).max()))
+    assert max(errs) <= MX_TOL * scale
+    assert not np.array_equal(out, outs["f16x3"])                     # the fp8 path really ran
+    assert abs(float(np.abs(out).mean()) - float(g["absmean"])) <= 1e-4
+
+
+def test_sr_blocks_golden_f16mx():
+    """Two chained blocks with per-layer styles (non-trivial ws) vs the reference's SynthesisBlocks (tests/golden/sr_small_a.npz)."""
+    import torch
+    from real3dportrait_amd import SynthesisBlock, synth
+    g = load_golden("sr_small_a")
+    params = synth.synth_sr_params(int(g["seed"]))
+    b0 = SynthesisBlock(32, 256, w_dim=512, resolution=32, img_channels=3, is_last=False, conv_clamp=None).cuda()
+    b1 = SynthesisBlock(256, 128, w_dim=512, resolution=64, img_channels=3, is_last=True, conv_clamp=None).cuda()
+    load_block(torch, b0, params[0]); load_block(torch, b1, params[1])
+    b0.precision = b1.precision = "f16mx"
+    ws = T(torch, g["ws"])
+    x0, r0 = b0(T(torch, g["x"]), T(torch, g["rgb"]), ws, noise_mode="none")
+    x1, r1 = b1(x0, r0, ws, noise_mode="none")
+    for got, ref in ((x0[:, ::4], g["x0"]), (r0, g["rgb0"]), (x1[:, ::8], g["x1"]), (r1, g["rgb1"])):
+        assert np.abs(got.cpu().numpy() - ref).max() <= MX_TOL * max(1.0, np.abs(ref).max())
+
+
+def test_synthesis_golden_f16mx():
+    """TriPlaneGenerator.synthesis (R=128, 48+48, SR -> 512^2) with the SR in f16mx against the reference's output."""
+    import torch
+    from real3dportrait_amd import synth
+    g = load_golden("synthesis_ref_a")
+    seed, R, Nc, Nf = int(g["seed"]), int(g["R"]), int(g["Nc"]), int(g["Nf"])
+    G = _generator(torch, seed)
+    G.superresolution.block0.precision = G.superresolution.block1.precision = "f16mx"
+    G.renderer.noise_override = (T(torch, synth.synth_noise(seed, (1, R * R, Nc, 1), stream=7)),
+                                 T(torch, synth.synth_noise(seed, (R * R, Nf), stream=8)))
+    out = G.synthesis(torch.ones(1, 14, 512, device="cuda"), T(torch, g["cam"]), use_cached_backbone=True, noise_mode="none")
+    img = out["image"].cpu().numpy()
+    assert np.abs(out["image_raw"].cpu().numpy() - g["image_raw"]).max() <= RGB_TOL
+    assert np.abs(img[:, :, ::4, ::4] - g["image_strided"]).max() <= 1e-3
+    assert np.abs(img[:, :, :96, :96] - g["image_corner"]).max() <= 1e-3
+
+
+@pytest.mark.parametrize("what", ["input", "weights", "styles", "bias"])
+@pytest.mark.parametrize("k", SWEEP)
+def test_sr_block_range_sweep_f16mx(what, k):
+    import torch
+    from real3dportrait_amd import synth
+    from real3dportrait_amd.superresolution import SynthesisBlock
+    N, Cin, Cout, H, W = 2, 32, 128, 18, 14
+    sc = np.float32(2.0 ** k)
+    p = {kk: tuple(np.array(a) for a in v) for kk, v in synth.synth_sr_block(71, Cin, Cout, 512, 700).items()}
+    if what == "weights":
+        for layer in ("conv0", "conv1"):
+            p[layer] = (p[layer][0] * sc,) + p[layer][1:]
+    elif what == "styles":
+        for layer in ("conv0", "conv1", "torgb"):
+            w_, b_, aw, ab = p[layer]
+            p[layer] = (w_, b_, aw * sc, ab * sc)
+    elif what == "bias":
+        for layer in ("conv0", "conv1"):
+            w_, b_, aw, ab = p[layer]
+            p[layer] = (w_, b_ * sc, aw, ab)
+    blk = SynthesisBlock(Cin, Cout, w_dim=512, resolution=2 * H, img_channels=3, is_last=False, conv_clamp=None).cuda()
+    load_block(torch, blk, p)
+    blk.precision = "f16mx"
+    x = synth.hash_unitvar(72, (N, Cin, H, W), stream=1) * (sc if what == "input" else np.float32(1.0))
+    img = synth.hash_unitvar(72, (N, 3, H, W), stream=2) * np.float32(0.5)
+    ws = np.ones((N, 3, 512), np.float32) + synth.hash_unitvar(72, (N, 3, 512), stream=3) * np.float32(0.2)
+    xo, io = blk(T(torch, x), T(torch, img), T(torch, ws), noise_mode="none")
+    rx, ri = _block_fp64(torch, p, torch.from_numpy(x), torch.from_numpy(img), torch.from_numpy(ws), True, None)
+    ex = (xo.cpu().double() - rx).abs().max().item() / max(rx.abs().max().item(), 1e-300)
+    ei = (io.cpu().double() - ri).abs().max().item() / max(ri.abs().max().item(), 1e-300)
+    assert torch.isfinite(xo).all() and torch.isfinite(io).all()
+    assert ex <= 1e-4 and ei <= 1e-4, (what, k, ex, ei)
