@@ -46,8 +46,9 @@ for k in sorted(cn):
         lines.append("    -> wave-parked (SQ_WAIT_ANY / SQ_WAVE_CYCLES)        %.3f" % (v.get("SQ_WAIT_ANY", 0) / wc))
         lines.append("    -> issue-stalled (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES) %.3f" % (v.get("SQ_WAIT_INST_ANY", 0) / wc))
         lines.append("    -> VALU active (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES) %.3f" % (v.get("SQ_ACTIVE_INST_VALU", 0) / wc))
-    if v.get("SQ_BUSY_CYCLES"):
-        lines.append("    -> MFMA busy (SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES x 4 SIMD-cycles per quad... raw ratio)) %.3f" % (v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / v["SQ_BUSY_CYCLES"]))
+    if v.get("GRBM_GUI_ACTIVE") and v.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+        # SQ_VALU_MFMA_BUSY_CYCLES sums cycles over the 1024 SIMDs (= 32 x the 32x32x16 MFMA count); GRBM_GUI_ACTIVE sums over the 8 XCDs
+        lines.append("    -> MFMA busy per SIMD / kernel cycles = (MFMA_BUSY / 1024) / (GUI_ACTIVE / 8)   %.3f" % ((v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (v["GRBM_GUI_ACTIVE"] / 8.0)))
     if v.get("TCC_HIT_sum", 0) + v.get("TCC_MISS_sum", 0):
         lines.append("    -> L2 hit rate TCC_HIT / (HIT + MISS)                 %.4f" % (v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])))
 open(O + "/pmc_summary.txt", "w").write("\n".join(lines) + "\n")
