@@ -349,7 +349,10 @@ def main():
                                       "planes cano+residual [1,3,32,256,256] -> 128^2 rays x (48 coarse + 48 importance) "
                                       "-> SuperresolutionHybrid8XDC -> 512^2 uint8; clip gathered to rank 0",
                           "neural_rendering_resolution": 128, "depth_samples": "48+48", "final_resolution": 512,
-                          "frames_total": total_frames, "streams_per_gpu": args.streams, "parallelism": "frame-sharded dp%d + gather" % world},
+                          "frames_total": total_frames, "streams_per_gpu": args.streams, "parallelism": "frame-sharded dp%d + gather" % world,
+                          "clip_constants": "weight prepack and the SR style / demodulation vectors (functions of ws = ones and the parameters only, "
+                                            "triplane.py:131-132) are computed once per clip; every per-frame input (planes = cano + residual_t, camera, "
+                                            "sampling noise) is processed inside the timed region"},
                "roofline": roofline}
         if single_stream_fps is not None:
             out["value_single_stream"] = round(single_stream_fps, 2)

@@ -2,6 +2,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -30,23 +31,26 @@ int check_launch(const char* what)
 }
 
 // ---- event-pair profiling of launch sites -------------------------------------------------------------
+// Process-global by design (a bench tool), but safe to use from several host threads driving different streams: the state is guarded by
+// a mutex and the events are created in r3d_profile_configure (a pool per family), not inside a timed region; a launch site that finds the
+// pool exhausted is simply not bracketed.
+static std::mutex g_prof_mu;
 static uint32_t g_prof_mask = 0;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev[R3D_PROF_COUNT];
 static size_t g_prof_used[R3D_PROF_COUNT] = {0};
+static constexpr size_t kProfPool = 1024;       // event pairs pre-created per enabled family
 
 void prof_begin(int id, hipStream_t st)
 {
     if (!(g_prof_mask & (1u << id))) return;
-    if (g_prof_used[id] == g_prof_ev[id].size()) {
-        hipEvent_t a, b;
-        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
-        g_prof_ev[id].push_back(std::make_pair(a, b));
-    }
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof_used[id] >= g_prof_ev[id].size()) return;
     (void)hipEventRecord(g_prof_ev[id][g_prof_used[id]].first, st);
 }
 void prof_end(int id, hipStream_t st)
 {
     if (!(g_prof_mask & (1u << id))) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     if (g_prof_used[id] >= g_prof_ev[id].size()) return;
     (void)hipEventRecord(g_prof_ev[id][g_prof_used[id]].second, st);
     ++g_prof_used[id];
@@ -171,15 +175,29 @@ extern "C" int r3d_frames_to_u8(const float* img, int N, int H, int W, uint8_t* 
     return check_launch("frames_to_u8");
 }
 
-extern "C" int r3d_profile_configure(uint32_t mask) { g_prof_mask = mask; return R3D_OK; }
+extern "C" int r3d_profile_configure(uint32_t mask)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (int i = 0; i < R3D_PROF_COUNT; ++i)
+        if (mask & (1u << i))
+            while (g_prof_ev[i].size() < kProfPool) {
+                hipEvent_t a, b;
+                if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { set_error("profile_configure: hipEventCreate failed"); return R3D_ERR_LAUNCH; }
+                g_prof_ev[i].push_back(std::make_pair(a, b));
+            }
+    g_prof_mask = mask;
+    return R3D_OK;
+}
 extern "C" int r3d_profile_reset(void)
 {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     for (int i = 0; i < R3D_PROF_COUNT; ++i) g_prof_used[i] = 0;
     return R3D_OK;
 }
 extern "C" int r3d_profile_read(int id, double* total_ms, int* launches)
 {
     if (id < 0 || id >= R3D_PROF_COUNT || !total_ms || !launches) { set_error("profile_read: bad argument"); return R3D_ERR_INVALID_ARG; }
+    std::lock_guard<std::mutex> lk(g_prof_mu);
     double tot = 0.0;
     for (size_t i = 0; i < g_prof_used[id]; ++i) {
         float ms = 0.f;
