@@ -921,22 +921,28 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
                     const h8 ah = *reinterpret_cast<h8*>(&q0), al = *reinterpret_cast<h8*>(&q1);
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 32)             // experiment build: operands read, no MFMAs
+                        asm volatile("" :: "v"(al), "v"(ah), "v"(bh[nt]), "v"(bl[nt]));
+#else
                         acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[nt], acc[p][nt], 0, 0, 0);
                         acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[nt], acc[p][nt], 0, 0, 0);
                         acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[nt], acc[p][nt], 0, 0, 0);
+#endif
                     }
                 }
         }
     }
 
-    // ---- epilogue: 4 slices of 8 couts through LDS.  T (demodulated, fp32) [pa][pb][cout half][16x16] float4 -> horizontal
-    // 4-tap pass -> H [pa][half][16 rows][28 cols] -> vertical 4-tap pass + bias + lrelu*sqrt2 (+clamp) -> * next styles ->
-    // fp16 hi/lo -> y.  Separable (8 instead of 16 FMAs per output), every pass conflict-free in LDS, arithmetic on float
-    // pairs (v_pk_fma_f32 / v_cvt_pk_f16_f32).
+    // ---- epilogue.  T (demodulated, fp32, in the accumulators) -> horizontal 4-tap pass IN REGISTERS -> H through LDS in 4 slices of
+    // 8 couts ([pa][half][16 rows][28 cols], double-buffered: one barrier per slice) -> vertical 4-tap pass + bias + lrelu*sqrt2
+    // (+clamp) -> * next styles -> fp16 hi/lo -> y.  Separable (8 instead of 16 FMAs per output), arithmetic on float pairs.
+    // The horizontal pass needs T at grid columns X, X+1, X+2 of the SAME grid row, and a grid row is one 16-lane DPP row of the
+    // accumulator layout (lane = pixel), so the neighbours arrive by row rotations (v_mov_dpp row_ror:15 / :14; the rotation also covers
+    // the odd rows, whose columns are stored rotated by one lane).  Round 1 wrote T to LDS and ran the pass LDS -> LDS: 56 b128 LDS
+    // operations per thread and slice, now 28 -- the ablations of round 2 had the epilogue at 56 % of this kernel.
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
-    float4* tls = reinterpret_cast<float4*>(lds);                   // T: 2048 float4
-    float4* hls = tls + 2048;                                       // H: [pa][half][gy][32] (28 used), column swizzled by 8*half
+    float4* hls0 = reinterpret_cast<float4*>(lds);                  // H: 2 x [pa][half][gy][32] (28 used), column swizzled by 8*half
     const int co0 = cg * 32;
     const float* D = a.out_scale + (size_t)n * a.vec_stride_n + co0;
     const float* Bv = a.bias + (size_t)n * a.vec_stride_n + co0;
@@ -957,41 +963,39 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
 #pragma unroll
     for (int g = 0; g < 4; ++g)
         asm volatile("" :: "v"(dv4[g].x), "v"(dv4[g].w), "v"(bv4[g].x), "v"(bv4[g].w), "v"(nv4[g].x), "v"(nv4[g].w));
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 8)              // experiment build: no epilogue
+    if (acc[0][0][0] == 123.456f) a.y[0] = make_uint4(__float_as_uint(acc[1][1][3] + acc[2][0][5] + acc[3][1][9]), 0, 0, 0);
+    return;
+#endif
+    __syncthreads();                                                // the main loop's LDS reads are done
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        if (g == 0) __syncthreads();                                // the main loop's LDS reads are done
-        const float4 d4 = dv4[g];
+        float4* hls = hls0 + (g & 1) * 2048;
+        const float dv[4] = {dv4[g].x, dv4[g].y, dv4[g].z, dv4[g].w};
+        // horizontal pass of this slice: (T[pa][pb=0], T[pa][pb=1]) at this lane's grid point -> (H column 2X, H column 2X+1)
+        //   T column 2X+1+cc = phase (cc+1)&1 at grid column X + (cc+1)/2;  H(dx) = (T[dx] + T[dx+3]) c0 + (T[dx+1] + T[dx+2]) c1
 #pragma unroll
-        for (int p = 0; p < 4; ++p)
+        for (int pa = 0; pa < 2; ++pa)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
-                const int px = (row0 + nt * 2 + prow) * 16 + pcol;
-                tls[(p * 2 + h) * 256 + px] = make_float4(acc[p][nt][4 * g + 0] * d4.x, acc[p][nt][4 * g + 1] * d4.y,
-                                                          acc[p][nt][4 * g + 2] * d4.z, acc[p][nt][4 * g + 3] * d4.w);
-            }
-        __syncthreads();
-        {   // horizontal: thread (X = tid & 15, gy = tid >> 4) x (pa, half): T columns 2X+1 .. 2X+5 -> H columns 2X, 2X+1
-            const int X = tid & 15, gy = tid >> 4;
-            if (X < U_TILE) {
+                float hx[2][4];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int half = k & 1, pa = k >> 1;
-                    f2 ta[5], tb[5];
-#pragma unroll
-                    for (int cc = 0; cc < 5; ++cc) {                // T column 2X+1+cc = phase (cc+1)&1 at grid column X + (cc+1)/2
-                        const float4 t4 = tls[(((pa * 2 + ((cc + 1) & 1)) * 2 + half) * 16 + gy) * 16 + X + ((cc + 1) >> 1)];
-                        ta[cc] = f2{t4.x, t4.y}; tb[cc] = f2{t4.z, t4.w};
-                    }
-#pragma unroll
-                    for (int dx = 0; dx < 2; ++dx) {
-                        const f2 ha = (ta[dx] + ta[dx + 3]) * c0 + (ta[dx + 1] + ta[dx + 2]) * c1;
-                        const f2 hb = (tb[dx] + tb[dx + 3]) * c0 + (tb[dx + 1] + tb[dx + 2]) * c1;
-                        hls[((pa * 2 + half) * 16 + gy) * 32 + ((2 * X + dx + 8 * half) & 31)] = make_float4(ha.x, ha.y, hb.x, hb.y);
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    const float t0 = acc[2 * pa][nt][4 * g + r] * dv[r], t1 = acc[2 * pa + 1][nt][4 * g + r] * dv[r];
+                    // lane i <- lane (i + 1) % 16 / (i + 2) % 16 of its 16-lane row: row_ror:15 = 0x12F, row_ror:14 = 0x12E
+                    const float t0p1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t0), 0x12F, 0xF, 0xF, false));
+                    const float t1p1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t1), 0x12F, 0xF, 0xF, false));
+                    const float t0p2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t0), 0x12E, 0xF, 0xF, false));
+                    const float t1p2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t1), 0x12E, 0xF, 0xF, false));
+                    hx[0][r] = (t1 + t0p2) * c0 + (t0p1 + t1p1) * c1;
+                    hx[1][r] = (t0p1 + t1p2) * c0 + (t1p1 + t0p2) * c1;
                 }
+                const int gy = row0 + nt * 2 + prow;
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx)
+                    hls[((pa * 2 + h) * 16 + gy) * 32 + ((2 * pcol + dx + 8 * h) & 31)] = make_float4(hx[dx][0], hx[dx][1], hx[dx][2], hx[dx][3]);
             }
-        }
-        __syncthreads();
+        __syncthreads();                                            // (buffer g & 1 was last read by slice g - 2's vertical pass: done before barrier g - 1)
         {   // vertical: item (row pair rp, column oc, half): H rows 2rp+1 .. 2rp+5 -> y rows 2rp, 2rp+1 (4 couts each)
             const float4 b4 = bv4[g], n4 = nv4[g];
             const f2 ba = f2{b4.x, b4.y}, bb = f2{b4.z, b4.w};
@@ -1031,6 +1035,10 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
                     // hi word and of the lo word (a wave store covers 32 pixels x 16 contiguous bytes per plane)
                     const uint2 hw = make_uint2(*reinterpret_cast<const unsigned*>(&hia), *reinterpret_cast<const unsigned*>(&hib));
                     const int oy = 2 * (i0 + rp) + dy, ox = 2 * j0 + oc;
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 16)             // experiment build: the epilogue computes everything but stores nothing
+                    if (hw.x == 0x12345678u && oy >= 0) a.y[0] = make_uint4(hw.x, hw.y, 0, 0);
+                    continue;
+#endif
                     if constexpr (MX) {
                         const f2 fha = __builtin_convertvector(hia, f2), fhb = __builtin_convertvector(hib, f2);
                         const f2 fla = va - fha, flb = vb - fhb;

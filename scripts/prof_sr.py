@@ -18,7 +18,8 @@ for _ in range(reps): sr(rgb, x, ws, noise_mode="none")
 torch.cuda.synchronize(); total = (time.perf_counter() - t) / reps * 1e3
 import ctypes
 from real3dportrait_amd import _lib
-lib = _lib.load(); lib.r3d_profile_configure(2); lib.r3d_profile_reset()
+lib = _lib.load(); lib.r3d_profile_configure(2 | 4); lib.r3d_profile_reset()
 for _ in range(reps): sr(rgb, x, ws, noise_mode="none")
 torch.cuda.synchronize(); ms, cnt = ctypes.c_double(0), ctypes.c_int(0); lib.r3d_profile_read(1, ctypes.byref(ms), ctypes.byref(cnt))
-print("SR 128->512: %.3f ms   conv kernels: %.3f ms/frame (%d launches)  dbg=%s" % (total, ms.value / reps, cnt.value, os.environ.get("R3D_DBG", "0")))
+ums, ucnt = ctypes.c_double(0), ctypes.c_int(0); lib.r3d_profile_read(2, ctypes.byref(ums), ctypes.byref(ucnt))
+print("SR 128->512: %.3f ms   conv kernels: %.3f ms/frame (%d launches)  upconv kernels: %.3f ms/frame  dbg=%s" % (total, ms.value / reps, cnt.value, ums.value / reps, os.environ.get("R3D_DBG", "0")))
