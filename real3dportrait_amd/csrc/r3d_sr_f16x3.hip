@@ -40,6 +40,13 @@ __device__ __forceinline__ void split1(float v, _Float16& hi, _Float16& lo)
     lo = (_Float16)(v - (float)hi);
 }
 
+// hot epilogues: the range fold (r3d_chain_fold) guarantees |v| < 2^15, so the saturation of split1 is dead weight there
+__device__ __forceinline__ void split1_folded(float v, _Float16& hi, _Float16& lo)
+{
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+
 // ---- "f16mx": the two 2^-11-sized correction products on the block-scaled fp8 MFMA (R3D_SR_F16MX) -------------------------------------
 // A product is x*w = xh*wh + (xh*wl + xl*wh) (+ xl*wl ~ 2^-22, dropped as in f16x3).  f16x3 spends two f16 MFMAs per K = 16 on the bracket;
 // here the bracket of TWO taps x 16 channels is ONE v_mfma_scale_f32_32x32x64_f8f6f4 (OCP e4m3, 2x the f16 rate):
@@ -309,7 +316,7 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
                 if (Ys) {
                     h4 hi, lo;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { _Float16 x0, x1; split1(v[r] * sv[r], x0, x1); hi[r] = x0; lo[r] = x1; }
+                    for (int r = 0; r < 4; ++r) { _Float16 x0, x1; split1_folded(v[r] * sv[r], x0, x1); hi[r] = x0; lo[r] = x1; }
                     uint2* dst = reinterpret_cast<uint2*>(Ys + pix) + ((co & 7) >> 2);
                     dst[0] = *reinterpret_cast<uint2*>(&hi);
                     dst[2 * oplane] = *reinterpret_cast<uint2*>(&lo);
