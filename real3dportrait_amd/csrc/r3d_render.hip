@@ -8,9 +8,9 @@
 // omega_i = (w_{r(i)-1}+w_{r(i)})/2 (r = rank of sample i in depth order), so colours are never sorted
 // or moved -- only the 96 (depth, density) scalars are.
 //
-// Lane mapping (wave64): lane = (q = lane>>4, s = lane&15).  A "tile" is 16 samples; lane (q,s) owns
-// channels 8q..8q+7 of sample s of each tile, so the four lanes of a sample read one 128-byte
-// channel-last tap as 4 x 32 B and the gathered features ARE the B operand of
+// Lane mapping (wave64): a "tile" is 16 samples.  The gather runs with lane = 4*sample + q (lane owns channels 8q..8q+7 of
+// its sample, the four lanes of a sample are adjacent and read one 128-byte channel-last tap as 4 x 32 B); the split
+// features cross once through LDS (gather_to_mfma) to lane = (q = lane>>4, s = lane&15), the B operand of
 // v_mfma_f32_16x16x32_f16 (fp16 hi/lo split, 3-term products; k-slot q <-> channels 8q..8q+7).  The MLP is evaluated transposed
 // (H^T = W1 X^T, Y^T = W2 H^T) so layer-1 accumulators feed layer 2 as B operands directly
 // (k-slot q <-> hidden unit 16mt+4q+reg): no LDS round trip between gather, layer 1, softplus, layer 2.
@@ -315,7 +315,13 @@ __device__ __forceinline__ void gather_sample(const float4* __restrict__ planes4
         for (int p = 0; p < 3; ++p) plane_taps(us[p], vs[p], H, W, p * HW8 + 2 * q, t + 4 * p);
         float4 lo[12], hi[12];
 #pragma unroll
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 64)      // experiment build: half the load instructions (wrong results): is the kernel bound by the L1 / TA request rate?
+        for (int i = 0; i < 12; ++i) { lo[i] = planes4[t[i].idx]; hi[i] = lo[i]; }
+#elif defined(R3D_ABLATE) && (R3D_ABLATE & 128)   // experiment build: same number of load instructions, the second one re-reads the first one's 16 bytes
+        for (int i = 0; i < 12; ++i) { lo[i] = planes4[t[i].idx]; int j = t[i].idx; asm volatile("" : "+v"(j)); hi[i] = planes4[j]; }
+#else
         for (int i = 0; i < 12; ++i) { lo[i] = planes4[t[i].idx]; hi[i] = planes4[t[i].idx + 1]; }
+#endif
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
 #pragma unroll
@@ -359,11 +365,9 @@ __device__ __forceinline__ void gather_sample(const float4* __restrict__ planes4
 // of layer 1.  Out: col[ot] (4 regs) = colour channel 16ot+4q+reg of sample s (after the sigmoid clamp of
 // triplane.py:187); sig = density of sample s (replicated over q).
 // -------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void decode_tile(const DecoderLds& L, int lane, const float (&X)[8], f32x4 (&col)[2], float& sig)
+__device__ __forceinline__ void decode_tile(const DecoderLds& L, int lane, const h8 xh, const h8 xl, f32x4 (&col)[2], float& sig)
 {
     const int q = lane >> 4;
-    h8 xh, xl;
-    split8(X, xh, xl);
     // layer 1: H^T[16mt.., samples] = W1'[16mt.., ch] X^T   (k-slot q <-> channels 8q..8q+7)
     f32x4 h[4];
 #pragma unroll
@@ -444,6 +448,29 @@ __device__ __forceinline__ void wave_lds_sync() {
     // LDS traffic of one wave is in order; this only stops the compiler from reordering around it
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+}
+
+// Gather mapping -> MFMA mapping.  The gather runs with the 4 lanes of a sample ADJACENT (lane = 4*sample + q), so a lane
+// quad reads 64 contiguous bytes of one 128-byte tap: the texture-address unit works through a wave's load one quad at a
+// time, and with lane = 16*q + sample every quad touched 4 different lines (measured: 0.30 -> 0.23 ms for the ray kernel
+// with nothing else changed).  The split features then cross to the B-operand mapping (lane = 16*q + sample) through a
+// 2 KB per-wave LDS tile; the 16-byte slot of (sample, q) is XOR-swizzled so that both the write (16 consecutive lanes
+// = 4 samples x 4 q) and the read (16 samples of one q) cover 256 contiguous-modulo-bank bytes: no bank conflicts.
+struct XchLds { uint4 v[2][64]; };
+__device__ __forceinline__ int gather_q(int lane) { return lane & 3; }
+__device__ __forceinline__ int gather_s(int lane) { return lane >> 2; }
+__device__ __forceinline__ void gather_to_mfma(XchLds& E, int lane, const float (&X)[8], h8& xh, h8& xl)
+{
+    split8(X, xh, xl);
+    const int gs = lane >> 2, gq = lane & 3, q = lane >> 4, s = lane & 15;
+    const int wi = gs * 4 + (gq ^ (gs >> 2)), ri = s * 4 + (q ^ (s >> 2));
+    E.v[0][wi] = *reinterpret_cast<uint4*>(&xh);
+    E.v[1][wi] = *reinterpret_cast<uint4*>(&xl);
+    wave_lds_sync();
+    uint4 rh = E.v[0][ri], rl = E.v[1][ri];
+    wave_lds_sync();
+    xh = *reinterpret_cast<h8*>(&rh);
+    xl = *reinterpret_cast<h8*>(&rl);
 }
 
 // per-wave scratch
@@ -533,13 +560,16 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
     constexpr int FSLOTS = NTF > 0 ? (16 * NTF + 63) / 64 : 1;
     __shared__ __attribute__((aligned(16))) DecoderLds dec;
     __shared__ __attribute__((aligned(16))) RayLds rl[kWavesPerBlock];
+    __shared__ __attribute__((aligned(16))) XchLds xch[kWavesPerBlock];
 
     stage_decoder(dec, a.w1, a.b1, a.w2, a.b2);
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int q = lane >> 4, s = lane & 15;
+    const int q = lane >> 4, s = lane & 15;          // MFMA / per-sample mapping
+    const int gq = gather_q(lane), gs = gather_s(lane);   // gather mapping
     RayLds& L = rl[wave];
+    XchLds& E = xch[wave];
     const int Nc = a.Nc, Nf = a.Nf, S = Nc + Nf;
     // min / max of the valid rays' starts (renderer.py:123-126): reduce the per-block partials of ray_limits_kernel
     int pmin = 0x7fffffff, pmax = (int)0x80000000, pany = 0;
@@ -583,8 +613,11 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
         for (int nt = 0; nt < NTC; ++nt) {            // per-tile pipeline: gather (24 loads in flight) -> decode
             float X[8];
             f32x4 c2[2];
-            gather_sample<GPF, TRI>(P, a.H, a.W, q, ox + tc[nt] * dx, oy + tc[nt] * dy, oz + tc[nt] * dz, a.scale, X, a.D);
-            decode_tile(dec, lane, X, c2, sigc[nt]);
+            h8 xh, xl;
+            const float tg = __shfl(tc[nt], gs);       // depth of the sample this lane gathers for (lane gs: q = 0, s = gs)
+            gather_sample<GPF, TRI>(P, a.H, a.W, gq, ox + tg * dx, oy + tg * dy, oz + tg * dz, a.scale, X, a.D);
+            gather_to_mfma(E, lane, X, xh, xl);
+            decode_tile(dec, lane, xh, xl, c2, sigc[nt]);
             colc[0][nt] = c2[0]; colc[1][nt] = c2[1];
             __builtin_amdgcn_sched_barrier(0);         // one tile at a time (VGPR budget)
         }
@@ -650,12 +683,14 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
             float sigf[NTF > 0 ? NTF : 1];
 #pragma unroll
             for (int nt = 0; nt < NTF; ++nt) {
-                const int k = 16 * nt + s;
+                const int k = 16 * nt + gs;
                 const float tf = L.t[Nc + (k < Nf ? k : 0)];
                 float X[8];
                 f32x4 c2[2];
-                gather_sample<GPF, TRI>(P, a.H, a.W, q, ox + tf * dx, oy + tf * dy, oz + tf * dz, a.scale, X, a.D);
-                decode_tile(dec, lane, X, c2, sigf[nt]);
+                h8 xh, xl;
+                gather_sample<GPF, TRI>(P, a.H, a.W, gq, ox + tf * dx, oy + tf * dy, oz + tf * dz, a.scale, X, a.D);
+                gather_to_mfma(E, lane, X, xh, xl);
+                decode_tile(dec, lane, xh, xl, c2, sigf[nt]);
                 colf[0][nt] = c2[0]; colf[1][nt] = c2[1];
                 __builtin_amdgcn_sched_barrier(0);
             }
@@ -854,10 +889,13 @@ __global__ __launch_bounds__(256, 2) void run_model_kernel(const float4* __restr
                                                           float* __restrict__ rgb, float* __restrict__ sigma)
 {
     __shared__ __attribute__((aligned(16))) DecoderLds dec;
+    __shared__ __attribute__((aligned(16))) XchLds xch[kWavesPerBlock];
     stage_decoder(dec, w1, b1, w2, b2);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, s = lane & 15;
+    const int gq = gather_q(lane), gs = gather_s(lane);
+    XchLds& E = xch[wave];
     const long long total = (long long)N * npts;
     const long long chunks = (total + 63) / 64;
     for (long long ch = (long long)blockIdx.x * kWavesPerBlock + wave; ch < chunks; ch += (long long)gridDim.x * kWavesPerBlock) {
@@ -867,13 +905,16 @@ __global__ __launch_bounds__(256, 2) void run_model_kernel(const float4* __restr
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
             idx[nt] = ch * 64 + 16 * nt + s;
-            const long long ii = idx[nt] < total ? idx[nt] : total - 1;
+            const long long ig = ch * 64 + 16 * nt + gs;          // the point this lane gathers for
+            const long long ii = ig < total ? ig : total - 1;
             const int n = (int)(ii / npts);
             const float4* P = planes4 + (size_t)n * 3 * (TRI ? D : 1) * H * W * 8;
             float X[8];
             f32x4 c2[2];
-            gather_sample<3, TRI>(P, H, W, q, coords[3 * ii], coords[3 * ii + 1], coords[3 * ii + 2], scale, X, D);
-            decode_tile(dec, lane, X, c2, sig[nt]);
+            h8 xh, xl;
+            gather_sample<3, TRI>(P, H, W, gq, coords[3 * ii], coords[3 * ii + 1], coords[3 * ii + 2], scale, X, D);
+            gather_to_mfma(E, lane, X, xh, xl);
+            decode_tile(dec, lane, xh, xl, c2, sig[nt]);
             col[0][nt] = c2[0]; col[1][nt] = c2[1];
             __builtin_amdgcn_sched_barrier(0);
         }
