@@ -77,7 +77,10 @@ int r3d_raygen(const float* c2w, const float* intrinsics, int N, int R,
  *   u_f          [N*M,Nf] U[0,1) importance draws       (the reference's torch.rand,      renderer.py:281)
  *                either may be NULL: the kernel then draws from a counter-based hash of
  *                (seed, ray, sample), which makes a frame's noise independent of how frames are sharded
- *   rgb [N,M,32], depth [N,M], wsum [N,M], valid [N,M] (1 byte, is_ray_valid)
+ *   rgb [N,M,32] (rgb_channel_major = 0: what the reference's renderer returns) or [N,32,M] (rgb_channel_major = 1: the NCHW
+ *                feature image TriPlaneGenerator.synthesis builds from it with permute(0,2,1).reshape(N,32,R,R), triplane.py:121-122,
+ *                written directly so that no transposition pass runs per frame)
+ *   depth [N,M] or NULL (no depth image: the global-range clamp launch is skipped), wsum [N,M], valid [N,M] (1 byte, is_ray_valid)
  *   workspace    r3d_render_workspace_bytes() bytes of device scratch
  */
 size_t r3d_render_workspace_bytes(int N, int M, int Nc, int Nf);
@@ -86,7 +89,7 @@ int r3d_render_forward(const float* planes_nhwc, int N, int H, int W, int tripla
                        const float* origins, const float* dirs, int M,
                        int Nc, int Nf, float box_warp, int white_back,
                        const float* noise_c, const float* u_f, uint64_t seed,
-                       float* rgb, float* depth, float* wsum, uint8_t* valid,
+                       float* rgb, int rgb_channel_major, float* depth, float* wsum, uint8_t* valid,
                        void* workspace, size_t workspace_bytes, r3d_stream_t stream);
 
 /* Replaces ImportanceRenderer.run_model(planes, decoder, sample_coordinates, sample_directions, options)

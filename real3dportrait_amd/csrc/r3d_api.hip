@@ -137,7 +137,7 @@ __global__ void person_occlusion_kernel(const float* __restrict__ alpha, const f
 
 using namespace r3d;
 
-extern "C" int r3d_version(void) { return 20; }   // 0.2.0
+extern "C" int r3d_version(void) { return 21; }   // 0.2.1
 
 extern "C" int r3d_resize_bilinear(const float* x, int planes, int H, int W, float* y, int OH, int OW, int antialias, r3d_stream_t stream)
 {

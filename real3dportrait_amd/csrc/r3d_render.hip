@@ -71,6 +71,35 @@ __global__ void planes_to_nhwc_kernel(const float* __restrict__ src, const float
     }
 }
 
+// The per-frame case (C = 32, no depth, no flips, HW a multiple of 64): 32 channels x 64 pixels per block, 16-byte loads along the
+// pixels, 16-byte stores along the channels (8 lanes = one pixel's 128 bytes), one LDS transposition in between.  The general
+// kernel above moves 4 bytes per lane and instruction: 26 us per frame for 75 MB, this one is bound by the HBM traffic.
+__global__ __launch_bounds__(256) void planes_to_nhwc32_kernel(const float* __restrict__ src, const float* __restrict__ add,
+                                                              float* __restrict__ dst, int HW)
+{
+    __shared__ float tile[32][68];                  // row stride 68 floats: 16-byte aligned rows, column reads spread over the banks
+    const int p = blockIdx.y, hw0 = blockIdx.x * 64, tid = threadIdx.x;
+    const float* s = src + (size_t)p * 32 * HW + hw0;
+    const float* a = add ? add + (size_t)p * 32 * HW + hw0 : nullptr;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int c = (tid >> 4) + 16 * j, h4 = (tid & 15) * 4;
+        float4 v = *reinterpret_cast<const float4*>(s + (size_t)c * HW + h4);
+        if (a) {
+            const float4 w = *reinterpret_cast<const float4*>(a + (size_t)c * HW + h4);
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+        *reinterpret_cast<float4*>(&tile[c][h4]) = v;
+    }
+    __syncthreads();
+    float* d = dst + ((size_t)p * HW + hw0) * 32;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int hw = (tid >> 3) + 32 * j, c4 = (tid & 7) * 4;
+        *reinterpret_cast<float4*>(d + (size_t)hw * 32 + c4) = make_float4(tile[c4][hw], tile[c4 + 1][hw], tile[c4 + 2][hw], tile[c4 + 3][hw]);
+    }
+}
+
 // -------------------------------------------------------------------------------------------------
 // A1 ray generation (ray_sampler.py:24-63)
 // -------------------------------------------------------------------------------------------------
@@ -525,7 +554,7 @@ struct RenderArgs {
     int* gstate; int nlimit_blocks;
     int Nc, Nf; float scale; int white_back;
     const float* noise_c; const float* u_f; unsigned long long seed;
-    float* rgb; float* depth; float* wsum;
+    float* rgb; float* depth; float* wsum; int rgb_cm;      // rgb_cm: rgb is [N,32,M] (channel-major) instead of [N,M,32]; depth may be NULL
 };
 
 // Ray order: XCD x (= blockIdx % 8, the observed dispatch rule -- speed only) renders the column strip
@@ -850,9 +879,15 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
                 acc[ot][r] = v * 2.0f - 1.0f;            // ray_marcher.py:52-55
             }
         if (s == 0) {
-            float4* o4 = reinterpret_cast<float4*>(a.rgb + (size_t)ray * kC);
-            o4[q] = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
-            o4[4 + q] = make_float4(acc[1][0], acc[1][1], acc[1][2], acc[1][3]);
+            if (a.rgb_cm) {                                 // lane q holds channels 4q..4q+3 and 16+4q..16+4q+3 of the ray
+                float* o = a.rgb + ((size_t)n * kC + 4 * q) * a.M + (ray - n * a.M);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { o[(size_t)r * a.M] = acc[0][r]; o[(size_t)(16 + r) * a.M] = acc[1][r]; }
+            } else {
+                float4* o4 = reinterpret_cast<float4*>(a.rgb + (size_t)ray * kC);
+                o4[q] = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+                o4[4 + q] = make_float4(acc[1][0], acc[1][1], acc[1][2], acc[1][3]);
+            }
         }
         // depth range of the marched samples (global clamp, ray_marcher.py:50)
         float lmin = INFINITY, lmax = -INFINITY;
@@ -863,7 +898,7 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
         }
         run_min = fminf(run_min, lmin); run_max = fmaxf(run_max, lmax);
         if (lane == 0) {
-            a.depth[ray] = dsum / wsum;                  // NaN handled + clamped by depth_clamp_kernel
+            if (a.depth) a.depth[ray] = dsum / wsum;     // NaN handled + clamped by depth_clamp_kernel
             a.wsum[ray] = wsum;
         }
         wave_lds_sync();
@@ -939,9 +974,14 @@ static inline size_t render_state_bytes(size_t nrays) { return ((kStateHeader + 
 template <int NTC, int NTF>
 static void launch_render(const RenderArgs& a, int R, int grid, hipStream_t st)
 {
-    // <OCC = 2 waves/SIMD, 3 planes (24 loads) in flight>.  Measured alternative <3, 1> (168-VGPR cap, one plane in flight):
-    // 73 spilled registers, 0.371 vs 0.335 ms at REF.
-    hipLaunchKernelGGL((render_kernel<NTC, NTF, 2, 3>), dim3(grid), dim3(256), 0, st, a, R);
+    // <OCC = 2 waves/SIMD, one plane (8 loads) in flight>: no scratch for every shape up to 64+64 samples (232 VGPRs at REF).
+    // Measured at REF with the quad-coalesced gather: <2,1> 0.229 ms, <2,3> (24 loads in flight, 8 spilled registers) 0.232,
+    // <3,1> (168-VGPR cap, 64 spilled) 0.353, <3,3> 0.423.  (Before the gather change <2,3> led <2,1> by 5 %: the loads were the limiter.)
+#if defined(R3D_RENDER_OCC) && defined(R3D_RENDER_GPF)          // experiment builds
+    hipLaunchKernelGGL((render_kernel<NTC, NTF, R3D_RENDER_OCC, R3D_RENDER_GPF>), dim3(grid), dim3(256), 0, st, a, R);
+#else
+    hipLaunchKernelGGL((render_kernel<NTC, NTF, 2, 1>), dim3(grid), dim3(256), 0, st, a, R);
+#endif
 }
 
 // tri-grid variants: only the three covering shapes are instantiated (a secondary configuration)
@@ -964,6 +1004,11 @@ extern "C" int r3d_planes_to_nhwc(const float* planes_nchw, const float* add_nch
     const int HW = H * W;
     dim3 grid((HW + 31) / 32, (C + 31) / 32, N * 3 * depth), block(32, 8);
     ProfScope ps(R3D_PROF_LAYOUT, (hipStream_t)stream);
+    const bool aligned16 = !(((uintptr_t)planes_nchw | (uintptr_t)add_nchw | (uintptr_t)planes_nhwc) & 15);
+    if (C == 32 && depth == 1 && add_flip == 0 && (HW & 63) == 0 && aligned16) {
+        hipLaunchKernelGGL(planes_to_nhwc32_kernel, dim3(HW / 64, N * 3), dim3(256), 0, (hipStream_t)stream, planes_nchw, add_nchw, planes_nhwc, HW);
+        return check_launch("planes_to_nhwc");
+    }
     hipLaunchKernelGGL(planes_to_nhwc_kernel, grid, block, 0, (hipStream_t)stream, planes_nchw, add_nchw, planes_nhwc, C, HW, W, add_flip, depth);
     return check_launch("planes_to_nhwc");
 }
@@ -990,10 +1035,10 @@ extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
                                   const float* origins, const float* dirs, int M,
                                   int Nc, int Nf, float box_warp, int white_back,
                                   const float* noise_c, const float* u_f, uint64_t seed,
-                                  float* rgb, float* depth, float* wsum, uint8_t* valid,
+                                  float* rgb, int rgb_channel_major, float* depth, float* wsum, uint8_t* valid,
                                   void* workspace, size_t workspace_bytes, r3d_stream_t stream)
 {
-    if (!planes_nhwc || !w1 || !b1 || !w2 || !b2 || !origins || !dirs || !rgb || !depth || !wsum || !valid) {
+    if (!planes_nhwc || !w1 || !b1 || !w2 || !b2 || !origins || !dirs || !rgb || !wsum || !valid) {
         set_error("render_forward: NULL pointer"); return R3D_ERR_INVALID_ARG;
     }
     if (N <= 0 || M <= 0 || H <= 1 || W <= 1 || triplane_depth < 1 || triplane_depth > 16 || !(box_warp > 0.f)) { set_error("render_forward: bad shape"); return R3D_ERR_INVALID_ARG; }
@@ -1021,7 +1066,7 @@ extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
     a.origins = origins; a.dirs = dirs; a.ray_start = ray_start; a.ray_end = ray_end; a.valid = valid;
     a.gstate = gstate; a.nlimit_blocks = (nrays + kLimitsBlock - 1) / kLimitsBlock; a.Nc = Nc; a.Nf = Nf; a.scale = 2.0f / box_warp; a.white_back = white_back;
     a.noise_c = noise_c; a.u_f = u_f; a.seed = seed;
-    a.rgb = rgb; a.depth = depth; a.wsum = wsum;
+    a.rgb = rgb; a.depth = depth; a.wsum = wsum; a.rgb_cm = rgb_channel_major ? 1 : 0;
 
     // square image -> XCD strip order; otherwise linear order
     int R = 0;
@@ -1049,8 +1094,10 @@ extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
     else launch_render<6, 6>(a, R, grid, st);
 #undef R3D_CASE
     }
-    ProfScope ps2(R3D_PROF_MISC, st);
-    hipLaunchKernelGGL(depth_clamp_kernel, dim3((nrays + 255) / 256), dim3(256), 0, st, depth, nrays, gstate);
+    if (depth) {
+        ProfScope ps2(R3D_PROF_MISC, st);
+        hipLaunchKernelGGL(depth_clamp_kernel, dim3((nrays + 255) / 256), dim3(256), 0, st, depth, nrays, gstate);
+    }
     return check_launch("render_forward");
 }
 

@@ -834,10 +834,25 @@ __global__ void sr_prepack_up_kernel(const float* __restrict__ w, int Cin, int C
 
 // MX = true (R3D_SR_F16MX): the output feeds the f16mx 3x3 conv: hi plane as usual, and in place of the fp16 lo words the fp8 records
 // (lo chunk 2G <- xh8 of channels 16G..16G+15, lo chunk 2G+1 <- xl8): slice g (8 couts) owns bytes [8 (g & 1), +8) of both words.
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 512)            // experiment build: per-block s_memtime stamps (scripts/gpu_up_stamps.py)
+__device__ unsigned long long g_up_stamps[8 * 4096];
+#define UP_STAMP(i, v) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_up_stamps[8 * blockIdx.x + (i)] = (v); } while (0)
+#else
+#define UP_STAMP(i, v) do { } while (0)
+#endif
 template <bool CLAMP, bool MX = false>
 __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
 {
     __shared__ uint4 lds[U_LDS_UINT4];
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 512)
+    const unsigned long long st_t0 = clock64(); unsigned long long st_wait = 0, st_first = 0;
+#endif
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 1024)           // experiment build: the second block of every CU starts half a main loop late
+    if ((((blockIdx.x >> 3) >> 5) & 1) && (blockIdx.x >> 3) < 64) {
+#pragma unroll 1
+        for (int i = 0; i < R3D_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     const int G = a.Cout >> 5;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;         // the cout groups of one tile share an XCD (one L2)
     const int tl = slot / G, cg = slot - tl * G;
@@ -903,9 +918,15 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
     };
     dma_stage(0, lds);
     for (int st = 0; st < nst; ++st) {
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 512)
+        const unsigned long long st_a = clock64();
+#endif
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this stage's DMAs (issued one stage ago) have landed
         __builtin_amdgcn_s_barrier();                               // ... everybody's; and the other buffer's readers are done
         asm volatile("" ::: "memory");
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 512)
+        { const unsigned long long d = clock64() - st_a; st_wait += d; if (st == 0) st_first = d; }
+#endif
         const uint4* cur = lds + (st & 1) * U_STAGE;
         if (st + 1 < nst) dma_stage(st + 1, lds + ((st + 1) & 1) * U_STAGE);
 #pragma unroll
@@ -947,6 +968,9 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
     // accumulator layout (lane = pixel), so the neighbours arrive by row rotations (v_mov_dpp row_ror:15 / :14; the rotation also covers
     // the odd rows, whose columns are stored rotated by one lane).  Round 1 wrote T to LDS and ran the pass LDS -> LDS: 56 b128 LDS
     // operations per thread and slice, now 28 -- the ablations of round 2 had the epilogue at 56 % of this kernel.
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 512)
+    const unsigned long long st_t1 = clock64();
+#endif
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
     float4* hls0 = reinterpret_cast<float4*>(lds);                  // H: 2 x [pa][half][gy][32] (28 used), column swizzled by 8*half
@@ -1070,7 +1094,22 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
             }
         }
     }
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 512)
+    {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long st_t2 = clock64();
+        UP_STAMP(0, st_t0); UP_STAMP(1, st_first); UP_STAMP(2, st_wait); UP_STAMP(3, st_t1 - st_t0); UP_STAMP(4, st_t2 - st_t0);
+        UP_STAMP(5, (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));   // HW_ID
+        UP_STAMP(6, (unsigned long long)wall_clock64());
+    }
+#endif
 }
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 512)
+extern "C" int r3d_debug_up_stamps(unsigned long long* host, int nblocks)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_up_stamps), sizeof(unsigned long long) * 8 * (size_t)nblocks);
+}
+#endif
 
 // ---- FIR 4x4 (gain 4, pad 1) + bias + lrelu*sqrt2 on the transposed-conv output; writes SPLIT scaled by the next
 // conv's styles.  T is PHASE-MAJOR: T[p=(r&1)*2+(c&1)][C/8][Hin+1][Win+1][8] holds row r, col c of the (2Hin+1)x(2Win+1)

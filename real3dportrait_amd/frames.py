@@ -90,6 +90,7 @@ class ClipRenderer:
         self.ws = ws
         self.base_seed = base_seed
         self.G.renderer.noise_mode = "hash"
+        self.G.renderer.need_depth = False          # only the frames leave this driver
 
     def planes_for(self, t):
         add = self.residuals[t % len(self.residuals)] if self.residuals else None

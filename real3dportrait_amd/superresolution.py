@@ -73,6 +73,7 @@ def const_bound(value, N, device):
     t = _CONST_BOUNDS.get(key)
     if t is None:
         t = torch.full((N,), float(value), device=device, dtype=torch.float32)
+        t._r3d_const = True          # never written again: a fold whose only inputs are such bounds and cached styles can be reused
         _CONST_BOUNDS[key] = t
     return t
 
@@ -198,6 +199,7 @@ class SynthesisBlock(nn.Module):
         self._workspace = None
         self._meter = _BoundMeter()
         self._depth_in = 0             # layers between the last measurement and this block's input (set by whoever folds it)
+        self._fold_epoch = 0           # bumped by every chain_op(): lets a caller see that nobody re-folded the block since its own fold
 
     def _buf(self, name, nbytes, dev):
         t = getattr(self, name)
@@ -258,6 +260,7 @@ class SynthesisBlock(nn.Module):
 
     def chain_op(self, src_a=-1, src_b=_lib.CHAIN_SRC_NONE, tail=False):
         """tail=True: re-fold only the conv1 operand from a MEASURED max|block input| (R3D_CHAIN_SR_BLOCK_TAIL)."""
+        self._fold_epoch += 1        # whoever asks for the op launches a fold that rewrites this block's folded vectors
         return _lib.ChainOp(kind=_lib.CHAIN_SR_BLOCK_TAIL if tail else _lib.CHAIN_SR_BLOCK, Cin=self.in_channels, Cout=self.out_channels, ksize=3, act=1, gain=_SQRT2,
                             clamp=self._clamp(), src_a=src_a, src_b=src_b, scales=self._styles.data_ptr(), prepacked=None, bias=None)
 
@@ -653,6 +656,7 @@ class SuperresolutionHybrid8XDC(nn.Module):
         self._meter = _BoundMeter()
         self._ws3 = None                       # (ws, version, ws[:, -1:].repeat(1, 3, 1)): a clip renders every frame with one ws
         self._mx_slot = None                   # f16mx: max|block0 output| measured in its conv1 epilogue
+        self._fold_sig, self._fold_bx = None, None
 
     def _ws_last3(self, ws):
         c = self._ws3
@@ -688,7 +692,14 @@ class SuperresolutionHybrid8XDC(nn.Module):
                 if self._mx_slot is None or self._mx_slot.shape[0] != x.shape[0] or self._mx_slot.device != x.device:
                     self._mx_slot = torch.zeros(x.shape[0], device=x.device, dtype=torch.float32)
                 x_absmax = self._mx_slot
-            chain_fold([b0.chain_op(-1), b1.chain_op(0)], x.shape[0], [bx], zero=[x_absmax] if mx else ())
+            # The fold is a function of (bx, both blocks' style vectors).  With a constant bound (the renderer's feature image,
+            # const_bound) and the per-clip style cache unchanged, the folded vectors of the previous frame are still in place:
+            # skip the launch (13 us per frame).  f16mx re-folds block1 from a measured max every frame: never skipped.
+            sig = (id(bx), dx, b0._styles_key, b1._styles_key, b0._fold_epoch, b1._fold_epoch, b0.precision)
+            if mx or not getattr(bx, "_r3d_const", False) or self._fold_sig != sig:
+                chain_fold([b0.chain_op(-1), b1.chain_op(0)], x.shape[0], [bx], zero=[x_absmax] if mx else ())
+                self._fold_sig = (id(bx), dx, b0._styles_key, b1._styles_key, b0._fold_epoch, b1._fold_epoch, b0.precision)
+                self._fold_bx = bx           # keeps id(bx) from being recycled
             b0.out_format, nxt = "split", b1
         else:
             b0.out_format, nxt = "cb8", None

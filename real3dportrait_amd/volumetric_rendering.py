@@ -116,6 +116,8 @@ class ImportanceRenderer(nn.Module):
         self.noise_override = None
         self.seed = 0
         self._plane_cache = None       # (source tensor, version, nhwc tensor)
+        self.rgb_channel_major = True  # memory layout of the colours (the returned tensor is [N,M,32] either way)
+        self.need_depth = True         # False: forward returns depth = None and skips the depth-clamp launch (ClipRenderer: frames only)
         self._workspace = None
 
     # -- plane layout ---------------------------------------------------------------------------------
@@ -192,8 +194,14 @@ class ImportanceRenderer(nn.Module):
         elif self.noise_mode != "hash":
             raise ValueError("noise_mode must be 'torch' or 'hash'")
 
-        rgb = torch.empty(N, M, 32, device=dev, dtype=torch.float32)
-        depth = torch.empty(N, M, 1, device=dev, dtype=torch.float32)
+        # the kernel writes the colours channel-major ([N,32,M] = the NCHW feature image synthesis() is about to build); the tensor
+        # handed back is the [N,M,32] VIEW of it, so the reference's permute(0,2,1).reshape(N,32,R,R).contiguous() is free
+        if self.rgb_channel_major:
+            rgb_cm = torch.empty(N, 32, M, device=dev, dtype=torch.float32)
+            rgb = rgb_cm.permute(0, 2, 1)
+        else:
+            rgb_cm = rgb = torch.empty(N, M, 32, device=dev, dtype=torch.float32)
+        depth = torch.empty(N, M, 1, device=dev, dtype=torch.float32) if self.need_depth else None
         wsum = torch.empty(N, M, 1, device=dev, dtype=torch.float32)
         valid = torch.empty(N, M, 1, device=dev, dtype=torch.bool)
         need = int(lib.r3d_render_workspace_bytes(N, M, Nc, Nf))
@@ -204,7 +212,7 @@ class ImportanceRenderer(nn.Module):
             _lib.ptr(o), _lib.ptr(d), M, Nc, Nf, float(rendering_options["box_warp"]),
             int(bool(rendering_options.get("white_back", False))),
             _lib.ptr(noise_c), _lib.ptr(u_f), int(self.seed) & 0xFFFFFFFFFFFFFFFF,
-            _lib.ptr(rgb), _lib.ptr(depth), _lib.ptr(wsum), _lib.ptr(valid),
+            _lib.ptr(rgb_cm), int(self.rgb_channel_major), _lib.ptr(depth), _lib.ptr(wsum), _lib.ptr(valid),
             _lib.ptr(self._workspace), need, _lib.stream_ptr()), "render_forward")
         return rgb, depth, wsum, valid
 

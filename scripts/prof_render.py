@@ -17,7 +17,9 @@ o, d = RaySampler()(cam[:, :16].view(-1, 4, 4), cam[:, 16:].view(-1, 3, 3), R)
 ren = ImportanceRenderer(hp={}); ren.noise_mode = "hash"
 opts = {"ray_start": "auto", "ray_end": "auto", "box_warp": 1.0, "depth_resolution": Nc, "depth_resolution_importance": Nf,
         "disparity_space_sampling": False, "clamp_mode": "softplus", "white_back": False}
-for _ in range(2): ren(planes, dec, o, d, opts)
-torch.cuda.synchronize(); t = time.perf_counter()
-for _ in range(reps): ren(planes, dec, o, d, opts)
-torch.cuda.synchronize(); print("render R=%d %d+%d: %.3f ms" % (R, Nc, Nf, (time.perf_counter() - t) / reps * 1e3))
+for cm in ((True, False, True, False) if os.environ.get("R3D_PROF_LAYOUTS") else (True,)):
+    ren.rgb_channel_major = cm
+    for _ in range(2): ren(planes, dec, o, d, opts)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(reps): ren(planes, dec, o, d, opts)
+    torch.cuda.synchronize(); print("render R=%d %d+%d%s: %.3f ms" % (R, Nc, Nf, "" if cm else " (colours [N,M,32])", (time.perf_counter() - t) / reps * 1e3))
