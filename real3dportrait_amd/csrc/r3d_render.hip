@@ -281,10 +281,11 @@ __device__ __forceinline__ void plane_taps(float u, float v, int H, int W, int p
     const bool vy0 = okc && y0 >= 0 && y0 < H, vy1 = okc && y0 + 1 >= 0 && y0 + 1 < H;
     const int xa = min(max(x0, 0), W - 1), xb = min(max(x0 + 1, 0), W - 1);
     const int ya = min(max(y0, 0), H - 1), yb = min(max(y0 + 1, 0), H - 1);
-    t[0].idx = plane_base4 + (ya * W + xa) * 8; t[0].w = (vx0 && vy0) ? fx0 * fy0 : 0.0f;
-    t[1].idx = plane_base4 + (ya * W + xb) * 8; t[1].w = (vx1 && vy0) ? fx1 * fy0 : 0.0f;
-    t[2].idx = plane_base4 + (yb * W + xa) * 8; t[2].w = (vx0 && vy1) ? fx0 * fy1 : 0.0f;
-    t[3].idx = plane_base4 + (yb * W + xb) * 8; t[3].w = (vx1 && vy1) ? fx1 * fy1 : 0.0f;
+    const int ra = __mul24(ya, W), rb = __mul24(yb, W);  // 24-bit multiply (full rate; v_mul_lo_u32 is quarter rate): H, W < 2^24 (host check)
+    t[0].idx = plane_base4 + (ra + xa) * 8; t[0].w = (vx0 && vy0) ? fx0 * fy0 : 0.0f;
+    t[1].idx = plane_base4 + (ra + xb) * 8; t[1].w = (vx1 && vy0) ? fx1 * fy0 : 0.0f;
+    t[2].idx = plane_base4 + (rb + xa) * 8; t[2].w = (vx0 && vy1) ? fx0 * fy1 : 0.0f;
+    t[3].idx = plane_base4 + (rb + xb) * 8; t[3].w = (vx1 && vy1) ? fx1 * fy1 : 0.0f;
 }
 
 template <int PLANES_IN_FLIGHT, bool TRI = false>

@@ -224,12 +224,13 @@ struct Conv2Args {
     const float* wrgb; size_t wrgb_stride_n; float* rgb_partial; size_t rgbp_stride_n;   // toRGB partials [Cout/128][3][OH*OW] or null
     int Cin, Cout, CoutReal, H, W, nphase;    // Cout: padded to 128 (weight layout); CoutReal: channels that exist in the outputs
     int act; float act_slope, act_gain, clamp; // act: leaky-relu(slope) * gain after the bias; clamp < 0: off
+    int order;                                // conv3x3_dma_block: 0 = (tile, cout tile) = (blockIdx.x, blockIdx.y); 1 / 2 = the cout tiles of a pixel tile adjacent in dispatch order on one XCD
     ConvPhase ph[4];
 };
 
 // Epilogue of a 128-cout x 16x16-pixel block held as acc[2][NT] per wave: demodulation * acc (+ bias -> lrelu * gain ->
 // clamp) -> any of {fp32 channel-blocked, fp32 NCHW, SPLIT scaled by the next layer's styles} + toRGB partial sums.
-// toRGB partials: one plane per 64-cout half (index 2 * blockIdx.y + wm); rgb_finalize_kernel adds them up.
+// toRGB partials: one plane per 64-cout half (index m0 / 64 + wm); rgb_finalize_kernel adds them up.
 // The per-cout vectors (out_scale, bias, next_scale, 3 toRGB weight rows) of the block's 128 couts are staged in LDS ONCE, after
 // the main loop: loaded from global inside the group loop they put an `s_waitcnt vmcnt(0)` -- which on gfx9 also waits for every
 // store issued before it -- in front of each of the 16 groups (48 serialised memory round trips = the 29 k-cycle epilogue that
@@ -335,7 +336,7 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
 #pragma unroll
             for (int o = 0; o < 3; ++o) rgbp[nt][o] += __shfl_xor(rgbp[nt][o], 32);
         if (h == 0) {
-            float* P = a.rgb_partial + (size_t)n * a.rgbp_stride_n + (size_t)(2 * blockIdx.y + wm) * 3 * a.OH * a.OW;
+            float* P = a.rgb_partial + (size_t)n * a.rgbp_stride_n + (size_t)(m0 / 64 + wm) * 3 * a.OH * a.OW;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int i = i0 + row0 + nt * 2 + prow, j = j0 + pcol;
@@ -541,10 +542,24 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
     uint4* pbuf = lds;                                                // [2][P_BUF]
     uint4* wbuf = lds + 2 * P_BUF;                                    // [2][W2_BUF]
     const int tiles_x = (ph.outW + F_TILE_W - 1) / F_TILE_W;
-    const int tile = blockIdx.x;
+    int tile = blockIdx.x, cgi = blockIdx.y;
+    if (a.order) {
+        // Workgroups are dispatched in linear order (x fastest), round-robin over the 8 XCDs.  With (tile, cout tile) = (x, y) the second
+        // cout tile of a 256-cout layer re-reads every input patch ~0.1 ms after the first: by then it has left the XCD's 4 MB L2 and
+        // comes from HBM again, and horizontally adjacent tiles sit on different XCDs, so the 288-byte patch rows (18 pixels, not
+        // line-aligned) are fetched as whole 128-byte lines by each of them: measured 318 MB for the 137 MB of block0.conv1.  Here the cout
+        // tiles of one pixel tile are consecutive slots of ONE XCD, and (order 2) an XCD owns a contiguous band of tiles, so halo
+        // lines and the second cout tile hit its L2: 172 MB (order 1, tiles interleaved over the XCDs: 233 MB).  Time-neutral: the
+        // kernel is MFMA / power bound.  (host: only when the tile count is a multiple of 8)
+        const int G = gridDim.y, b = blockIdx.x + gridDim.x * blockIdx.y;
+        const int xcd = b & 7, slot = b >> 3;
+        cgi = slot % G;
+        const int t = slot / G;
+        tile = a.order == 1 ? t * 8 + xcd : xcd * (gridDim.x >> 3) + t;
+    }
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
     const int i0 = ty * F_TILE_H, j0 = tx * F_TILE_W;
-    const int m0 = blockIdx.y * BLOCK_M;
+    const int m0 = cgi * BLOCK_M;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int wm = wave / WN, wn = wave - wm * WN;
@@ -1013,11 +1028,12 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float t0 = acc[2 * pa][nt][4 * g + r] * dv[r], t1 = acc[2 * pa + 1][nt][4 * g + r] * dv[r];
-                    // lane i <- lane (i + 1) % 16 / (i + 2) % 16 of its 16-lane row: row_ror:15 = 0x12F, row_ror:14 = 0x12E
-                    const float t0p1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t0), 0x12F, 0xF, 0xF, false));
-                    const float t1p1 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t1), 0x12F, 0xF, 0xF, false));
-                    const float t0p2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t0), 0x12E, 0xF, 0xF, false));
-                    const float t1p2 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, t1), 0x12E, 0xF, 0xF, false));
+                    // lane i <- lane (i + 1) % 16 / (i + 2) % 16 of its 16-lane row: row_ror:15 = 0x12F, row_ror:14 = 0x12E (a rotation has no
+                    // invalid source lane: mov_dpp with bound_ctrl, no `old` operand to initialise -- update_dpp(0, ...) cost one v_mov per DPP)
+                    const float t0p1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t0), 0x12F, 0xF, 0xF, true));
+                    const float t1p1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t1), 0x12F, 0xF, 0xF, true));
+                    const float t0p2 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t0), 0x12E, 0xF, 0xF, true));
+                    const float t1p2 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t1), 0x12E, 0xF, 0xF, true));
                     hx[0][r] = (t1 + t0p2) * c0 + (t0p1 + t1p1) * c1;
                     hx[1][r] = (t0p1 + t1p2) * c0 + (t1p1 + t0p2) * c1;
                 }
@@ -1382,6 +1398,8 @@ static void launch_conv2(Conv2Args& a, int tiles, int N, hipStream_t st, bool mx
 
     dim3 grid(tiles, a.Cout / BLOCK_M, N * a.nphase);
     static const int shape = getenv("R3D_CONV_SHAPE") ? atoi(getenv("R3D_CONV_SHAPE")) : 0;   // tuning switch, default 0
+    static const int order = getenv("R3D_CONV_ORDER") ? atoi(getenv("R3D_CONV_ORDER")) : 2;   // tuning switch (0: plain (x, y) order)
+    a.order = (tiles & 7) == 0 ? order : 0;
     const int kind = a.nphase > 1 ? 2 : (a.ph[0].ntaps == 9 ? 0 : 1);      // 0: 3x3 conv, 1: 1x1 conv, 2: transposed-conv phases
     if (shape == 1) {           // 4 waves x (64 couts x 128 px), 2 blocks/CU
         if (kind == 0) hipLaunchKernelGGL((conv_mfma_f16x3_kernel<2, 4, 2>), grid, dim3(256), 0, st, a);
