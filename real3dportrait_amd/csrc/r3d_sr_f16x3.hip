@@ -689,7 +689,11 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
                     for (int mt = 0; mt < 2; ++mt) {
                         uint4 q0 = curW[ts * 512 + aoff + mt * 32];
                         ah[mt] = *reinterpret_cast<h8*>(&q0);
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 2048)          // experiment build (wrong results): half the operand reads from LDS, same MFMAs
+                        if (!MX) al[mt] = ah[mt];
+#else
                         if (!MX) { uint4 q1 = curW[ts * 512 + aoff + mt * 32 + 128]; al[mt] = *reinterpret_cast<h8*>(&q1); }
+#endif
                     }
                     const int toff = ph.dy[t] * F_PATCH_W + ph.dx[t];
 #pragma unroll
@@ -697,7 +701,11 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
                         uint4 r0 = curP[boff[nt] + toff];
                         const h8 bh = *reinterpret_cast<h8*>(&r0);
                         h8 bl;
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 2048)
+                        if (!MX) bl = bh;
+#else
                         if (!MX) { uint4 r1 = curP[boff[nt] + toff + 2 * F_PATCH_PIX]; bl = *reinterpret_cast<h8*>(&r1); }
+#endif
 #pragma unroll
                         for (int mt = 0; mt < 2; ++mt) {
 #if defined(R3D_ABLATE) && (R3D_ABLATE & 1)     // experiment build: operands are still read (kept alive), no MFMAs
