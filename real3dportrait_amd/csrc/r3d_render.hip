@@ -365,14 +365,20 @@ __device__ __forceinline__ void gather_sample(const float4* __restrict__ planes4
             }
         }
     } else {
-        // one plane's 8 loads in flight at a time (register budget for 3 waves/SIMD)
+        // one plane's 8 loads in flight at a time.
+        // (Tried in round 2: the four lanes of a sample are one DPP quad in the gather mapping and compute the same 12 taps; letting
+        // lane q compute plane min(q, 2) only and sharing the taps inside the quad -- quad_perm DPP or ds_bpermute, both -- was 4 %
+        // faster and bit-identical in every single-stream test, but produced rare wrong rays (1 in ~15 000) whenever SR kernels of other
+        // streams were co-resident on the CU, and not when any checking code was compiled in.  Not understood, not shipped:
+        // scripts/gpu_debug_determinism.py)
+        const float4* __restrict__ pl = planes4 + 2 * q;            // this lane's 8 channels of a texel
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             Tap t[4];
-            plane_taps(us[p], vs[p], H, W, p * HW8 + 2 * q, t);
+            plane_taps(us[p], vs[p], H, W, p * HW8, t);
             float4 lo[4], hi[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { lo[i] = planes4[t[i].idx]; hi[i] = planes4[t[i].idx + 1]; }
+            for (int i = 0; i < 4; ++i) { lo[i] = pl[t[i].idx]; hi[i] = pl[t[i].idx + 1]; }
 #pragma unroll
             for (int c = 0; c < 8; ++c) acc[p][c] = 0.0f;
 #pragma unroll
@@ -459,21 +465,34 @@ __device__ __forceinline__ void decode_tile(const DecoderLds& L, int lane, const
 // -------------------------------------------------------------------------------------------------
 // wave scans
 // -------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_incl_mul(float v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const float o = __shfl_up(v, d); if (lane >= d) v *= o; }
+// DPP scans (no LDS crossbar round trips: a __shfl_up step is a ds_bpermute + compare + select, six dependent ones per scan; here a
+// step is one VALU instruction): Hillis-Steele inside each 16-lane row (row_shr:1,2,4,8; lanes without a source keep `old` = the
+// identity), then the row totals travel with row_bcast:15 (rows 1, 3 <- lane 15 of rows 0, 2) and row_bcast:31 (rows 2, 3 <- lane 31).
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f(float old, float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_i(int old, int x) { return __builtin_amdgcn_update_dpp(old, x, CTRL, ROW_MASK, 0xF, false); }
+__device__ __forceinline__ float wave_incl_mul(float v, int) {
+    v *= dpp_f<0x111>(1.0f, v); v *= dpp_f<0x112>(1.0f, v); v *= dpp_f<0x114>(1.0f, v); v *= dpp_f<0x118>(1.0f, v);
+    v *= dpp_f<0x142, 0xA>(1.0f, v); v *= dpp_f<0x143, 0xC>(1.0f, v);
     return v;
 }
-__device__ __forceinline__ float wave_incl_add(float v, int lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const float o = __shfl_up(v, d); if (lane >= d) v += o; }
+__device__ __forceinline__ float wave_incl_add(float v, int) {
+    v += dpp_f<0x111>(0.0f, v); v += dpp_f<0x112>(0.0f, v); v += dpp_f<0x114>(0.0f, v); v += dpp_f<0x118>(0.0f, v);
+    v += dpp_f<0x142, 0xA>(0.0f, v); v += dpp_f<0x143, 0xC>(0.0f, v);
     return v;
 }
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+__device__ __forceinline__ int wave_incl_add_i(int v) {
+    v += dpp_i<0x111>(0, v); v += dpp_i<0x112>(0, v); v += dpp_i<0x114>(0, v); v += dpp_i<0x118>(0, v);
+    v += dpp_i<0x142, 0xA>(0, v); v += dpp_i<0x143, 0xC>(0, v);
     return v;
 }
+// lane i <- lane i - 1 over the whole wave (wave_shr:1), lane 0 <- `first`
+__device__ __forceinline__ float wave_shift_up1(float v, float first) { return dpp_f<0x138>(first, v); }
+__device__ __forceinline__ float lane63(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63)); }
+__device__ __forceinline__ float wave_sum(float v) { return lane63(wave_incl_add(v, 0)); }
 __device__ __forceinline__ void wave_lds_sync() {
     // LDS traffic of one wave is in order; this only stops the compiler from reordering around it
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -535,10 +554,9 @@ __device__ __forceinline__ void march(const float* T, const float* S, float* wv,
         const float alpha = 1.0f - fexp(-(sp * delta));
         const float om1 = act ? (1.0f - alpha + 1e-10f) : 1.0f;
         const float incl = wave_incl_mul(om1, lane);
-        float excl = __shfl_up(incl, 1);
-        if (lane == 0) excl = 1.0f;
+        const float excl = wave_shift_up1(incl, 1.0f);
         const float w = act ? alpha * (carry * excl) : 0.0f;
-        carry *= __shfl(incl, 63);
+        carry *= lane63(incl);
         if (act) wv[i] = w;
         ws += w;
         ds += w * tmid;
@@ -689,7 +707,7 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
                 const int i = sl * 64 + lane;
                 const float incl = wave_incl_add(omega[sl] / tot, lane);
                 if (i < ns) L.cdf[i + 1] = carry + incl;
-                carry += __shfl(incl, 63);
+                carry += lane63(incl);
             }
             wave_lds_sync();
 #pragma unroll
@@ -772,10 +790,9 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
                 for (int sl = 0; sl < CSLOTS; ++sl) {
                     const int i = sl * 64 + lane;
                     int v = i < Nc ? L.cnt[i] : 0;
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(v, d); if (lane >= d) v += o; }
+                    v = wave_incl_add_i(v);
                     rc[sl] = i + carry + v;
-                    carry += __shfl(v, 63);
+                    carry += __builtin_amdgcn_readlane(v, 63);
                 }
                 wave_lds_sync();
                 // collision check: every rank slot must be claimed exactly once
@@ -875,7 +892,8 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v = acc[ot][r];
-                v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+                // sum over the 16 samples of the tile row (all 16 lanes end with the total): rotations inside the DPP row
+                v += dpp_f<0x128>(0.0f, v); v += dpp_f<0x124>(0.0f, v); v += dpp_f<0x122>(0.0f, v); v += dpp_f<0x121>(0.0f, v);
                 if (a.white_back) v = v + 1.0f - wsum;
                 acc[ot][r] = v * 2.0f - 1.0f;            // ray_marcher.py:52-55
             }

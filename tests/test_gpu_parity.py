@@ -489,6 +489,38 @@ def test_sr_concurrent_streams_are_bit_identical(torch_cuda):
             assert torch.equal(o, ref)
 
 
+def test_ray_kernel_is_independent_of_coresident_kernels(torch_cuda):
+    """The feature images of frames rendered on three streams, with SR kernels of the other streams co-resident on the CUs, must equal
+    the sequentially rendered ones bit for bit (a round-2 variant of the gather that shared tap addresses inside lane quads passed every
+    single-stream test and failed exactly this: ~1 ray in 15 000; scripts/gpu_debug_determinism.py)."""
+    torch = torch_cuda
+    from real3dportrait_amd import TriPlaneGenerator, synth
+    from real3dportrait_amd.frames import ClipRenderer, clone_generator_shell
+    G = TriPlaneGenerator().cuda().eval()
+    dec = synth.synth_decoder(3, sigma_bias=4.0)
+    with torch.no_grad():
+        G.decoder.net[0].weight.copy_(T(torch, dec[0])); G.decoder.net[0].bias.copy_(T(torch, dec[1]))
+        G.decoder.net[2].weight.copy_(T(torch, dec[2])); G.decoder.net[2].bias.copy_(T(torch, dec[3]))
+    cano = T(torch, synth.synth_planes(3, N=1)); res = [T(torch, synth.synth_planes(4 + i, N=1, scale=0.1)) for i in range(2)]
+    cams = T(torch, synth.camera_sweep(6, -0.3, 0.3)); ws = torch.ones(1, 14, 512, device="cuda")
+    shells = [ClipRenderer(G, cano, res, cams, ws, base_seed=11)]
+    shells += [ClipRenderer(clone_generator_shell(G), cano, res, cams, ws, base_seed=11) for _ in range(2)]
+    ref = [shells[0]._features(t).clone() for t in range(6)]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    sr_in = torch.randn(1, 32, 128, 128, device="cuda")
+    torch.cuda.synchronize()
+    bad = 0
+    for _ in range(30):
+        out = [None] * 6
+        for t in range(6):
+            with torch.cuda.stream(streams[t % 3]):
+                out[t] = shells[t % 3]._features(t).clone()
+                shells[t % 3].G.superresolution(sr_in[:, :3], sr_in, ws, noise_mode="none")
+        torch.cuda.synchronize()
+        bad += sum(int(not torch.equal(a, b)) for a, b in zip(ref, out))
+    assert bad == 0, "%d of 180 frames differ from the sequential render" % bad
+
+
 def test_multi_stream_pipeline_is_bit_identical(torch_cuda):
     """Frames issued round-robin on several HIP streams (own workspaces, shared parameters) must equal the
     single-stream frames bit for bit: the hash noise depends on the frame index only."""
