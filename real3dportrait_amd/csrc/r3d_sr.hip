@@ -618,6 +618,10 @@ extern "C" int r3d_sr_block_forward(const void* prepacked, const void* styles, i
         set_error("sr_block_forward: bad argument"); return R3D_ERR_INVALID_ARG;
     }
     if (!up && precision == R3D_SR_F32) { set_error("sr_block_forward: up=0 (SynthesisBlockNoUp) needs R3D_SR_F16X3"); return R3D_ERR_INVALID_ARG; }
+    {   // the kernels index one sample's activation with 32 bits
+        const size_t ohw = (size_t)(up ? 4 : 1) * Hin * Win, cmax = (size_t)(Cin > Cout ? Cin : Cout);
+        if (cmax * ohw >= ((size_t)1 << 32)) { set_error("sr_block_forward: activation of %zu elements per sample exceeds the 32-bit index range", cmax * ohw); return R3D_ERR_INVALID_ARG; }
+    }
     if (!workspace || workspace_bytes < r3d_sr_block_workspace_bytes(N, Cin, Cout, Hin, Win)) {
         set_error("sr_block_forward: workspace too small"); return R3D_ERR_WORKSPACE;
     }
@@ -790,6 +794,10 @@ extern "C" int r3d_conv_forward(const void* prepacked, const void* scales, const
         set_error("conv_forward: unsupported activation format (x %d, y %d)", x_format, y_format); return R3D_ERR_INVALID_ARG;
     }
     if (Cout & 3) { set_error("conv_forward: Cout = %d must be a multiple of 4", Cout); return R3D_ERR_INVALID_ARG; }
+    {   // the kernels index one sample's activation with 32 bits (Cout padded to the 128-cout block)
+        const size_t cmax = (size_t)((Cin > Cout ? Cin : Cout) + BLOCK_M);
+        if (cmax * H * W >= ((size_t)1 << 32)) { set_error("conv_forward: activation of %zu elements per sample exceeds the 32-bit index range", cmax * H * W); return R3D_ERR_INVALID_ARG; }
+    }
     if ((x_format != R3D_FMT_NCHW && (Cin & 15)) || (y_format != R3D_FMT_NCHW && (Cout & 7))) {
         set_error("conv_forward: blocked formats need Cin %% 16 == 0 and Cout %% 8 == 0 (Cin %d, Cout %d)", Cin, Cout); return R3D_ERR_INVALID_ARG;
     }

@@ -267,6 +267,19 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { rgbp[nt][0] = 0.f; rgbp[nt][1] = 0.f; rgbp[nt][2] = 0.f; }
     const size_t oplane = (size_t)(a.CoutReal >> 3) * a.OH * a.OW;
+    // Address arithmetic in 32 bits with the per-channel-plane part on the scalar unit: plane index and plane stride are wave-uniform,
+    // the pixel offset is computed once per N tile (the 64-bit multiplies per store group were a third of the epilogue's VALU cycles).
+    // host: (Cout/8) * OH * OW * 8 < 2^32 for every layer that gets here (checked in launch_conv2)
+    const unsigned cs = (unsigned)a.OH * (unsigned)a.OW;
+    const int wm_u = __builtin_amdgcn_readfirstlane(wm);
+    unsigned p0[NT];
+    bool inside_nt[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int i = i0 + row0 + nt * 2 + prow, j = j0 + pcol;
+        inside_nt[nt] = i < ph.outH && j < ph.outW;
+        p0[nt] = (unsigned)(i * ph.oy_mul + ph.oy_add) * (unsigned)a.OW + (unsigned)(j * ph.ox_mul + ph.ox_add);
+    }
     float* Yf = a.y_f32 ? a.y_f32 + (size_t)n * a.y_f32_stride_n + ph.out_off : nullptr;
     float* Yn = (FULL_EPI && a.y_nchw) ? a.y_nchw + (size_t)n * a.y_nchw_stride_n : nullptr;
     uint4* Ys = (FULL_EPI && a.y_split) ? a.y_split + (size_t)n * a.y_split_stride_n : nullptr;
@@ -275,8 +288,10 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const int cl = 64 * wm + 32 * mt + 8 * g + 4 * h, co = m0 + cl;
+            const int cu = 64 * wm_u + 32 * mt + 8 * g;                // wave-uniform part of the cout index
+            const int cl = cu + 4 * h, co = m0 + cl;
             if (co >= a.CoutReal) continue;                           // channels that only exist as weight padding
+            const unsigned pbase = (unsigned)((m0 + cu) >> 3) * cs;   // first element of this group's 8-channel plane (scalar)
             const float4 d4 = *reinterpret_cast<const float4*>(ev + cl);
             const float4 b4 = *reinterpret_cast<const float4*>(ev + EV_STRIDE + cl);
             const float4 s4 = *reinterpret_cast<const float4*>(ev + 2 * EV_STRIDE + cl);
@@ -286,9 +301,7 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
             const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w}, sv[4] = {s4.x, s4.y, s4.z, s4.w};
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const int i = i0 + row0 + nt * 2 + prow, j = j0 + pcol;
-                const bool inside = i < ph.outH && j < ph.outW;
-                const int oy = i * ph.oy_mul + ph.oy_add, ox = j * ph.ox_mul + ph.ox_add;
+                const bool inside = inside_nt[nt];
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -307,18 +320,18 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
                 }
                 if (!inside) continue;
                 if (want_max) vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
-                const size_t pix = ((size_t)(co >> 3) * a.OH + oy) * a.OW + ox;
-                if (Yf) *reinterpret_cast<float4*>(Yf + pix * 8 + (co & 7)) = make_float4(v[0], v[1], v[2], v[3]);
+                const unsigned pix = pbase + p0[nt];
+                if (Yf) *reinterpret_cast<float4*>(Yf + (size_t)pix * 8 + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
                 if (Yn) {
-                    const size_t hw = (size_t)a.OH * a.OW, p0 = (size_t)oy * a.OW + ox;
+                    float* yn = Yn + (size_t)(unsigned)(m0 + cu) * cs + (size_t)((unsigned)(4 * h) * cs + p0[nt]);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) Yn[(size_t)(co + r) * hw + p0] = v[r];
+                    for (int r = 0; r < 4; ++r) yn[(size_t)r * cs] = v[r];
                 }
                 if (Ys) {
                     h4 hi, lo;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { _Float16 x0, x1; split1_folded(v[r] * sv[r], x0, x1); hi[r] = x0; lo[r] = x1; }
-                    uint2* dst = reinterpret_cast<uint2*>(Ys + pix) + ((co & 7) >> 2);
+                    uint2* dst = reinterpret_cast<uint2*>(Ys + pix) + h;
                     dst[0] = *reinterpret_cast<uint2*>(&hi);
                     dst[2 * oplane] = *reinterpret_cast<uint2*>(&lo);
                 }
