@@ -255,7 +255,17 @@ __global__ void absmax_kernel(const float* __restrict__ x, size_t count, unsigne
     const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)n * count);
     const size_t n4 = (count & 3) ? 0 : (count >> 2);                  // vector path only when every sample stays 16-byte aligned
     float m = 0.f;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {                      // four independent 16-byte loads in flight per lane
+        const float4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+        const float ma = fmaxf(fmaxf(fabsf(a.x), fabsf(a.y)), fmaxf(fabsf(a.z), fabsf(a.w)));
+        const float mb = fmaxf(fmaxf(fabsf(b.x), fabsf(b.y)), fmaxf(fabsf(b.z), fabsf(b.w)));
+        const float mc = fmaxf(fmaxf(fabsf(c.x), fabsf(c.y)), fmaxf(fabsf(c.z), fabsf(c.w)));
+        const float md = fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w)));
+        m = fmaxf(m, fmaxf(fmaxf(ma, mb), fmaxf(mc, md)));
+    }
+    for (; i < n4; i += stride) {
         const float4 v = x4[i];
         m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
@@ -772,7 +782,7 @@ extern "C" int r3d_absmax(const float* x, size_t count_per_sample, int N, float*
     using namespace r3d;
     if (!x || !out || N <= 0 || count_per_sample == 0) { set_error("absmax: bad argument"); return R3D_ERR_INVALID_ARG; }
     size_t blocks = (count_per_sample / 4 + 255) / 256;
-    if (blocks > 512) blocks = 512;
+    if (blocks > 2048) blocks = 2048;                   // 8 blocks per CU; each lane then streams 4 x 16 B per iteration
     if (blocks < 1) blocks = 1;
     ProfScope ps(R3D_PROF_LAYOUT, (hipStream_t)stream);
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, x, count_per_sample,
