@@ -264,6 +264,9 @@ __device__ __forceinline__ void stage_decoder(DecoderLds& L, const float* __rest
 // plane2 (z,x); first coordinate indexes W.  planes: [3][H][W][32] floats viewed as float4.
 // -------------------------------------------------------------------------------------------------
 struct Tap { int idx; float w; };
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 8192)
+__device__ int g_dbg[64 + 64 * 24];
+#endif
 
 __device__ __forceinline__ void plane_taps(float u, float v, int H, int W, int plane_base4, Tap t[4])
 {
@@ -290,7 +293,7 @@ __device__ __forceinline__ void plane_taps(float u, float v, int H, int W, int p
 
 template <int PLANES_IN_FLIGHT, bool TRI = false>
 __device__ __forceinline__ void gather_sample(const float4* __restrict__ planes4, int H, int W, int q,
-                                              float px, float py, float pz, float scale, float x[8], int D = 1)
+                                              float px, float py, float pz, float scale, float x[8], int D = 1, int* dbg_flag = nullptr)
 {
     const float qx = px * scale, qy = py * scale, qz = pz * scale;
     const int HW8 = H * W * 8;
@@ -372,10 +375,40 @@ __device__ __forceinline__ void gather_sample(const float4* __restrict__ planes4
         // streams were co-resident on the CU, and not when any checking code was compiled in.  Not understood, not shipped:
         // scripts/gpu_debug_determinism.py)
         const float4* __restrict__ pl = planes4 + 2 * q;            // this lane's 8 channels of a texel
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 4096)           // experiment build: the quad-shared taps described above
+        const int pq = q < 2 ? q : 2;
+        Tap tq[4];
+        plane_taps(pq == 2 ? qz : qx, pq == 0 ? qy : (pq == 1 ? qz : qx), H, W, pq * HW8, tq);
+#endif
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             Tap t[4];
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 4096)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                t[k].idx = p == 0 ? __builtin_amdgcn_mov_dpp(tq[k].idx, 0x00, 0xF, 0xF, true) : p == 1 ? __builtin_amdgcn_mov_dpp(tq[k].idx, 0x55, 0xF, 0xF, true) : __builtin_amdgcn_mov_dpp(tq[k].idx, 0xAA, 0xF, 0xF, true);
+                const int wi = __builtin_bit_cast(int, tq[k].w);
+                t[k].w = __builtin_bit_cast(float, p == 0 ? __builtin_amdgcn_mov_dpp(wi, 0x00, 0xF, 0xF, true) : p == 1 ? __builtin_amdgcn_mov_dpp(wi, 0x55, 0xF, 0xF, true) : __builtin_amdgcn_mov_dpp(wi, 0xAA, 0xF, 0xF, true));
+            }
+#if (R3D_ABLATE & 8192)                                 // ... and compared (branch-free) with this lane's own taps
+            {
+                Tap tr[4];
+                plane_taps(us[p], vs[p], H, W, p * HW8, tr);
+                int f = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) f |= (t[k].idx ^ tr[k].idx) | (__float_as_int(t[k].w) ^ __float_as_int(tr[k].w));
+                if (dbg_flag) {
+                    *dbg_flag |= (f != 0) << p;
+                    // do the quad's lanes hold the same sample position at all?
+                    const int x0 = __builtin_amdgcn_mov_dpp(__float_as_int(qx), 0x00, 0xF, 0xF, true), y0 = __builtin_amdgcn_mov_dpp(__float_as_int(qy), 0x00, 0xF, 0xF, true);
+                    const int z0 = __builtin_amdgcn_mov_dpp(__float_as_int(qz), 0x00, 0xF, 0xF, true);
+                    *dbg_flag |= ((x0 ^ __float_as_int(qx)) | (y0 ^ __float_as_int(qy)) | (z0 ^ __float_as_int(qz))) != 0 ? 8 : 0;
+                }
+            }
+#endif
+#else
             plane_taps(us[p], vs[p], H, W, p * HW8, t);
+#endif
             float4 lo[4], hi[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) { lo[i] = pl[t[i].idx]; hi[i] = pl[t[i].idx + 1]; }
@@ -630,6 +663,9 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
     const float gmin_start = ord2f(pmin), gmax_start = ord2f(pmax);
     const bool any_valid = pany != 0;
     float run_min = INFINITY, run_max = -INFINITY;
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 8192)
+    int dbg_flag = 0;
+#endif
 
     for (int iter = 0;; ++iter) {
         int ray;
@@ -663,7 +699,11 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
             f32x4 c2[2];
             h8 xh, xl;
             const float tg = __shfl(tc[nt], gs);       // depth of the sample this lane gathers for (lane gs: q = 0, s = gs)
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 8192)
+            { int f1 = 0; gather_sample<GPF, TRI>(P, a.H, a.W, gq, ox + tg * dx, oy + tg * dy, oz + tg * dz, a.scale, X, a.D, &f1); dbg_flag |= f1 ? (f1 | (16 << nt)) : 0; }
+#else
             gather_sample<GPF, TRI>(P, a.H, a.W, gq, ox + tg * dx, oy + tg * dy, oz + tg * dz, a.scale, X, a.D);
+#endif
             gather_to_mfma(E, lane, X, xh, xl);
             decode_tile(dec, lane, xh, xl, c2, sigc[nt]);
             colc[0][nt] = c2[0]; colc[1][nt] = c2[1];
@@ -736,7 +776,11 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
                 float X[8];
                 f32x4 c2[2];
                 h8 xh, xl;
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 8192)
+                { int f1 = 0; gather_sample<GPF, TRI>(P, a.H, a.W, gq, ox + tf * dx, oy + tf * dy, oz + tf * dz, a.scale, X, a.D, &f1); dbg_flag |= f1 ? (f1 | (128 << nt)) : 0; }
+#else
                 gather_sample<GPF, TRI>(P, a.H, a.W, gq, ox + tf * dx, oy + tf * dy, oz + tf * dz, a.scale, X, a.D);
+#endif
                 gather_to_mfma(E, lane, X, xh, xl);
                 decode_tile(dec, lane, xh, xl, c2, sigf[nt]);
                 colf[0][nt] = c2[0]; colf[1][nt] = c2[1];
@@ -920,6 +964,19 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
             if (a.depth) a.depth[ray] = dsum / wsum;     // NaN handled + clamped by depth_clamp_kernel
             a.wsum[ray] = wsum;
         }
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 8192)
+        {
+            const unsigned long long bal = __ballot(dbg_flag != 0);
+            if (lane == 0 && bal) a.wsum[ray] = wsum + 1000.0f * (float)__popcll(bal);
+            if (bal) {
+                int slot = 0;
+                if (lane == 0) slot = atomicAdd(&g_dbg[0], 1);
+                slot = __shfl(slot, 0);
+                if (slot < 24) g_dbg[64 + 64 * slot + lane] = dbg_flag | (ray << 8);
+            }
+            dbg_flag = 0;
+        }
+#endif
         wave_lds_sync();
     }
 #pragma unroll
@@ -1014,6 +1071,9 @@ static void launch_render_tri(const RenderArgs& a, int R, int grid, hipStream_t 
 
 using namespace r3d;
 
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 8192)
+extern "C" int r3d_debug_read(int* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(r3d::g_dbg), sizeof(int) * (64 + 64 * 24)); }
+#endif
 extern "C" int r3d_planes_to_nhwc(const float* planes_nchw, const float* add_nchw, float* planes_nhwc,
                                   int N, int C, int H, int W, int depth, int add_flip, r3d_stream_t stream)
 {

@@ -106,6 +106,7 @@ class ClipRenderer:
         cam = self.cameras[t: t + 1]
         o, d = G.ray_sampler(cam[:, :16].view(-1, 4, 4), cam[:, 16:25].view(-1, 3, 3), G.neural_rendering_resolution)
         feat, depth, wsum, valid = G.renderer(self.planes_for(t), G.decoder, o, d, G.rendering_kwargs)
+        self._last_wsum = wsum          # (kept for the determinism probe)
         R = G.neural_rendering_resolution
         fimg = feat.permute(0, 2, 1).reshape(1, 32, R, R).contiguous()
         fimg._r3d_bound = const_bound(1.01, 1, fimg.device)

@@ -7,6 +7,7 @@ from real3dportrait_amd import TriPlaneGenerator, synth
 from real3dportrait_amd.frames import ClipRenderer, clone_generator_shell
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 with_sr = (sys.argv[2] != "0") if len(sys.argv) > 2 else True
+other = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] not in ("0", "1") else None      # co-resident load instead of the SR: gemm | copy | f32sr
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 G = TriPlaneGenerator().cuda().eval()
 dec = synth.synth_decoder(3, sigma_bias=4.0)
@@ -16,36 +17,61 @@ cano = T(synth.synth_planes(3, N=1)); res = [T(synth.synth_planes(4 + i, N=1, sc
 cams = T(synth.camera_sweep(6, -0.3, 0.3)); ws = torch.ones(1, 14, 512, device="cuda")
 single = ClipRenderer(G, cano, res, cams, ws, base_seed=11)
 a = [single._features(t).clone() for t in range(6)]
+aw = []
+for t in range(6):
+    single._features(t); aw.append(single._last_wsum.clone())
 b = [single._features(t).clone() for t in range(6)]
 print("same shell twice, sequential: max diff", max(float((x - y).abs().max()) for x, y in zip(a, b)))
 shells = [single] + [ClipRenderer(clone_generator_shell(G), cano, res, cams, ws, base_seed=11) for _ in range(2)]
 streams = [torch.cuda.Stream() for _ in range(3)]
 sr_in = torch.randn(1, 32, 128, 128, device="cuda")
-bad_frames = bad_rays = 0
+gm_a = torch.randn(4096, 4096, device="cuda", dtype=torch.float16); gm_b = torch.randn(4096, 4096, device="cuda", dtype=torch.float16); gm_c = [None] * 3
+cp_a = torch.randn(64 << 20, device="cuda"); cp_b = [torch.empty_like(cp_a) for _ in range(3)]
+if other == "f32sr":
+    for sh in shells:
+        sh.G.superresolution.block0.precision = "f32"; sh.G.superresolution.block1.precision = "f32"
+bad_frames = bad_rays = flag_rays = wsum_bad = 0
 for rep in range(reps):
-    out = [None] * 6
+    out = [None] * 6; flagged = [None] * 6
     for t in range(6):
         with torch.cuda.stream(streams[t % 3]):
             out[t] = shells[t % 3]._features(t).clone()
-            if with_sr: shells[t % 3].G.superresolution(sr_in[:, :3], sr_in, ws, noise_mode="none")
+            flagged[t] = shells[t % 3]._last_wsum
+            if other == "gemm":
+                for _ in range(3): gm_c[t % 3] = gm_a @ gm_b                       # rocBLAS / hipBLASLt MFMA kernels
+            elif other == "copy":
+                for _ in range(6): cp_b[t % 3].copy_(cp_a)                         # plain HBM traffic
+            elif other == "f32sr":
+                shells[t % 3].G.superresolution(sr_in[:, :3], sr_in, ws, noise_mode="none")
+            elif with_sr: shells[t % 3].G.superresolution(sr_in[:, :3], sr_in, ws, noise_mode="none")
     torch.cuda.synchronize()
     for t in range(6):
         dmap = (a[t] - out[t]).abs().amax(dim=1)[0]
         n = int((dmap > 0).sum())
+        nflag = int((flagged[t] > 500).sum()); flag_rays += nflag
+        if nflag and flag_rays <= 40:
+            fr = torch.nonzero(flagged[t].flatten() > 500).flatten().tolist()
+            print("  rep %d frame %d: in-kernel tap mismatch flagged on rays %s (lanes flagged: %s)" % (rep, t, [(r // 128, r % 128) for r in fr[:8]], [int(flagged[t].flatten()[r] // 1000) for r in fr[:8]]))
         if n:
+            dw = (aw[t] - flagged[t]).abs().flatten()
+            wsum_bad += int((dw > 0).sum())
+            if bad_frames < 3:
+                rr = torch.nonzero(dmap.flatten() > 0).flatten().tolist()[:4]
+                for r in rr:
+                    dch = (a[t] - out[t]).abs()[0, :, r // 128, r % 128]
+                    print("    ray (%d,%d): wsum seq %.6f conc %.6f | per-channel diff: %s" % (r // 128, r % 128, float(aw[t].flatten()[r]), float(flagged[t].flatten()[r]), " ".join("%.0e" % float(x) for x in dch.tolist())))
             bad_frames += 1; bad_rays += n
             if bad_frames <= 6:
                 rc = [(int(r), int(c)) for r, c in torch.nonzero(dmap > 0).tolist()]
                 print("  rep %d frame %d: %d rays differ %s max %.2e" % (rep, t, n, rc[:12], float(dmap.max())))
-print("lib %s  with_sr %s: %d of %d frames differ, %d rays in total" % (os.environ.get("R3D_LIB", "default")[-24:], with_sr, bad_frames, 6 * reps, bad_rays))
-if "bis256" in os.environ.get("R3D_LIB", "") or "bis2048" in os.environ.get("R3D_LIB", ""):
+print("rays with an in-kernel shared-vs-own tap mismatch flag: %d; differing rays whose weight sum also differs: %d" % (flag_rays, wsum_bad))
+print("lib %s  co-resident load %s: %d of %d frames differ, %d rays in total" % (os.environ.get("R3D_LIB", "default")[-24:], other or ("f16x3 SR" if with_sr else "none"), bad_frames, 6 * reps, bad_rays))
+if "ablate12288" in os.environ.get("R3D_LIB", ""):
     import ctypes
     from real3dportrait_amd import _lib
-    lib = ctypes.CDLL(_lib.LIB_PATH); buf = (ctypes.c_int * (16 + 16 * 32))(); lib.r3d_debug_read(buf)
-    print("tap mismatches recorded:", buf[0])
-    import struct
-    f = lambda i: struct.unpack("f", struct.pack("i", i))[0]
-    for sl in range(min(buf[0], 30)):
-        r = buf[16 + 16 * sl: 32 + 16 * sl]
-        print("  plane %d tap %d tid %3d (q %d) block %4d: idx dpp %9d own %9d | w dpp %.6f own %.6f | exec %08x%08x | src-lane value idx %9d w %.6f | pos %.4f %.4f %.4f" % (
-            r[0], r[1], r[2], r[12], r[11], r[3], r[4], f(r[5]), f(r[6]), r[8] & 0xffffffff, r[7] & 0xffffffff, r[9], f(r[10]), f(r[13]), f(r[14]), f(r[15])))
+    lib = ctypes.CDLL(_lib.LIB_PATH); buf = (ctypes.c_int * (64 + 64 * 24))(); lib.r3d_debug_read(buf)
+    print("flagged rays recorded:", buf[0], " (per lane: plane bits 0-2, bit 3 = position differs inside the quad, bits 4-6 coarse tile, 7-9 fine tile)")
+    for sl in range(min(buf[0], 24)):
+        w = [buf[64 + 64 * sl + l] for l in range(64)]
+        ray = max(x >> 8 for x in w)
+        print("  ray (%d,%d): " % (ray // 128, ray % 128) + " ".join("%d:%03x" % (l, w[l] & 0xff | ((w[l] & 0x300))) for l in range(64) if w[l] & 0x3ff))
