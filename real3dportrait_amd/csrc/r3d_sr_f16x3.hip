@@ -1414,6 +1414,10 @@ int sr_prepack_f16x3(int Cin, int Cout, const float* c0_w, const float* c1_w, vo
     return check_launch("sr_block_prepack");
 }
 
+// tuning switch (experiment): extra dynamic LDS per block of the two big kernels, e.g. 24576 -> one block per CU, which leaves room for a
+// ray-kernel block of another stream on the same CU
+static unsigned lds_pad() { static const unsigned v = getenv("R3D_SR_LDS_PAD") ? (unsigned)atoi(getenv("R3D_SR_LDS_PAD")) : 0u; return v; }
+
 static void launch_conv2(Conv2Args& a, int tiles, int N, hipStream_t st, bool mx = false)
 {
 
@@ -1428,7 +1432,7 @@ static void launch_conv2(Conv2Args& a, int tiles, int N, hipStream_t st, bool mx
         else hipLaunchKernelGGL((tconv_mfma_f16x3_kernel<2, 4, 2>), grid, dim3(256), 0, st, a);
     } else {                    // 8 waves x (64 couts x 64 px): 4 waves/SIMD at 2 blocks/CU
         if (kind == 0 && mx) hipLaunchKernelGGL((conv_mfma_f16x3_kernel<4, 2, 4, true>), grid, dim3(512), 0, st, a);
-        else if (kind == 0) hipLaunchKernelGGL((conv_mfma_f16x3_kernel<4, 2, 4>), grid, dim3(512), 0, st, a);
+        else if (kind == 0) hipLaunchKernelGGL((conv_mfma_f16x3_kernel<4, 2, 4>), grid, dim3(512), lds_pad(), st, a);
         else if (kind == 1) hipLaunchKernelGGL((conv1x1_mfma_f16x3_kernel<4, 2, 4>), grid, dim3(512), 0, st, a);
         else hipLaunchKernelGGL((tconv_mfma_f16x3_kernel<4, 2, 4>), grid, dim3(512), 0, st, a);
     }
@@ -1480,7 +1484,7 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
         if (mx && clamp >= 0.f) hipLaunchKernelGGL((upconv_fir_f16x3_kernel<true, true>), ugrid, dim3(256), 0, st, u);
         else if (mx) hipLaunchKernelGGL((upconv_fir_f16x3_kernel<false, true>), ugrid, dim3(256), 0, st, u);
         else if (clamp >= 0.f) hipLaunchKernelGGL(upconv_fir_f16x3_kernel<true>, ugrid, dim3(256), 0, st, u);
-        else hipLaunchKernelGGL(upconv_fir_f16x3_kernel<false>, ugrid, dim3(256), 0, st, u);
+        else hipLaunchKernelGGL(upconv_fir_f16x3_kernel<false>, ugrid, dim3(256), lds_pad(), st, u);
     } else if (up) {
         // ---- conv0: stride-2 transposed conv as 4 phases -> T (demodulated, fp32), then FIR + bias + lrelu -> SPLIT ----
         {

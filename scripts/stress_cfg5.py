@@ -6,6 +6,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from real3dportrait_amd import ImportanceRenderer, OSGDecoder, RaySampler, SynthesisBlock, synth
+from real3dportrait_amd.superresolution import chain_fold, const_bound
 N, R, Nc, Nf = 8, 256, 96, 96
 check = "--check" in sys.argv
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
@@ -34,9 +35,13 @@ def frame_batch():
     o, d = rs(cams[:, :16].view(-1, 4, 4), cams[:, 16:].view(-1, 3, 3), R)
     feat, depth, wsum, valid = ren(planes, dec, o, d, opts)
     fimg = feat.permute(0, 2, 1).reshape(N, 32, R, R).contiguous()
-    prep1 = b1.prepare(ws)
-    x, rgb = b0(fimg, fimg[:, :3].contiguous(), ws, noise_mode="none", _next=(prep1[1].view(torch.float32), b1.styles_stride()))
-    x, rgb = b1(x, rgb, ws, noise_mode="none", _prepared=prep1)
+    # the two-block flow of SuperresolutionHybrid8XDC.forward at 256^2 -> 1024^2: one range fold for both blocks, SPLIT hand-over
+    prep0, prep1 = b0.prepare(ws, fimg.device), b1.prepare(ws, fimg.device)
+    bx = const_bound(1.01, N, fimg.device)            # |feature image| <= 1.002 by construction
+    b0._depth_in, b1._depth_in = 0, 2
+    chain_fold([b0.chain_op(-1), b1.chain_op(0)], N, [bx])
+    x, rgb = b0(fimg, fimg[:, :3].contiguous(), ws, noise_mode="none", _prepared=prep0, _next=b1, _folded=True)
+    x, rgb = b1(x, rgb, ws, noise_mode="none", _prepared=prep1, _folded=True)
     return feat, depth, rgb
 
 for _ in range(2): out = frame_batch()
