@@ -289,6 +289,10 @@ __device__ __forceinline__ void plane_taps(float u, float v, int H, int W, int p
     t[1].idx = plane_base4 + (ra + xb) * 8; t[1].w = (vx1 && vy0) ? fx1 * fy0 : 0.0f;
     t[2].idx = plane_base4 + (rb + xa) * 8; t[2].w = (vx0 && vy1) ? fx0 * fy1 : 0.0f;
     t[3].idx = plane_base4 + (rb + xb) * 8; t[3].w = (vx1 && vy1) ? fx1 * fy1 : 0.0f;
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 65536)         // experiment build (wrong results): every tap inside one 16 KB window -> L1 hits: what is the gather latency worth?
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k].idx = plane_base4 + ((t[k].idx - plane_base4) & 0x3F8);
+#endif
 }
 
 template <int PLANES_IN_FLIGHT, bool TRI = false>
