@@ -90,7 +90,6 @@ class ClipRenderer:
         self.ws = ws
         self.base_seed = base_seed
         self.G.renderer.noise_mode = "hash"
-        self.G.renderer.need_depth = False          # only the frames leave this driver
 
     def planes_for(self, t):
         add = self.residuals[t % len(self.residuals)] if self.residuals else None
@@ -105,7 +104,12 @@ class ClipRenderer:
         G.renderer.seed = frame_seed(self.base_seed, t)
         cam = self.cameras[t: t + 1]
         o, d = G.ray_sampler(cam[:, :16].view(-1, 4, 4), cam[:, 16:25].view(-1, 3, 3), G.neural_rendering_resolution)
-        feat, depth, wsum, valid = G.renderer(self.planes_for(t), G.decoder, o, d, G.rendering_kwargs)
+        ren = G.renderer
+        keep, ren.need_depth = ren.need_depth, False          # only the frames leave this driver: no depth image, no clamp launch
+        try:
+            feat, depth, wsum, valid = ren(self.planes_for(t), G.decoder, o, d, G.rendering_kwargs)
+        finally:
+            ren.need_depth = keep                             # (G.synthesis() on the same generator still gets its depth)
         self._last_wsum = wsum          # (kept for the determinism probe)
         R = G.neural_rendering_resolution
         fimg = feat.permute(0, 2, 1).reshape(1, 32, R, R).contiguous()

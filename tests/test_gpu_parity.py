@@ -545,3 +545,7 @@ def test_multi_stream_pipeline_is_bit_identical(torch_cuda):
     pipe.sync(); torch.cuda.synchronize()
     assert torch.equal(ring, ref)
     assert int(ref.float().std()) > 5          # not a constant image
+    # the clip driver skips the depth image per call; the generator it wraps must still serve synthesis() with one
+    G._last_planes = cano + res[0]
+    out = G.synthesis(ws, cams[:1], use_cached_backbone=True)
+    assert out["image_depth"].shape == (1, 1, 128, 128) and torch.isfinite(out["image_depth"]).all()
