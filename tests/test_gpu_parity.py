@@ -510,7 +510,7 @@ def test_ray_kernel_is_independent_of_coresident_kernels(torch_cuda):
     sr_in = torch.randn(1, 32, 128, 128, device="cuda")
     torch.cuda.synchronize()
     bad = 0
-    for _ in range(30):
+    for _ in range(12):                          # (the failing variant differed in a quarter of its frames: 72 frames are plenty)
         out = [None] * 6
         for t in range(6):
             with torch.cuda.stream(streams[t % 3]):
@@ -518,7 +518,7 @@ def test_ray_kernel_is_independent_of_coresident_kernels(torch_cuda):
                 shells[t % 3].G.superresolution(sr_in[:, :3], sr_in, ws, noise_mode="none")
         torch.cuda.synchronize()
         bad += sum(int(not torch.equal(a, b)) for a, b in zip(ref, out))
-    assert bad == 0, "%d of 180 frames differ from the sequential render" % bad
+    assert bad == 0, "%d of 72 frames differ from the sequential render" % bad
 
 
 def test_multi_stream_pipeline_is_bit_identical(torch_cuda):
