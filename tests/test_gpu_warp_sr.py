@@ -58,3 +58,29 @@ def test_resize_blend_kernels_vs_torch():
     occ = torch.rand(2, 1, 40, 50, device="cuda")
     head = m.clone(); head[head > 0.9] = 1.0
     assert torch.equal(person_occlusion(m, occ, 0.9), (occ + head).clamp_(0, 1))
+
+
+def test_torso_frames_on_three_streams_are_bit_identical():
+    """bench.py's torso frame (to_plane_cnn -> planes -> rays -> fused SuperresolutionHybrid8XDC_Warp.forward) issued round-robin on three
+    streams, each with its own module shells, must equal the single-stream frames bit for bit."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from real3dportrait_amd.frames import clone_generator_shell
+    dev = torch.device("cuda", 0)
+    G, clip, dec, scene = bench.build_scene(torch, dev, n_frames=8)
+    frames = [bench.build_torso_frame(torch, dev, G)[0]] + [bench.build_torso_frame(torch, dev, clone_generator_shell(G))[0] for _ in range(2)]
+    ref = [frames[0](t).clone() for t in range(6)]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    for rep in range(3):
+        out = [None] * 6
+        for t in range(6):
+            with torch.cuda.stream(streams[t % 3]):
+                out[t] = frames[t % 3](t).clone()
+        torch.cuda.synchronize()
+        for t in range(6):
+            assert torch.equal(out[t], ref[t]), (rep, t, float((out[t] - ref[t]).abs().max()))
+    assert float(ref[0].std()) > 1e-3
