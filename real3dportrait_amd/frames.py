@@ -110,7 +110,6 @@ class ClipRenderer:
             feat, depth, wsum, valid = ren(self.planes_for(t), G.decoder, o, d, G.rendering_kwargs)
         finally:
             ren.need_depth = keep                             # (G.synthesis() on the same generator still gets its depth)
-        self._last_wsum = wsum          # (kept for the determinism probe)
         R = G.neural_rendering_resolution
         fimg = feat.permute(0, 2, 1).reshape(1, 32, R, R).contiguous()
         fimg._r3d_bound = const_bound(1.01, 1, fimg.device)

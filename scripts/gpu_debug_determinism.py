@@ -15,14 +15,17 @@ with torch.no_grad():
     G.decoder.net[0].weight.copy_(T(dec[0])); G.decoder.net[0].bias.copy_(T(dec[1])); G.decoder.net[2].weight.copy_(T(dec[2])); G.decoder.net[2].bias.copy_(T(dec[3]))
 cano = T(synth.synth_planes(3, N=1)); res = [T(synth.synth_planes(4 + i, N=1, scale=0.1)) for i in range(2)]
 cams = T(synth.camera_sweep(6, -0.3, 0.3)); ws = torch.ones(1, 14, 512, device="cuda")
-single = ClipRenderer(G, cano, res, cams, ws, base_seed=11)
+def watch(c):                       # keep the weight sums of the last render (experiment builds flag rays in them)
+    c.G.renderer.register_forward_hook(lambda m, inp, out: setattr(c, "_last_wsum", out[2]))
+    return c
+single = watch(ClipRenderer(G, cano, res, cams, ws, base_seed=11))
 a = [single._features(t).clone() for t in range(6)]
 aw = []
 for t in range(6):
     single._features(t); aw.append(single._last_wsum.clone())
 b = [single._features(t).clone() for t in range(6)]
 print("same shell twice, sequential: max diff", max(float((x - y).abs().max()) for x, y in zip(a, b)))
-shells = [single] + [ClipRenderer(clone_generator_shell(G), cano, res, cams, ws, base_seed=11) for _ in range(2)]
+shells = [single] + [watch(ClipRenderer(clone_generator_shell(G), cano, res, cams, ws, base_seed=11)) for _ in range(2)]
 streams = [torch.cuda.Stream() for _ in range(3)]
 sr_in = torch.randn(1, 32, 128, 128, device="cuda")
 gm_a = torch.randn(4096, 4096, device="cuda", dtype=torch.float16); gm_b = torch.randn(4096, 4096, device="cuda", dtype=torch.float16); gm_c = [None] * 3
