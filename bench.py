@@ -416,22 +416,18 @@ def main():
         lib.r3d_profile_configure(0)
         # the same frames round-robin on 3 streams (own module shells, as the head path's PipelinedClipRenderer): the under-filled launches of
         # the small layers (to_plane_cnn at 128^2 = 128 blocks for 512 block slots) and the kernel tails fill with other frames' work
-        from real3dportrait_amd.frames import clone_generator_shell
-        frames3 = [frame] + [build_torso_frame(torch, dev, clone_generator_shell(G))[0] for _ in range(2)]
-        streams3 = [torch.cuda.Stream() for _ in range(3)]
+        from real3dportrait_amd.frames import StreamPipeline, clone_generator_shell
+        pipe3 = StreamPipeline([frame] + [build_torso_frame(torch, dev, clone_generator_shell(G))[0] for _ in range(2)])
         for i in range(6):
-            with torch.cuda.stream(streams3[i % 3]):
-                frames3[i % 3](i)
-        torch.cuda.synchronize()
+            pipe3.submit(i)
+        pipe3.sync(); torch.cuda.synchronize()
         nb3 = 18
         t1 = time.perf_counter()
         for i in range(nb3):
-            streams3[i % 3].wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(streams3[i % 3]):
-                frames3[i % 3](i)
-        torch.cuda.synchronize()
+            pipe3.submit(i)
+        pipe3.sync(); torch.cuda.synchronize()
         t_frame3 = (time.perf_counter() - t1) / nb3
-        del frames3
+        del pipe3
         conv_ms = bd2["conv_mfma"] + bd2["upconv_fir"]
         out["torso_frame"] = {"what": "to_plane_cnn -> planes -> 128^2 rays x (48+48) -> fused SuperresolutionHybrid8XDC_Warp.forward (fuse mode v2) "
                                       "-> 512^2; cold encoders and the face-vid2vid warp net replaced by synthetic outputs",

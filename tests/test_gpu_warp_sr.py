@@ -68,19 +68,16 @@ def test_torso_frames_on_three_streams_are_bit_identical():
     import torch
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
-    from real3dportrait_amd.frames import clone_generator_shell
+    from real3dportrait_amd.frames import StreamPipeline, clone_generator_shell
     dev = torch.device("cuda", 0)
     G, clip, dec, scene = bench.build_scene(torch, dev, n_frames=8)
     frames = [bench.build_torso_frame(torch, dev, G)[0]] + [bench.build_torso_frame(torch, dev, clone_generator_shell(G))[0] for _ in range(2)]
     ref = [frames[0](t).clone() for t in range(6)]
     torch.cuda.synchronize()
-    streams = [torch.cuda.Stream() for _ in range(3)]
+    pipe = StreamPipeline(frames)
     for rep in range(3):
-        out = [None] * 6
-        for t in range(6):
-            with torch.cuda.stream(streams[t % 3]):
-                out[t] = frames[t % 3](t).clone()
-        torch.cuda.synchronize()
+        out = [pipe.submit(t) for t in range(6)]
+        pipe.sync(); torch.cuda.synchronize()
         for t in range(6):
             assert torch.equal(out[t], ref[t]), (rep, t, float((out[t] - ref[t]).abs().max()))
     assert float(ref[0].std()) > 1e-3
