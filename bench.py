@@ -421,6 +421,18 @@ def main():
             alt["R512_48+%d_fps" % nf] = round(5 / (time.perf_counter() - t1), 2)
         out["alt_neural_render_512"] = alt
 
+        # the same W + K measurement from an idle (cold-clock) GPU, i.e. without the device warm-up: what the first K frames after a pause cost
+        if pipe is not None and args.device_warmup_ms > 0:
+            torch.cuda.synchronize(); time.sleep(0.25)
+            for i in range(max(W, args.streams)):
+                step(i % K)
+            pipe.sync(); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(K):
+                step(i)
+            pipe.sync(); torch.cuda.synchronize()
+            out["value_cold_start"] = round(K / (time.perf_counter() - t1), 2)
+
     # ---- BASELINE config 4 surrogate: the per-frame hot path of the shipped torso model (extra, rank 0 of a 1-GPU run) ----
     if rank == 0 and world == 1 and not args.no_extras:
         frame, tf_flops = build_torso_frame(torch, dev, G)
