@@ -415,7 +415,13 @@ __device__ __forceinline__ void gather_sample(const float4* __restrict__ planes4
 #endif
             float4 lo[4], hi[4];
 #pragma unroll
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 64)              // experiment build (wrong results): half the load instructions
+            for (int i = 0; i < 4; ++i) { lo[i] = pl[t[i].idx]; hi[i] = lo[i]; }
+#elif defined(R3D_ABLATE) && (R3D_ABLATE & 128)           // experiment build: the second load re-reads the first one's 16 bytes
+            for (int i = 0; i < 4; ++i) { lo[i] = pl[t[i].idx]; int j = t[i].idx; asm volatile("" : "+v"(j)); hi[i] = pl[j]; }
+#else
             for (int i = 0; i < 4; ++i) { lo[i] = pl[t[i].idx]; hi[i] = pl[t[i].idx + 1]; }
+#endif
 #pragma unroll
             for (int c = 0; c < 8; ++c) acc[p][c] = 0.0f;
 #pragma unroll
@@ -652,7 +658,11 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, s = lane & 15;          // MFMA / per-sample mapping
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 256)             // experiment build (wrong results): round 1's gather mapping, the 4 lanes of a sample 16 lanes apart
+    const int gq = lane >> 4, gs = lane & 15;
+#else
     const int gq = gather_q(lane), gs = gather_s(lane);   // gather mapping
+#endif
     RayLds& L = rl[wave];
     XchLds& E = xch[wave];
     const int Nc = a.Nc, Nf = a.Nf, S = Nc + Nf;
