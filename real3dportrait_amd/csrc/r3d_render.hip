@@ -380,9 +380,21 @@ __device__ __forceinline__ void gather_sample(const float4* __restrict__ planes4
         // scripts/gpu_debug_determinism.py)
         const float4* __restrict__ pl = planes4 + 2 * q;            // this lane's 8 channels of a texel
 #if defined(R3D_ABLATE) && (R3D_ABLATE & 4096)           // experiment build: the quad-shared taps described above
-        const int pq = q < 2 ? q : 2;
+        int qv = q;
+#if (R3D_ABLATE & 131072)                                // ... with the lane predicates recomputed per call (no long-lived SGPR lane masks / SGPR spills of them)
+        asm volatile("" : "+v"(qv));
+#endif
+        const int pq = qv < 2 ? qv : 2;
         Tap tq[4];
+#if (R3D_ABLATE & 262144)                                // ... with bit selects on per-lane VGPR masks instead of v_cndmask on SGPR lane masks
+        int m0 = (pq - 1) >> 31, m1 = -(pq & 1), m2 = -(pq >> 1);
+        asm volatile("" : "+v"(m0), "+v"(m1), "+v"(m2));
+        const float uq = __int_as_float((__float_as_int(qz) & m2) | (__float_as_int(qx) & ~m2));
+        const float vq = __int_as_float((__float_as_int(qy) & m0) | (__float_as_int(qz) & m1) | (__float_as_int(qx) & m2));
+        plane_taps(uq, vq, H, W, pq * HW8, tq);
+#else
         plane_taps(pq == 2 ? qz : qx, pq == 0 ? qy : (pq == 1 ? qz : qx), H, W, pq * HW8, tq);
+#endif
 #endif
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
@@ -655,6 +667,9 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
 
     stage_decoder(dec, a.w1, a.b1, a.w2, a.b2);
     __syncthreads();
+#if defined(R3D_ABLATE) && (R3D_ABLATE & 524288)          // experiment build: ray waves win the issue arbitration against co-resident waves
+    __builtin_amdgcn_s_setprio(3);
+#endif
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, s = lane & 15;          // MFMA / per-sample mapping

@@ -16,21 +16,9 @@ they are).  Compared with running the reference forward over patched sub-modules
 The face-vid2vid warp network `torso_model` is a cold-ish PyTorch encoder and is called as is (out of scope).
 """
 import torch
-import torch.nn.functional as F
 
 from . import _lib
-from .superresolution import (_BoundMeter, _f32c, _keep_tags, _tag, blend_cat, bound_of, chain_fold, const_bound)
-
-
-def resize_bilinear(x, size, antialias=True):
-    """F.interpolate(x, size=size, mode='bilinear', align_corners=False, antialias=antialias) on the HIP kernel."""
-    lib = _lib.load()
-    x = _f32c(x)
-    N, C, H, W = x.shape
-    OH, OW = size
-    y = torch.empty(N, C, OH, OW, device=x.device, dtype=torch.float32)
-    _lib.check(lib.r3d_resize_bilinear(_lib.ptr(x), N * C, H, W, _lib.ptr(y), OH, OW, int(bool(antialias)), _lib.stream_ptr()), "resize_bilinear")
-    return y
+from .superresolution import (_BoundMeter, _f32c, _keep_tags, _tag, blend_cat, bound_of, chain_fold, const_bound, resize_bilinear)
 
 
 def blend(a, b, mask):
@@ -94,14 +82,34 @@ def forward_v2(self, rgb, x, ws, ref_torso_rgb, ref_bg_rgb, weights_img, segmap,
     hp = S.hparams
     if not hp.get("weight_fuse", True) or hp.get("htbsr_head_weight_fuse_mode") != "v2":
         raise NotImplementedError("fused HIP forward covers weight_fuse=True, htbsr_head_weight_fuse_mode='v2' (the shipped torso model)")
+    if self.block0.precision == "f32":
+        # the exact-f32 kernels have no channel-blocked hand-off / epilogue measurements: run the reference's own forward over the
+        # patched sub-modules (patch_model keeps it), or refuse for the mirror class that has none
+        ref_forward = getattr(self, "_r3d_reference_forward", None)
+        if ref_forward is None:
+            raise NotImplementedError("the fused SuperresolutionHybrid8XDC_Warp forward needs SR precision 'f16x3' (got 'f32')")
+        return ref_forward(rgb, x, ws, ref_torso_rgb, ref_bg_rgb, weights_img, segmap, kp_s, kp_d, target_torso_mask=target_torso_mask,
+                           **block_kwargs)
+    # block0 / head_torso_block / block1 are shared with the reference's other entry points (infer_forward_stage1/2,
+    # sr_with_ref.py:165-214, call self.block0(x, rgb, ws) and expect NCHW x): the hand-off formats are set for this call only
+    b0, b1, hb = self.block0, self.block1, self.head_torso_block
+    saved = [(m, m.out_format, m.return_x) for m in (b0, hb, b1)]
+    try:
+        return _forward_v2(self, S, rgb, x, ws, ref_torso_rgb, ref_bg_rgb, weights_img, segmap, kp_s, kp_d, target_torso_mask, block_kwargs)
+    finally:
+        for m, fmt, rx in saved:
+            m.out_format, m.return_x = fmt, rx
+
+
+def _forward_v2(self, S, rgb, x, ws, ref_torso_rgb, ref_bg_rgb, weights_img, segmap, kp_s, kp_d, target_torso_mask, block_kwargs):
+    hp = S.hparams
     aa = self.sr_antialias
     weights_img = weights_img.detach()
     N, dev = rgb.shape[0], rgb.device
     ws3 = S.c_ws3.get(ws, lambda w: w[:, -1:, :].expand(N, 3, -1).contiguous())                      # :69
     if x.shape[-1] != self.input_resolution:                                                           # :71-75, cold
         sz = (self.input_resolution, self.input_resolution)
-        x = F.interpolate(x, size=sz, mode="bilinear", align_corners=False, antialias=aa)
-        rgb = F.interpolate(rgb, size=sz, mode="bilinear", align_corners=False, antialias=aa)
+        x, rgb = resize_bilinear(x, sz, aa), resize_bilinear(rgb, sz, aa)
     rgb_256 = resize_bilinear(rgb, (256, 256), aa)                                                      # :77
     weights_256 = resize_bilinear(weights_img, (256, 256), aa)                                          # :78
     ref_torso_rgb_256 = S.c_torso256.get(ref_torso_rgb, lambda t: resize_bilinear(t, (256, 256), aa))  # :80 (clip constant)

@@ -26,7 +26,6 @@ import os
 import numpy as np
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import _lib
 from .volumetric_rendering import _FC, _f32c
@@ -73,6 +72,9 @@ def const_bound(value, N, device):
     t = _CONST_BOUNDS.get(key)
     if t is None:
         t = torch.full((N,), float(value), device=device, dtype=torch.float32)
+        # The tensor is shared by every stream of the process (PipelinedClipRenderer / StreamPipeline shells read it in r3d_chain_fold on
+        # their own streams, ordered only against the caller's stream): finish the fill before anybody can see it.  Once per key.
+        torch.cuda.current_stream(t.device).synchronize()
         t._r3d_const = True          # never written again: a fold whose only inputs are such bounds and cached styles can be reused
         _CONST_BOUNDS[key] = t
     return t
@@ -268,7 +270,8 @@ class SynthesisBlock(nn.Module):
         """Device view [N] of the bound on this block's output x written by the last fold (valid until the next fold)."""
         lib = _lib.load()
         off = int(lib.r3d_sr_block_bound_offset(self.in_channels, self.out_channels))
-        return self._styles.view(torch.float32).as_strided((N,), (self.styles_stride(),), off)
+        # N > 1: the per-sample bounds sit one styles record apart; consumers (r3d_chain_fold ext bounds) read a dense float[N]
+        return self._styles.view(torch.float32).as_strided((N,), (self.styles_stride(),), off).contiguous()
 
     def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, noise_mode="random",
                 _prepared=None, _next=None, _folded=False, _u8_out=None, _need_img=True, _x_absmax=None, **layer_kwargs):
@@ -392,7 +395,7 @@ class Conv2d(nn.Module):
     def bound_out(self, N):
         lib = _lib.load()
         off = int(lib.r3d_conv_scales_bound_offset(self.in_channels, self.out_channels))
-        return self._scales.view(torch.float32).as_strided((N,), (self.in_scale()[1],), off)
+        return self._scales.view(torch.float32).as_strided((N,), (self.in_scale()[1],), off).contiguous()     # dense float[N] (a copy for N > 1)
 
     @staticmethod
     def _shape(x, x_fmt):
@@ -471,6 +474,18 @@ def upsample2x_bilinear(x, out_format="split", _next=None):
         y._r3d_for = _next
     elif bx is not None:
         _tag(y, bx, dx)            # a convex combination does not raise the bound
+    return y
+
+
+def resize_bilinear(x, size, antialias=True):
+    """F.interpolate(x, size=size, mode='bilinear', align_corners=False, antialias=antialias) on the HIP kernel (ATen's separable
+    antialiased weights; superresolution.py:351-355, sr_with_ref.py:71-82,110)."""
+    lib = _lib.load()
+    x = _f32c(x)
+    N, C, H, W = x.shape
+    OH, OW = size
+    y = torch.empty(N, C, OH, OW, device=x.device, dtype=torch.float32)
+    _lib.check(lib.r3d_resize_bilinear(_lib.ptr(x), N * C, H, W, _lib.ptr(y), OH, OW, int(bool(antialias)), _lib.stream_ptr()), "resize_bilinear")
     return y
 
 
@@ -671,11 +686,9 @@ class SuperresolutionHybrid8XDC(nn.Module):
         into the last block's toRGB kernel (the conversion real3d_infer.py:472,518-522 does per frame); with
         _need_img=False the fp32 image is not materialised and None is returned."""
         ws3 = self._ws_last3(ws)
-        if x.shape[-1] != self.input_resolution:      # cold path, same ATen op as the reference (:351-355)
-            x = F.interpolate(x, size=(self.input_resolution, self.input_resolution), mode="bilinear",
-                              align_corners=False, antialias=self.sr_antialias)
-            rgb = F.interpolate(rgb, size=(self.input_resolution, self.input_resolution), mode="bilinear",
-                                align_corners=False, antialias=self.sr_antialias)
+        if x.shape[-1] != self.input_resolution:      # :351-355: any other neural-rendering resolution is resampled to 128^2 first
+            sz = (self.input_resolution, self.input_resolution)
+            x, rgb = resize_bilinear(x, sz, self.sr_antialias), resize_bilinear(rgb, sz, self.sr_antialias)
         b0, b1 = self.block0, self.block1
         b1.precision = b0.precision
         prep0 = b0.prepare(ws3, x.device, ws_key=ws)

@@ -64,8 +64,13 @@ class TriPlaneGenerator(nn.Module):
         """triplane.py:73-88: the mapping network lives in the (cold, PyTorch) tri-plane producer."""
         if self.backbone is None or not hasattr(self.backbone, "mapping"):
             raise RuntimeError("mapping() needs a backbone with a mapping network (the StyleGAN2 producer is a cold encoder, out of scope)")
-        return self.backbone.mapping(z, camera * self.rendering_kwargs.get("c_scale", 0), truncation_psi=truncation_psi,
-                                     truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+        ws = self.backbone.mapping(z, camera * self.rendering_kwargs.get("c_scale", 0), truncation_psi=truncation_psi,
+                                   truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+        if self.hparams.get("gen_cond_mode", "none") == "mapping":        # triplane.py:85-87
+            d_ws = self.backbone.cond_mapping(cond, None, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff,
+                                              update_emas=update_emas)
+            ws = ws * 0.5 + d_ws * 0.5
+        return ws
 
     def _planes(self, ws, update_emas, cache_backbone, use_cached_backbone, synthesis_kwargs):
         if use_cached_backbone and self._last_planes is not None:
@@ -205,8 +210,12 @@ def patch_model(model, fuse_warp_sr=True):
                 and type(getattr(sr, "head_torso_block", None)).__name__ == "SynthesisBlockNoUp"
                 and type(sr.head_torso_block).__module__.startswith("real3dportrait_amd")):
             from . import sr_with_ref
+            # snapshot of the keys the fused forward reads -- only those that are SET (absent keys keep the reference's defaults, e.g.
+            # torso_model_version 'v1', sr_with_ref.py:84); the reference reads its global hparams at call time, so patch_model must
+            # run after set_hparams()
             sr._r3d_state = sr_with_ref.WarpSRState(
-                {k: hp.get(k) for k in ("weight_fuse", "htbsr_head_weight_fuse_mode", "htbsr_head_threshold", "torso_model_version")})
+                {k: hp[k] for k in ("weight_fuse", "htbsr_head_weight_fuse_mode", "htbsr_head_threshold", "torso_model_version") if k in hp})
+            sr._r3d_reference_forward = sr.forward           # the exact-f32 precision runs the reference forward over the patched sub-modules
             sr.forward = types.MethodType(sr_with_ref.forward_v2, sr)
     for owner in (getattr(model, "secc_img2plane_backbone", None), getattr(model, "img2plane_backbone", None)):
         _patch_sequential(owner, "to_plane_cnn", dev)       # per-frame plane producer tail (segformer.py:691-700)

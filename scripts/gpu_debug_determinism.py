@@ -7,7 +7,14 @@ from real3dportrait_amd import TriPlaneGenerator, synth
 from real3dportrait_amd.frames import ClipRenderer, clone_generator_shell
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 with_sr = (sys.argv[2] != "0") if len(sys.argv) > 2 else True
-other = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] not in ("0", "1") else None      # co-resident load instead of the SR: gemm | copy | f32sr
+other = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] not in ("0", "1") else None      # co-resident load instead of the SR: gemm | copy | f32sr | agg:<mode>[:iters[:grid]]
+agg = None
+if other and other.startswith("agg:"):      # synthetic load assembled from feature bits (scripts/probes/aggressor.hip)
+    import ctypes
+    f = other.split(":")
+    agg_mode, agg_iters, agg_grid = int(f[1]), int(f[2]) if len(f) > 2 else 150, int(f[3]) if len(f) > 3 else 1024
+    agg = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "probes", "bin", "libaggressor.so"))
+    agg.agg_launch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
 G = TriPlaneGenerator().cuda().eval()
 dec = synth.synth_decoder(3, sigma_bias=4.0)
@@ -30,6 +37,9 @@ streams = [torch.cuda.Stream() for _ in range(3)]
 sr_in = torch.randn(1, 32, 128, 128, device="cuda")
 gm_a = torch.randn(4096, 4096, device="cuda", dtype=torch.float16); gm_b = torch.randn(4096, 4096, device="cuda", dtype=torch.float16); gm_c = [None] * 3
 cp_a = torch.randn(64 << 20, device="cuda"); cp_b = [torch.empty_like(cp_a) for _ in range(3)]
+if agg is not None:
+    agg_src = torch.randn(1 << 18, 8, device="cuda").mul_(0.01).to(torch.float16).contiguous()                               # 2^18 uint4
+    agg_out = [torch.empty(agg_grid * 512, device="cuda") for _ in range(3)]
 if other == "f32sr":
     for sh in shells:
         sh.G.superresolution.block0.precision = "f32"; sh.G.superresolution.block1.precision = "f32"
@@ -46,6 +56,10 @@ for rep in range(reps):
                 for _ in range(6): cp_b[t % 3].copy_(cp_a)                         # plain HBM traffic
             elif other == "f32sr":
                 shells[t % 3].G.superresolution(sr_in[:, :3], sr_in, ws, noise_mode="none")
+            elif agg is not None:
+                for _ in range(3):
+                    rc = agg.agg_launch(agg_mode, agg_src.data_ptr(), 1 << 18, agg_out[t % 3].data_ptr(), agg_grid, agg_iters, torch.cuda.current_stream().cuda_stream)
+                    assert rc == 0, rc
             elif with_sr: shells[t % 3].G.superresolution(sr_in[:, :3], sr_in, ws, noise_mode="none")
     torch.cuda.synchronize()
     for t in range(6):

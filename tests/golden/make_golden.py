@@ -440,9 +440,71 @@ def warp_sr_case(name):
     print(name, out.shape, float(np.abs(out).mean()))
 
 
+def render_r512_case(name, Nf):
+    """BASELINE configs[1] read literally: a 512x512 NEURAL render (R = 512) with 48 (+48) depth samples on full-size planes.  The
+    reference renders all 262 144 rays; the fixture keeps the rays of every 8th row and column (the global couplings -- min / max of
+    the valid ray starts, the global depth clamp -- still come from the full render).  Planes, decoder and sampling noise are
+    regenerated from their seeds by the tests (50 MB of noise is not stored).  With Nf = 48 the feature image is also sent through
+    the reference SuperresolutionHybrid8XDC, whose first step resamples any R != 128 input to 128^2 (superresolution.py:351-355)."""
+    R, Nc, seed = 512, 48, 61
+    planes = synth.synth_planes(seed, N=1)
+    cams = np.asarray([synth.look_at_camera(0.12, -0.07)], np.float32).reshape(-1, 25)
+    N, M = 1, R * R
+    dec_np = synth.synth_decoder(seed + 1, sigma_bias=3.0)
+    dec = make_decoder(dec_np)
+    noise_c = synth.synth_noise(seed + 2, (N, M, Nc, 1), stream=7)
+    u_f = synth.synth_noise(seed + 2, (N * M, max(Nf, 1)), stream=8)[:, :Nf].copy() if Nf > 0 else np.zeros((N * M, 0), np.float32)
+    cam_t = torch.from_numpy(cams)
+    with torch.no_grad():
+        o, d = RaySampler()(cam_t[:, :16].view(-1, 4, 4), cam_t[:, 16:].view(-1, 3, 3), R)
+        ren = ImportanceRenderer(hp={"enable_rescale_plane_regulation": False, "triplane_feature_type": "triplane"}).eval()
+        with injected_noise(noise_c, u_f) as st:
+            rgb, depth, wsum, valid = ren(torch.from_numpy(planes), dec, o, d, opts(Nc, Nf))
+    idx = (np.arange(0, R, 8)[:, None] * R + np.arange(0, R, 8)[None, :]).reshape(-1)
+    out = dict(cams=cams, R=R, Nc=Nc, Nf=Nf, seed=seed, ray_index=idx.astype(np.int64),
+               rgb=rgb.numpy()[:, idx], depth=depth.numpy()[:, idx], wsum=wsum.numpy()[:, idx], valid=valid.numpy()[:, idx],
+               valid_frac=np.float64(valid.float().mean()), depth_min=np.float64(depth.min()), depth_max=np.float64(depth.max()))
+    if Nf > 0:
+        params = synth.synth_sr_params(seed + 3)
+        sr = SuperresolutionHybrid8XDC(channels=32, img_resolution=512, sr_num_fp16_res=0, sr_antialias=True,
+                                       channel_base=32768, channel_max=512, fused_modconv_default="inference_only").eval()
+        load_block(sr.block0, params[0]); load_block(sr.block1, params[1])
+        feat = rgb.permute(0, 2, 1).reshape(1, 32, R, R).contiguous()
+        with torch.no_grad():
+            img = sr(feat[:, :3], feat, torch.ones(1, 14, 512), noise_mode="none").numpy()
+        out.update(sr_seed=seed + 3, sr_strided=img[:, :, ::4, ::4], sr_corner=img[:, :, :96, :96])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(name, "rgb", rgb.shape, "valid frac", float(valid.float().mean()), "wsum mean", float(wsum.mean()))
+
+
+def sr_resize_case(name):
+    """SuperresolutionHybrid8XDC fed with a neural render that is NOT 128^2: the reference first resamples x and rgb to 128^2 with the
+    antialiased bilinear filter (superresolution.py:351-355): one down-sampling (192^2) and one up-sampling (80^2) input."""
+    seed = 71
+    params = synth.synth_sr_params(seed)
+    sr = SuperresolutionHybrid8XDC(channels=32, img_resolution=512, sr_num_fp16_res=0, sr_antialias=True,
+                                   channel_base=32768, channel_max=512, fused_modconv_default="inference_only").eval()
+    load_block(sr.block0, params[0]); load_block(sr.block1, params[1])
+    out = dict(seed=seed)
+    for tag, r in (("down", 192), ("up", 80)):
+        x = synth.hash_unitvar(seed, (1, 32, r, r), stream=3 if tag == "down" else 4)
+        with torch.no_grad():
+            img = sr(torch.from_numpy(x[:, :3].copy()), torch.from_numpy(x), torch.ones(1, 14, 512), noise_mode="none").numpy()
+        out["r_" + tag] = r
+        out["strided_" + tag] = img[:, :, ::4, ::4]
+        out["corner_" + tag] = img[:, :, :64, :64]
+        print(name, tag, img.shape, float(np.abs(img).mean()))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+
+
 def main():
     which = sys.argv[1:] or ["render", "run_model", "sr_small", "sr_full", "synthesis", "fusion", "toplane", "sr_cfg5", "fusion_full",
-                             "toplane_full", "synthesis_mask", "warp_sr"]
+                             "toplane_full", "synthesis_mask", "warp_sr", "render_r512", "sr_resize"]
+    if "render_r512" in which:
+        render_r512_case("render_g_r512_48p0", 0)
+        render_r512_case("render_h_r512_48p48_sr", 48)
+    if "sr_resize" in which:
+        sr_resize_case("sr_resize_a")
     if "warp_sr" in which:
         warp_sr_case("warp_sr_a")
     if "sr_cfg5" in which:
