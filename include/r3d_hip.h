@@ -50,7 +50,12 @@ const char* r3d_last_error(void);
  * [N,3,C*depth,H,W] with channel c*depth + d (the reference's .view(N*3, C, D, H, W)) -> [N,3,depth,H,W,C]. */
 #define R3D_SECC_PLANE_FLIPS 53
 int r3d_planes_to_nhwc(const float* planes_nchw, const float* add_nchw, float* planes_nhwc,
-                       int N, int C, int H, int W, int depth, int add_flip, r3d_stream_t stream);
+                       int N, int C, int H, int W, int depth, int add_flip, float* absmax_partials, int* n_partials,
+                       r3d_stream_t stream);
+/* absmax_partials (may be NULL): device float[r3d_planes_absmax_partials(...)] that receives one max|value| per thread block of the
+ * layout pass (no extra pass over the 25 MB, no atomics); *n_partials (host int) = how many were written.  They feed the renderer's
+ * fp16 range fold (r3d_render_forward / r3d_run_model `plane_absmax`). */
+size_t r3d_planes_absmax_partials(int N, int C, int H, int W, int depth);
 
 /* --- A1 ray generation --------------------------------------------------------------------------
  * Replaces RaySampler.forward(cam2world[N,4,4], intrinsics[N,3,3], resolution)
@@ -81,7 +86,13 @@ int r3d_raygen(const float* c2w, const float* intrinsics, int N, int R,
  *                feature image TriPlaneGenerator.synthesis builds from it with permute(0,2,1).reshape(N,32,R,R), triplane.py:121-122,
  *                written directly so that no transposition pass runs per frame)
  *   depth [N,M] or NULL (no depth image: the global-range clamp launch is skipped), wsum [N,M], valid [N,M] (1 byte, is_ray_valid)
- *   workspace    r3d_render_workspace_bytes() bytes of device scratch
+ *   plane_absmax device float[n_plane_absmax] whose maximum bounds |planes_nhwc| (the partials of r3d_planes_to_nhwc), or NULL / 0: the
+ *                bound is then measured here (one extra pass over the planes).  fp16 range management of the decoder: the MLP runs on
+ *                the f16 matrix pipe with fp32 operands split into fp16 hi + lo; one small launch per call (decoder_fold_kernel) derives
+ *                exact power-of-two factors from this bound and from the weights (features * 2^b against W1 * 2^-b, and -- only when a
+ *                bound would reach 2^15 -- 2^c on the hidden values / 2^d on the colour rows), so that the result equals the reference's
+ *                unbounded fp32 evaluation for any magnitude of planes and weights whose pre-activations fit fp32
+ *   workspace    r3d_render_workspace_bytes() bytes of device scratch, 64-byte aligned
  */
 size_t r3d_render_workspace_bytes(int N, int M, int Nc, int Nf);
 int r3d_render_forward(const float* planes_nhwc, int N, int H, int W, int triplane_depth,
@@ -90,6 +101,7 @@ int r3d_render_forward(const float* planes_nhwc, int N, int H, int W, int tripla
                        int Nc, int Nf, float box_warp, int white_back,
                        const float* noise_c, const float* u_f, uint64_t seed,
                        float* rgb, int rgb_channel_major, float* depth, float* wsum, uint8_t* valid,
+                       const float* plane_absmax, int n_plane_absmax,
                        void* workspace, size_t workspace_bytes, r3d_stream_t stream);
 
 /* Replaces ImportanceRenderer.run_model(planes, decoder, sample_coordinates, sample_directions, options)
@@ -98,7 +110,10 @@ int r3d_render_forward(const float* planes_nhwc, int N, int H, int W, int tripla
 int r3d_run_model(const float* planes_nhwc, int N, int H, int W, int triplane_depth,
                   const float* w1, const float* b1, const float* w2, const float* b2,
                   const float* coords, int npts, float box_warp,
-                  float* rgb, float* sigma, r3d_stream_t stream);
+                  float* rgb, float* sigma, const float* plane_absmax, int n_plane_absmax,
+                  void* workspace, size_t workspace_bytes, r3d_stream_t stream);
+/* plane_absmax / n_plane_absmax: as for r3d_render_forward; workspace: r3d_run_model_workspace_bytes() bytes, 16-byte aligned */
+size_t r3d_run_model_workspace_bytes(void);
 
 /* --- A12..A14 super-resolution ------------------------------------------------------------------
  * One StyleGAN2 SynthesisBlock (architecture 'skip', up=2, fp32, eval, noise_mode 'none'):

@@ -20,14 +20,16 @@ P = c_void_p
 SIGNATURES = {
     "r3d_version": (c_int, []),
     "r3d_last_error": (ctypes.c_char_p, []),
-    "r3d_planes_to_nhwc": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "r3d_planes_to_nhwc": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, ctypes.POINTER(c_int), P]),
+    "r3d_planes_absmax_partials": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "r3d_blend_cat_to_split": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, P, P, c_size_t, P]),
     "r3d_upsample2x_bilinear": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P, c_size_t, P]),
     "r3d_raygen": (c_int, [P, P, c_int, c_int, P, P, P]),
     "r3d_render_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "r3d_render_forward": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_int,
-                                   P, P, c_uint64, P, c_int, P, P, P, P, c_size_t, P]),
-    "r3d_run_model": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, c_float, P, P, P]),
+                                   P, P, c_uint64, P, c_int, P, P, P, P, c_int, P, c_size_t, P]),
+    "r3d_run_model": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, c_float, P, P, P, c_int, P, c_size_t, P]),
+    "r3d_run_model_workspace_bytes": (c_size_t, []),
     "r3d_sr_block_prepacked_bytes": (c_size_t, [c_int, c_int]),
     "r3d_sr_block_styles_bytes": (c_size_t, [c_int, c_int, c_int]),
     "r3d_sr_block_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),

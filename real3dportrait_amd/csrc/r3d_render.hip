@@ -36,10 +36,28 @@ static constexpr int kRayArr = kMaxSamples + 8;
 // its conv output, modules/real3d/segformer.py:722-728, fused with the cano + secc add of secc_img2plane.py:76-77)
 // -------------------------------------------------------------------------------------------------
 // depth D > 1 (tri-grids, renderer.py:78-89): source channel c*D + d of plane p goes to slice d: [N*3][D][H*W][C]
+// absmax_part (may be NULL): one float per block = max |value written| of the block (no atomics, no init); the decoder fold
+// (decoder_fold_kernel) reduces them to the bound the fp16 split of the gathered features is scaled with.
+__device__ __forceinline__ void block_absmax_store(float m, float* __restrict__ absmax_part, int block_linear, float* red)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
+    const int tid = threadIdx.y * blockDim.x + threadIdx.x, nw = (blockDim.x * blockDim.y) >> 6;
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+        float r = red[0];
+        for (int w = 1; w < nw; ++w) r = fmaxf(r, red[w]);
+        absmax_part[block_linear] = r;
+    }
+}
+
 __global__ void planes_to_nhwc_kernel(const float* __restrict__ src, const float* __restrict__ add,
-                                      float* __restrict__ dst, int C, int HW, int W, int add_flip, int D)
+                                      float* __restrict__ dst, int C, int HW, int W, int add_flip, int D, float* __restrict__ absmax_part)
 {
     __shared__ float tile[32][33];
+    __shared__ float red[4];
+    float amax = 0.f;
     const int p = blockIdx.z / D, dsl = blockIdx.z - p * D;
     const int fl = (add_flip >> (2 * (p % 3))) & 3;
     const int hw0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
@@ -62,6 +80,7 @@ __global__ void planes_to_nhwc_kernel(const float* __restrict__ src, const float
             }
         }
         tile[j][tx] = v;
+        amax = fmaxf(amax, fabsf(v));
     }
     __syncthreads();
     float* d = dst + (size_t)blockIdx.z * HW * C;
@@ -69,15 +88,18 @@ __global__ void planes_to_nhwc_kernel(const float* __restrict__ src, const float
         const int hw = hw0 + j, c = c0 + tx;
         if (c < C && hw < HW) d[(size_t)hw * C + c] = tile[tx][j];
     }
+    if (absmax_part) block_absmax_store(amax, absmax_part, (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x, red);
 }
 
 // The per-frame case (C = 32, no depth, no flips, HW a multiple of 64): 32 channels x 64 pixels per block, 16-byte loads along the
 // pixels, 16-byte stores along the channels (8 lanes = one pixel's 128 bytes), one LDS transposition in between.  The general
 // kernel above moves 4 bytes per lane and instruction: 26 us per frame for 75 MB, this one is bound by the HBM traffic.
 __global__ __launch_bounds__(256) void planes_to_nhwc32_kernel(const float* __restrict__ src, const float* __restrict__ add,
-                                                              float* __restrict__ dst, int HW)
+                                                              float* __restrict__ dst, int HW, float* __restrict__ absmax_part)
 {
     __shared__ float tile[32][68];                  // row stride 68 floats: 16-byte aligned rows, column reads spread over the banks
+    __shared__ float red[4];
+    float amax = 0.f;
     const int p = blockIdx.y, hw0 = blockIdx.x * 64, tid = threadIdx.x;
     const float* s = src + (size_t)p * 32 * HW + hw0;
     const float* a = add ? add + (size_t)p * 32 * HW + hw0 : nullptr;
@@ -90,6 +112,7 @@ __global__ __launch_bounds__(256) void planes_to_nhwc32_kernel(const float* __re
             v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
         }
         *reinterpret_cast<float4*>(&tile[c][h4]) = v;
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
     }
     __syncthreads();
     float* d = dst + ((size_t)p * HW + hw0) * 32;
@@ -98,6 +121,20 @@ __global__ __launch_bounds__(256) void planes_to_nhwc32_kernel(const float* __re
         const int hw = (tid >> 3) + 32 * j, c4 = (tid & 7) * 4;
         *reinterpret_cast<float4*>(d + (size_t)hw * 32 + c4) = make_float4(tile[c4][hw], tile[c4 + 1][hw], tile[c4 + 2][hw], tile[c4 + 3][hw]);
     }
+    if (absmax_part) block_absmax_store(amax, absmax_part, blockIdx.y * gridDim.x + blockIdx.x, red);
+}
+
+// max |x| of a channel-last plane tensor that arrives without partials (a caller of the raw C ABI that did its own layout)
+static constexpr int kAbsmaxBlocks = 512;
+__global__ __launch_bounds__(256) void plane_absmax_kernel(const float4* __restrict__ p4, size_t n4, float* __restrict__ absmax_part)
+{
+    __shared__ float red[4];
+    float amax = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = p4[i];
+        amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    block_absmax_store(amax, absmax_part, blockIdx.x, red);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -201,6 +238,64 @@ __global__ void depth_clamp_kernel(float* __restrict__ depth, int nrays, const i
 // -------------------------------------------------------------------------------------------------
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 
+// ---- fp16 range fold of the decoder (exact powers of two; the SR's counterpart is r3d_chain_fold) -------------------------------
+// The decoder runs on the f16 matrix pipe with every fp32 operand split into fp16 hi + lo: exact to ~2^-22 only while an operand sits
+// inside the fp16 window (max < 65504, typical values well above the 2^-24 subnormal step).  The reference computes in fp32 with no range
+// limit, so one launch per call derives exact power-of-two factors from guaranteed bounds:
+//   * features x (a convex combination of plane texels: |x| <= Bx = max |planes|) and W1' = W1 / sqrt(32) * log2(e) share ONE degree of
+//     freedom, x * 2^b and W1' * 2^-b (the product is untouched, so nothing is undone on the accumulators and the kernel pays nothing:
+//     2^b rides in the 1/3 of the plane mean, 2^-b is applied when the weights are staged): b = floor((log2 Bw1 - log2 Bx) / 2) puts both
+//     at sqrt(Bx * Bw1) -- inside the window whenever the pre-activations themselves are sane;
+//   * hidden values h in [0, Bh], Bh = 1 + max_u log2(e) (|b1[u]| + ||W1[u]||_1 / sqrt(32) * Bx): times 2^c only when Bh >= 2^15 (c < 0);
+//   * colour rows W2' * 2^-c * 2^-d with d > 0 only when they would reach 2^15; the accumulators are then multiplied by 2^d.
+// c = d = 0 (a wave-uniform branch not taken) for every sane checkpoint.
+struct DecFold { float xs, w1s, hs, w2s, ys, b2s; float bx, bh; };
+
+__device__ __forceinline__ float pow2i(int e) { return __int_as_float((min(max(e, -126), 127) + 127) << 23); }
+__device__ __forceinline__ int ilog2_floor(float x) { return (int)((__float_as_uint(x) >> 23) & 0xFF) - 127; }     // x > 0, normal
+
+__global__ __launch_bounds__(256) void decoder_fold_kernel(const float* __restrict__ part, int npart, const float* __restrict__ w1,
+                                                          const float* __restrict__ b1, const float* __restrict__ w2, DecFold* __restrict__ out)
+{
+    __shared__ float red[3][4];
+    const int tid = threadIdx.x;
+    float bx = 0.f, bw1 = 0.f, bw2 = 0.f;
+    for (int i = tid; i < npart; i += 256) bx = fmaxf(bx, part[i]);
+    for (int i = tid; i < R3D_HIDDEN * R3D_FEATURES; i += 256) bw1 = fmaxf(bw1, fabsf(w1[i]));
+    for (int i = R3D_HIDDEN + tid; i < R3D_DECODER_OUT * R3D_HIDDEN; i += 256) bw2 = fmaxf(bw2, fabsf(w2[i]));      // colour rows 1..32
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { bx = fmaxf(bx, __shfl_xor(bx, d)); bw1 = fmaxf(bw1, __shfl_xor(bw1, d)); bw2 = fmaxf(bw2, __shfl_xor(bw2, d)); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = bx; red[1][tid >> 6] = bw1; red[2][tid >> 6] = bw2; }
+    __shared__ float rowsum[R3D_HIDDEN];
+    if (tid < R3D_HIDDEN) {
+        float a = 0.f;
+        for (int c = 0; c < R3D_FEATURES; ++c) a += fabsf(w1[tid * R3D_FEATURES + c]);
+        rowsum[tid] = a;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+    bx = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    bw1 = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3])) * (0.17677669529663687f * 1.4426950408889634f);
+    bw2 = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3])) * 0.125f;
+    const float kTiny = 1e-30f, kHuge = 1e30f;
+    int b = 0;
+    if (bx > kTiny && bx < kHuge && bw1 > kTiny && bw1 < kHuge) b = (ilog2_floor(bw1) - ilog2_floor(bx)) >> 1;     // arithmetic shift = floor
+    b = min(max(b, -100), 100);
+    float bh = 0.f;
+    const float bxs = (bx < kHuge) ? bx : kHuge;
+    for (int u = 0; u < R3D_HIDDEN; ++u) bh = fmaxf(bh, 1.4426950408889634f * (fabsf(b1[u]) + rowsum[u] * 0.17677669529663687f * bxs));
+    bh += 1.0f;
+    int c = 0;
+    if (bh >= 32768.f && bh < kHuge) c = 14 - (ilog2_floor(bh) + 1);
+    int d = 0;
+    const float bw2c = bw2 * pow2i(-c);
+    if (bw2c >= 32768.f && bw2c < kHuge) d = (ilog2_floor(bw2c) + 1) - 14;
+    DecFold f;
+    f.xs = pow2i(b); f.w1s = pow2i(-b); f.hs = pow2i(c); f.w2s = pow2i(-c - d); f.ys = pow2i(d); f.b2s = pow2i(-d);
+    f.bx = bx; f.bh = bh;
+    *out = f;
+}
+
 // fp32 -> (hi, lo) fp16 pair with hi + lo == x to 2^-24 relative (lo subnormals are kept by the MFMA)
 __device__ __forceinline__ void split8(const float (&x)[8], h8& hi, h8& lo)
 {
@@ -222,21 +317,24 @@ struct DecoderLds {
                                //   (mt = 2p + (j>>2), reg = j&3) of k-slot q holds after layer 1
     float w2s[kHid];           // W2'[0][:]  (density row, evaluated on the VALU)
     float b1[kHid];
-    float b2[kOut];            // b2[0] density bias, b2[1..32] colour biases
+    float b2[kOut];            // b2[0] density bias, b2[1..32] colour biases (times 2^-d, see DecFold)
+    float xs3, hs, ys;         // range fold: (1/3) * 2^b for the plane mean; 2^c for the hidden values; 2^d for the colour accumulators
 };
 
 __device__ __forceinline__ void stage_decoder(DecoderLds& L, const float* __restrict__ w1,
                                               const float* __restrict__ b1, const float* __restrict__ w2,
-                                              const float* __restrict__ b2)
+                                              const float* __restrict__ b2, const DecFold* __restrict__ fold)
 {
+    const DecFold F = *fold;
     // FullyConnectedLayer: w * (1/sqrt(in_features))  (networks_stylegan2.py:115,119).
     // The hidden layer is evaluated in the log2 domain: h' = log2(e) * (W1 x + b1), softplus(h) = ln2 * sp2(h') with
     // sp2(h') = max(h',0) + log2(1 + 2^-|h'|)  (5 instructions on v_exp_f32 / v_log_f32).  ln2 folds into layer 2:
     // for the colour rows, which feed sigmoid(y) = 1/(1 + 2^(-log2(e) y)), ln2 * log2(e) = 1 leaves W2 unchanged and
     // only b2 picks up log2(e); the density row (natural units) picks up ln2.
     const float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
-    const float g1 = 0.17677669529663687f * kLog2e;  // 1/sqrt(32) * log2(e)
-    const float g2 = 0.125f;                         // 1/sqrt(64)
+    const float g1 = 0.17677669529663687f * kLog2e * F.w1s;  // 1/sqrt(32) * log2(e) * 2^-b
+    const float g2 = 0.125f;                                 // 1/sqrt(64)
+    const float g2c = g2 * F.w2s;                            // colour rows: * 2^-c * 2^-d
     for (int i = threadIdx.x; i < 4 * 64; i += blockDim.x) {
         const int l = i & 63, mt = i >> 6;
         float v[8];
@@ -250,12 +348,13 @@ __device__ __forceinline__ void stage_decoder(DecoderLds& L, const float* __rest
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            v[j] = w2[(1 + 16 * ot + (l & 15)) * kHid + 16 * (2 * pp + (j >> 2)) + 4 * (l >> 4) + (j & 3)] * g2;
+            v[j] = w2[(1 + 16 * ot + (l & 15)) * kHid + 16 * (2 * pp + (j >> 2)) + 4 * (l >> 4) + (j & 3)] * g2c;
         h8 hi, lo; split8(v, hi, lo);
         L.w2f[ot][pp][0][l] = *reinterpret_cast<uint4*>(&hi); L.w2f[ot][pp][1][l] = *reinterpret_cast<uint4*>(&lo);
     }
     for (int i = threadIdx.x; i < kHid; i += blockDim.x) { L.w2s[i] = w2[i] * (g2 * kLn2); L.b1[i] = b1[i] * kLog2e; }
-    for (int i = threadIdx.x; i < kOut; i += blockDim.x) L.b2[i] = i == 0 ? b2[i] : b2[i] * kLog2e;
+    for (int i = threadIdx.x; i < kOut; i += blockDim.x) L.b2[i] = i == 0 ? b2[i] : b2[i] * kLog2e * F.b2s;
+    if (threadIdx.x == 0) { L.xs3 = F.xs * (1.0f / 3.0f); L.hs = F.hs; L.ys = F.ys; }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -264,9 +363,6 @@ __device__ __forceinline__ void stage_decoder(DecoderLds& L, const float* __rest
 // plane2 (z,x); first coordinate indexes W.  planes: [3][H][W][32] floats viewed as float4.
 // -------------------------------------------------------------------------------------------------
 struct Tap { int idx; float w; };
-#if defined(R3D_ABLATE) && (R3D_ABLATE & 8192)
-__device__ int g_dbg[64 + 64 * 24];
-#endif
 
 __device__ __forceinline__ void plane_taps(float u, float v, int H, int W, int plane_base4, Tap t[4])
 {
@@ -297,7 +393,7 @@ __device__ __forceinline__ void plane_taps(float u, float v, int H, int W, int p
 
 template <int PLANES_IN_FLIGHT, bool TRI = false>
 __device__ __forceinline__ void gather_sample(const float4* __restrict__ planes4, int H, int W, int q,
-                                              float px, float py, float pz, float scale, float x[8], int D = 1, int* dbg_flag = nullptr)
+                                              float px, float py, float pz, float scale, float xs3, float x[8], int D = 1)
 {
     const float qx = px * scale, qy = py * scale, qz = pz * scale;
     const int HW8 = H * W * 8;
@@ -342,7 +438,7 @@ __device__ __forceinline__ void gather_sample(const float4* __restrict__ planes4
             __builtin_amdgcn_sched_barrier(0);          // one slice's loads in flight at a time (VGPR budget)
         }
 #pragma unroll
-        for (int c = 0; c < 8; ++c) x[c] = (accs[0][c] + accs[1][c] + accs[2][c]) * (1.0f / 3.0f);
+        for (int c = 0; c < 8; ++c) x[c] = (accs[0][c] + accs[1][c] + accs[2][c]) * xs3;
         return;
     }
     float acc[3][8];
@@ -372,56 +468,29 @@ __device__ __forceinline__ void gather_sample(const float4* __restrict__ planes4
             }
         }
     } else {
-        // one plane's 8 loads in flight at a time.
-        // (Tried in round 2: the four lanes of a sample are one DPP quad in the gather mapping and compute the same 12 taps; letting
-        // lane q compute plane min(q, 2) only and sharing the taps inside the quad -- quad_perm DPP or ds_bpermute, both -- was 4 %
-        // faster and bit-identical in every single-stream test, but produced rare wrong rays (1 in ~15 000) whenever SR kernels of other
-        // streams were co-resident on the CU, and not when any checking code was compiled in.  Not understood, not shipped:
-        // scripts/gpu_debug_determinism.py)
+        // one plane's 8 loads in flight at a time.  The four lanes of a sample are one DPP quad and would compute the same 12 taps: lane q
+        // computes the taps of plane min(q, 2) only and the quad shares them (quad_perm) -- a third of the tap arithmetic, -4 % kernel time.
+        // (Round 2 measured this and could not ship it: ~1 ray in 15 000 came out different whenever MFMA kernels of other streams were
+        // co-resident.  Round 3 found the cause -- not the sharing: with the shared taps hipcc packs the bilinear weights into
+        // v_pk_mul_f32 ... op_sel:[0,1], and gfx950 computes a wrong low half for lanes 48-63 of a packed-f32 instruction whose src1 / src2
+        // op_sel bit is set while another wave of the SIMD executes MFMAs.  The build now rewrites those forms, csrc/tools/pk_opsel_fix.py,
+        // DESIGN 4.1a.)
         const float4* __restrict__ pl = planes4 + 2 * q;            // this lane's 8 channels of a texel
-#if defined(R3D_ABLATE) && (R3D_ABLATE & 4096)           // experiment build: the quad-shared taps described above
-        int qv = q;
-#if (R3D_ABLATE & 131072)                                // ... with the lane predicates recomputed per call (no long-lived SGPR lane masks / SGPR spills of them)
-        asm volatile("" : "+v"(qv));
-#endif
-        const int pq = qv < 2 ? qv : 2;
+#if !(defined(R3D_ABLATE) && (R3D_ABLATE & 4096))          // (experiment build 4096: round 2's per-lane taps, for A/B timing)
+        const int pq = q < 2 ? q : 2;
         Tap tq[4];
-#if (R3D_ABLATE & 262144)                                // ... with bit selects on per-lane VGPR masks instead of v_cndmask on SGPR lane masks
-        int m0 = (pq - 1) >> 31, m1 = -(pq & 1), m2 = -(pq >> 1);
-        asm volatile("" : "+v"(m0), "+v"(m1), "+v"(m2));
-        const float uq = __int_as_float((__float_as_int(qz) & m2) | (__float_as_int(qx) & ~m2));
-        const float vq = __int_as_float((__float_as_int(qy) & m0) | (__float_as_int(qz) & m1) | (__float_as_int(qx) & m2));
-        plane_taps(uq, vq, H, W, pq * HW8, tq);
-#else
         plane_taps(pq == 2 ? qz : qx, pq == 0 ? qy : (pq == 1 ? qz : qx), H, W, pq * HW8, tq);
-#endif
 #endif
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             Tap t[4];
-#if defined(R3D_ABLATE) && (R3D_ABLATE & 4096)
+#if !(defined(R3D_ABLATE) && (R3D_ABLATE & 4096))
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 t[k].idx = p == 0 ? __builtin_amdgcn_mov_dpp(tq[k].idx, 0x00, 0xF, 0xF, true) : p == 1 ? __builtin_amdgcn_mov_dpp(tq[k].idx, 0x55, 0xF, 0xF, true) : __builtin_amdgcn_mov_dpp(tq[k].idx, 0xAA, 0xF, 0xF, true);
                 const int wi = __builtin_bit_cast(int, tq[k].w);
                 t[k].w = __builtin_bit_cast(float, p == 0 ? __builtin_amdgcn_mov_dpp(wi, 0x00, 0xF, 0xF, true) : p == 1 ? __builtin_amdgcn_mov_dpp(wi, 0x55, 0xF, 0xF, true) : __builtin_amdgcn_mov_dpp(wi, 0xAA, 0xF, 0xF, true));
             }
-#if (R3D_ABLATE & 8192)                                 // ... and compared (branch-free) with this lane's own taps
-            {
-                Tap tr[4];
-                plane_taps(us[p], vs[p], H, W, p * HW8, tr);
-                int f = 0;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) f |= (t[k].idx ^ tr[k].idx) | (__float_as_int(t[k].w) ^ __float_as_int(tr[k].w));
-                if (dbg_flag) {
-                    *dbg_flag |= (f != 0) << p;
-                    // do the quad's lanes hold the same sample position at all?
-                    const int x0 = __builtin_amdgcn_mov_dpp(__float_as_int(qx), 0x00, 0xF, 0xF, true), y0 = __builtin_amdgcn_mov_dpp(__float_as_int(qy), 0x00, 0xF, 0xF, true);
-                    const int z0 = __builtin_amdgcn_mov_dpp(__float_as_int(qz), 0x00, 0xF, 0xF, true);
-                    *dbg_flag |= ((x0 ^ __float_as_int(qx)) | (y0 ^ __float_as_int(qy)) | (z0 ^ __float_as_int(qz))) != 0 ? 8 : 0;
-                }
-            }
-#endif
 #else
             plane_taps(us[p], vs[p], H, W, p * HW8, t);
 #endif
@@ -446,9 +515,9 @@ __device__ __forceinline__ void gather_sample(const float4* __restrict__ planes4
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // mean over the three planes (triplane.py:179)
+    // mean over the three planes (triplane.py:179), times the range fold's 2^b (xs3 = 2^b / 3)
 #pragma unroll
-    for (int c = 0; c < 8; ++c) x[c] = (acc[0][c] + acc[1][c] + acc[2][c]) * (1.0f / 3.0f);
+    for (int c = 0; c < 8; ++c) x[c] = (acc[0][c] + acc[1][c] + acc[2][c]) * xs3;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -487,6 +556,13 @@ __device__ __forceinline__ void decode_tile(const DecoderLds& L, int lane, const
     sg += __shfl_xor(sg, 16);
     sg += __shfl_xor(sg, 32);
     sig = sg + L.b2[0];
+    const float hs = L.hs, ys = L.ys;                // range fold (DecFold): 1 unless a bound reaches 2^15 -- wave-uniform, not taken
+    if (hs != 1.0f) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[mt][r] *= hs;
+    }
     // layer 2: Y^T[1+16ot.., samples] = W2'[.., hidden] H^T, two k-steps of 32 hidden units; the B operand of k-step p is
     // this lane's accumulator registers of tiles mt = 2p, 2p+1 (no data movement)
 #pragma unroll
@@ -508,6 +584,12 @@ __device__ __forceinline__ void decode_tile(const DecoderLds& L, int lane, const
             col[ot] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl, col[ot], 0, 0, 0);
             col[ot] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh, col[ot], 0, 0, 0);
         }
+    }
+    if (ys != 1.0f) {
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) col[ot][r] *= ys;
     }
     // sigmoid clamp from MipNeRF: sigmoid(y)*(1+2*0.001)-0.001; col holds log2(e) * y
 #pragma unroll
@@ -628,6 +710,7 @@ struct RenderArgs {
     int* gstate; int nlimit_blocks;
     int Nc, Nf; float scale; int white_back;
     const float* noise_c; const float* u_f; unsigned long long seed;
+    const DecFold* fold;                            // written by decoder_fold_kernel (same stream, before this kernel)
     float* rgb; float* depth; float* wsum; int rgb_cm;      // rgb_cm: rgb is [N,32,M] (channel-major) instead of [N,M,32]; depth may be NULL
 };
 
@@ -665,11 +748,9 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
     __shared__ __attribute__((aligned(16))) RayLds rl[kWavesPerBlock];
     __shared__ __attribute__((aligned(16))) XchLds xch[kWavesPerBlock];
 
-    stage_decoder(dec, a.w1, a.b1, a.w2, a.b2);
+    stage_decoder(dec, a.w1, a.b1, a.w2, a.b2, a.fold);
     __syncthreads();
-#if defined(R3D_ABLATE) && (R3D_ABLATE & 524288)          // experiment build: ray waves win the issue arbitration against co-resident waves
-    __builtin_amdgcn_s_setprio(3);
-#endif
+    const float xs3 = dec.xs3;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, s = lane & 15;          // MFMA / per-sample mapping
@@ -692,9 +773,6 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
     const float gmin_start = ord2f(pmin), gmax_start = ord2f(pmax);
     const bool any_valid = pany != 0;
     float run_min = INFINITY, run_max = -INFINITY;
-#if defined(R3D_ABLATE) && (R3D_ABLATE & 8192)
-    int dbg_flag = 0;
-#endif
 
     for (int iter = 0;; ++iter) {
         int ray;
@@ -728,11 +806,7 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
             f32x4 c2[2];
             h8 xh, xl;
             const float tg = __shfl(tc[nt], gs);       // depth of the sample this lane gathers for (lane gs: q = 0, s = gs)
-#if defined(R3D_ABLATE) && (R3D_ABLATE & 8192)
-            { int f1 = 0; gather_sample<GPF, TRI>(P, a.H, a.W, gq, ox + tg * dx, oy + tg * dy, oz + tg * dz, a.scale, X, a.D, &f1); dbg_flag |= f1 ? (f1 | (16 << nt)) : 0; }
-#else
-            gather_sample<GPF, TRI>(P, a.H, a.W, gq, ox + tg * dx, oy + tg * dy, oz + tg * dz, a.scale, X, a.D);
-#endif
+            gather_sample<GPF, TRI>(P, a.H, a.W, gq, ox + tg * dx, oy + tg * dy, oz + tg * dz, a.scale, xs3, X, a.D);
             gather_to_mfma(E, lane, X, xh, xl);
             decode_tile(dec, lane, xh, xl, c2, sigc[nt]);
             colc[0][nt] = c2[0]; colc[1][nt] = c2[1];
@@ -805,11 +879,7 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
                 float X[8];
                 f32x4 c2[2];
                 h8 xh, xl;
-#if defined(R3D_ABLATE) && (R3D_ABLATE & 8192)
-                { int f1 = 0; gather_sample<GPF, TRI>(P, a.H, a.W, gq, ox + tf * dx, oy + tf * dy, oz + tf * dz, a.scale, X, a.D, &f1); dbg_flag |= f1 ? (f1 | (128 << nt)) : 0; }
-#else
-                gather_sample<GPF, TRI>(P, a.H, a.W, gq, ox + tf * dx, oy + tf * dy, oz + tf * dz, a.scale, X, a.D);
-#endif
+                gather_sample<GPF, TRI>(P, a.H, a.W, gq, ox + tf * dx, oy + tf * dy, oz + tf * dz, a.scale, xs3, X, a.D);
                 gather_to_mfma(E, lane, X, xh, xl);
                 decode_tile(dec, lane, xh, xl, c2, sigf[nt]);
                 colf[0][nt] = c2[0]; colf[1][nt] = c2[1];
@@ -993,19 +1063,6 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
             if (a.depth) a.depth[ray] = dsum / wsum;     // NaN handled + clamped by depth_clamp_kernel
             a.wsum[ray] = wsum;
         }
-#if defined(R3D_ABLATE) && (R3D_ABLATE & 8192)
-        {
-            const unsigned long long bal = __ballot(dbg_flag != 0);
-            if (lane == 0 && bal) a.wsum[ray] = wsum + 1000.0f * (float)__popcll(bal);
-            if (bal) {
-                int slot = 0;
-                if (lane == 0) slot = atomicAdd(&g_dbg[0], 1);
-                slot = __shfl(slot, 0);
-                if (slot < 24) g_dbg[64 + 64 * slot + lane] = dbg_flag | (ray << 8);
-            }
-            dbg_flag = 0;
-        }
-#endif
         wave_lds_sync();
     }
 #pragma unroll
@@ -1026,12 +1083,13 @@ template <bool TRI>
 __global__ __launch_bounds__(256, 2) void run_model_kernel(const float4* __restrict__ planes4, int N, int H, int W, int D,
                                                           const float* w1, const float* b1, const float* w2, const float* b2,
                                                           const float* __restrict__ coords, int npts, float scale,
-                                                          float* __restrict__ rgb, float* __restrict__ sigma)
+                                                          float* __restrict__ rgb, float* __restrict__ sigma, const DecFold* __restrict__ fold)
 {
     __shared__ __attribute__((aligned(16))) DecoderLds dec;
     __shared__ __attribute__((aligned(16))) XchLds xch[kWavesPerBlock];
-    stage_decoder(dec, w1, b1, w2, b2);
+    stage_decoder(dec, w1, b1, w2, b2, fold);
     __syncthreads();
+    const float xs3 = dec.xs3;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, s = lane & 15;
     const int gq = gather_q(lane), gs = gather_s(lane);
@@ -1052,7 +1110,7 @@ __global__ __launch_bounds__(256, 2) void run_model_kernel(const float4* __restr
             float X[8];
             f32x4 c2[2];
             h8 xh, xl;
-            gather_sample<3, TRI>(P, H, W, gq, coords[3 * ii], coords[3 * ii + 1], coords[3 * ii + 2], scale, X, D);
+            gather_sample<3, TRI>(P, H, W, gq, coords[3 * ii], coords[3 * ii + 1], coords[3 * ii + 2], scale, xs3, X, D);
             gather_to_mfma(E, lane, X, xh, xl);
             decode_tile(dec, lane, xh, xl, c2, sig[nt]);
             col[0][nt] = c2[0]; col[1][nt] = c2[1];
@@ -1075,6 +1133,22 @@ __global__ __launch_bounds__(256, 2) void run_model_kernel(const float4* __restr
 // -------------------------------------------------------------------------------------------------
 // workspace: gstate header (8 ints) + 3 ints per ray_limits block, then ray_start[nrays], ray_end[nrays]
 static inline size_t render_state_bytes(size_t nrays) { return ((kStateHeader + 3 * ((nrays + kLimitsBlock - 1) / kLimitsBlock)) * sizeof(int) + 63) & ~(size_t)63; }
+// decoder fold record (64 bytes) + room for the partials of plane_absmax_kernel (when the caller passes none)
+static constexpr size_t kFoldBytes = 64 + kAbsmaxBlocks * sizeof(float);
+
+// launches (plane_absmax_kernel if needed +) decoder_fold_kernel; returns the device address of the DecFold record
+static const DecFold* launch_decoder_fold(const float* planes_nhwc, size_t plane_floats, const float* plane_absmax, int n_plane_absmax,
+                                          const float* w1, const float* b1, const float* w2, void* fold_mem, hipStream_t st)
+{
+    DecFold* fold = reinterpret_cast<DecFold*>(fold_mem);
+    float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(fold_mem) + 64);
+    if (!plane_absmax || n_plane_absmax <= 0) {
+        hipLaunchKernelGGL(plane_absmax_kernel, dim3(kAbsmaxBlocks), dim3(256), 0, st, reinterpret_cast<const float4*>(planes_nhwc), plane_floats / 4, part);
+        plane_absmax = part; n_plane_absmax = kAbsmaxBlocks;
+    }
+    hipLaunchKernelGGL(decoder_fold_kernel, dim3(1), dim3(256), 0, st, plane_absmax, n_plane_absmax, w1, b1, w2, fold);
+    return fold;
+}
 
 template <int NTC, int NTF>
 static void launch_render(const RenderArgs& a, int R, int grid, hipStream_t st)
@@ -1100,24 +1174,38 @@ static void launch_render_tri(const RenderArgs& a, int R, int grid, hipStream_t 
 
 using namespace r3d;
 
-#if defined(R3D_ABLATE) && (R3D_ABLATE & 8192)
-extern "C" int r3d_debug_read(int* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(r3d::g_dbg), sizeof(int) * (64 + 64 * 24)); }
-#endif
-extern "C" int r3d_planes_to_nhwc(const float* planes_nchw, const float* add_nchw, float* planes_nhwc,
-                                  int N, int C, int H, int W, int depth, int add_flip, r3d_stream_t stream)
+// number of per-block |max| partials r3d_planes_to_nhwc writes for this shape (the same kernel choice as below)
+static inline bool nhwc32_fast_path(const void* a, const void* b, const void* c, int C, int HW, int depth, int add_flip)
 {
+    const bool aligned16 = !(((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15);
+    return C == 32 && depth == 1 && add_flip == 0 && (HW & 63) == 0 && aligned16;
+}
+extern "C" size_t r3d_planes_absmax_partials(int N, int C, int H, int W, int depth)
+{
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0 || depth < 1) return 0;
+    const size_t HW = (size_t)H * W;
+    // upper bound over both kernels: the general kernel's grid is the larger one
+    return ((HW + 31) / 32) * ((C + 31) / 32) * (size_t)N * 3 * depth;
+}
+
+extern "C" int r3d_planes_to_nhwc(const float* planes_nchw, const float* add_nchw, float* planes_nhwc,
+                                  int N, int C, int H, int W, int depth, int add_flip, float* absmax_partials, int* n_partials,
+                                  r3d_stream_t stream)
+{
+    if (absmax_partials && !n_partials) { set_error("planes_to_nhwc: absmax_partials needs n_partials"); return R3D_ERR_INVALID_ARG; }
     if (!planes_nchw || !planes_nhwc || N <= 0 || C <= 0 || H <= 0 || W <= 0 || depth < 1 || depth > 16 || add_flip < 0 || add_flip > 63) {
         set_error("planes_to_nhwc: bad argument"); return R3D_ERR_INVALID_ARG;
     }
     const int HW = H * W;
     dim3 grid((HW + 31) / 32, (C + 31) / 32, N * 3 * depth), block(32, 8);
     ProfScope ps(R3D_PROF_LAYOUT, (hipStream_t)stream);
-    const bool aligned16 = !(((uintptr_t)planes_nchw | (uintptr_t)add_nchw | (uintptr_t)planes_nhwc) & 15);
-    if (C == 32 && depth == 1 && add_flip == 0 && (HW & 63) == 0 && aligned16) {
-        hipLaunchKernelGGL(planes_to_nhwc32_kernel, dim3(HW / 64, N * 3), dim3(256), 0, (hipStream_t)stream, planes_nchw, add_nchw, planes_nhwc, HW);
+    if (nhwc32_fast_path(planes_nchw, add_nchw, planes_nhwc, C, HW, depth, add_flip)) {
+        if (n_partials) *n_partials = (HW / 64) * N * 3;
+        hipLaunchKernelGGL(planes_to_nhwc32_kernel, dim3(HW / 64, N * 3), dim3(256), 0, (hipStream_t)stream, planes_nchw, add_nchw, planes_nhwc, HW, absmax_partials);
         return check_launch("planes_to_nhwc");
     }
-    hipLaunchKernelGGL(planes_to_nhwc_kernel, grid, block, 0, (hipStream_t)stream, planes_nchw, add_nchw, planes_nhwc, C, HW, W, add_flip, depth);
+    if (n_partials) *n_partials = (int)(grid.x * grid.y * grid.z);
+    hipLaunchKernelGGL(planes_to_nhwc_kernel, grid, block, 0, (hipStream_t)stream, planes_nchw, add_nchw, planes_nhwc, C, HW, W, add_flip, depth, absmax_partials);
     return check_launch("planes_to_nhwc");
 }
 
@@ -1135,8 +1223,10 @@ extern "C" size_t r3d_render_workspace_bytes(int N, int M, int Nc, int Nf)
 {
     (void)Nc; (void)Nf;
     const size_t nrays = (size_t)N * M;
-    return render_state_bytes(nrays) + 2 * nrays * sizeof(float) + 64;
+    return render_state_bytes(nrays) + 2 * nrays * sizeof(float) + 64 + kFoldBytes;
 }
+
+extern "C" size_t r3d_run_model_workspace_bytes(void) { return kFoldBytes; }
 
 extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W, int triplane_depth,
                                   const float* w1, const float* b1, const float* w2, const float* b2,
@@ -1144,6 +1234,7 @@ extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
                                   int Nc, int Nf, float box_warp, int white_back,
                                   const float* noise_c, const float* u_f, uint64_t seed,
                                   float* rgb, int rgb_channel_major, float* depth, float* wsum, uint8_t* valid,
+                                  const float* plane_absmax, int n_plane_absmax,
                                   void* workspace, size_t workspace_bytes, r3d_stream_t stream)
 {
     if (!planes_nhwc || !w1 || !b1 || !w2 || !b2 || !origins || !dirs || !rgb || !wsum || !valid) {
@@ -1161,6 +1252,7 @@ extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
     int* gstate = reinterpret_cast<int*>(workspace);
     float* ray_start = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + render_state_bytes(nrays));
     float* ray_end = ray_start + nrays;
+    void* fold_mem = reinterpret_cast<char*>(workspace) + ((render_state_bytes(nrays) + 2 * (size_t)nrays * sizeof(float) + 63) & ~(size_t)63);
 
     {
         ProfScope ps(R3D_PROF_MISC, st);
@@ -1169,6 +1261,10 @@ extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
     }
 
     RenderArgs a;
+    {
+        ProfScope ps(R3D_PROF_MISC, st);
+        a.fold = launch_decoder_fold(planes_nhwc, (size_t)N * 3 * triplane_depth * H * W * kC, plane_absmax, n_plane_absmax, w1, b1, w2, fold_mem, st);
+    }
     a.planes4 = reinterpret_cast<const float4*>(planes_nhwc); a.N = N; a.H = H; a.W = W; a.M = M; a.D = triplane_depth;
     a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
     a.origins = origins; a.dirs = dirs; a.ray_start = ray_start; a.ray_end = ray_end; a.valid = valid;
@@ -1212,22 +1308,26 @@ extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
 extern "C" int r3d_run_model(const float* planes_nhwc, int N, int H, int W, int triplane_depth,
                              const float* w1, const float* b1, const float* w2, const float* b2,
                              const float* coords, int npts, float box_warp,
-                             float* rgb, float* sigma, r3d_stream_t stream)
+                             float* rgb, float* sigma, const float* plane_absmax, int n_plane_absmax,
+                             void* workspace, size_t workspace_bytes, r3d_stream_t stream)
 {
     if (!planes_nhwc || !w1 || !b1 || !w2 || !b2 || !coords || !rgb || !sigma || N <= 0 || npts <= 0 || triplane_depth < 1 || triplane_depth > 16 || !(box_warp > 0.f)) {
         set_error("run_model: bad argument"); return R3D_ERR_INVALID_ARG;
     }
+    if (!workspace || workspace_bytes < kFoldBytes || ((uintptr_t)workspace & 15)) { set_error("run_model: workspace too small (r3d_run_model_workspace_bytes) or unaligned"); return R3D_ERR_WORKSPACE; }
+    if (H <= 1 || W <= 1) { set_error("run_model: bad shape"); return R3D_ERR_INVALID_ARG; }
     const long long chunks = ((long long)N * npts + 63) / 64;
     int grid = (int)((chunks + kWavesPerBlock - 1) / kWavesPerBlock);
     if (grid > 1024) grid = 1024;
+    const DecFold* fold = launch_decoder_fold(planes_nhwc, (size_t)N * 3 * triplane_depth * H * W * kC, plane_absmax, n_plane_absmax, w1, b1, w2, workspace, (hipStream_t)stream);
     ProfScope ps(R3D_PROF_RENDER, (hipStream_t)stream);
     if (triplane_depth > 1)
         hipLaunchKernelGGL(run_model_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                            reinterpret_cast<const float4*>(planes_nhwc), N, H, W, triplane_depth, w1, b1, w2, b2, coords, npts,
-                           2.0f / box_warp, rgb, sigma);
+                           2.0f / box_warp, rgb, sigma, fold);
     else
         hipLaunchKernelGGL(run_model_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream,
                            reinterpret_cast<const float4*>(planes_nhwc), N, H, W, triplane_depth, w1, b1, w2, b2, coords, npts,
-                           2.0f / box_warp, rgb, sigma);
+                           2.0f / box_warp, rgb, sigma, fold);
     return check_launch("run_model");
 }

@@ -12,6 +12,8 @@ Mirrors (same class names, call signatures, option keys, return values):
 
 There is no eager/PyTorch fallback: tensors must live on the GPU and the HIP library must be built.
 """
+import ctypes
+
 import torch
 import torch.nn as nn
 
@@ -135,11 +137,19 @@ class ImportanceRenderer(nn.Module):
         if CD != 32 * D:
             raise NotImplementedError("HIP renderer is built for 32 feature channels (x triplane_depth %d), got %d" % (D, CD))
         C = CD // D
-        out = torch.empty((N, 3, H, W, C) if D == 1 else (N, 3, D, H, W, C), device=planes.device, dtype=torch.float32)
+        # one allocation: the channel-last planes, then the per-block |max| partials of the layout pass (the bound the renderer's fp16
+        # range fold needs, r3d_hip.h "plane_absmax") -- the tensor handed back is the view of the first part
+        numel = N * 3 * D * H * W * C
+        npart = int(lib.r3d_planes_absmax_partials(N, C, H, W, D))
+        buf = torch.empty(numel + npart, device=planes.device, dtype=torch.float32)
+        out = buf[:numel].view((N, 3, H, W, C) if D == 1 else (N, 3, D, H, W, C))
+        part = buf[numel:]
         addc = _f32c(add).reshape(planes.shape) if add is not None else None
+        nwritten = ctypes.c_int(0)
         _lib.check(lib.r3d_planes_to_nhwc(_lib.ptr(planes), _lib.ptr(addc), _lib.ptr(out), N, C, H, W, D,
-                                          int(add_flip), _lib.stream_ptr()), "planes_to_nhwc")
+                                          int(add_flip), part.data_ptr(), ctypes.byref(nwritten), _lib.stream_ptr()), "planes_to_nhwc")
         out._r3d_nhwc = True
+        out._r3d_absmax = (part, int(nwritten.value))
         return out
 
     def _planes_nhwc(self, planes):
@@ -207,12 +217,14 @@ class ImportanceRenderer(nn.Module):
         need = int(lib.r3d_render_workspace_bytes(N, M, Nc, Nf))
         if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
             self._workspace = torch.empty(need, device=dev, dtype=torch.uint8)
+        part, npart = getattr(planes_nhwc, "_r3d_absmax", (None, 0))        # absent (caller's own layout): measured inside the call
         _lib.check(lib.r3d_render_forward(
             _lib.ptr(planes_nhwc), N, H, W, D, _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2),
             _lib.ptr(o), _lib.ptr(d), M, Nc, Nf, float(rendering_options["box_warp"]),
             int(bool(rendering_options.get("white_back", False))),
             _lib.ptr(noise_c), _lib.ptr(u_f), int(self.seed) & 0xFFFFFFFFFFFFFFFF,
             _lib.ptr(rgb_cm), int(self.rgb_channel_major), _lib.ptr(depth), _lib.ptr(wsum), _lib.ptr(valid),
+            None if part is None else part.data_ptr(), npart,
             _lib.ptr(self._workspace), need, _lib.stream_ptr()), "render_forward")
         return rgb, depth, wsum, valid
 
@@ -231,7 +243,12 @@ class ImportanceRenderer(nn.Module):
         w1, b1, w2, b2 = decoder_params(decoder)
         rgb = torch.empty(N, npts, 32, device=coords.device, dtype=torch.float32)
         sigma = torch.empty(N, npts, 1, device=coords.device, dtype=torch.float32)
+        need = int(lib.r3d_run_model_workspace_bytes())
+        if self._workspace is None or self._workspace.numel() < need or self._workspace.device != coords.device:
+            self._workspace = torch.empty(need, device=coords.device, dtype=torch.uint8)
+        part, npart = getattr(planes_nhwc, "_r3d_absmax", (None, 0))
         _lib.check(lib.r3d_run_model(_lib.ptr(planes_nhwc), N, H, W, D, _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2),
                                      _lib.ptr(b2), _lib.ptr(coords), npts, float(options["box_warp"]),
-                                     _lib.ptr(rgb), _lib.ptr(sigma), _lib.stream_ptr()), "run_model")
+                                     _lib.ptr(rgb), _lib.ptr(sigma), None if part is None else part.data_ptr(), npart,
+                                     _lib.ptr(self._workspace), need, _lib.stream_ptr()), "run_model")
         return {"rgb": rgb, "sigma": sigma}

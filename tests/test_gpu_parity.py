@@ -549,3 +549,72 @@ def test_multi_stream_pipeline_is_bit_identical(torch_cuda):
     G._last_planes = cano + res[0]
     out = G.synthesis(ws, cams[:1], use_cached_backbone=True)
     assert out["image_depth"].shape == (1, 1, 128, 128) and torch.isfinite(out["image_depth"]).all()
+
+
+# ---- BASELINE configs[1] read literally: a 512 x 512 NEURAL render (R = 512), 48 (+48) samples, then the SR's resample-to-128^2 path ----------
+def _render_r512(torch, g):
+    from real3dportrait_amd import ImportanceRenderer, RaySampler, synth
+    R, Nc, Nf, seed = int(g["R"]), int(g["Nc"]), int(g["Nf"]), int(g["seed"])
+    M = R * R
+    planes = synth.synth_planes(seed, N=1)
+    dec_np = synth.synth_decoder(seed + 1, sigma_bias=3.0)
+    noise_c = synth.synth_noise(seed + 2, (1, M, Nc, 1), stream=7)
+    u_f = synth.synth_noise(seed + 2, (M, max(Nf, 1)), stream=8)[:, :Nf].copy() if Nf > 0 else None
+    cams = T(torch, g["cams"])
+    o, d = RaySampler()(cams[:, :16].view(-1, 4, 4), cams[:, 16:].view(-1, 3, 3), R)
+    ren = ImportanceRenderer(hp={})
+    ren.noise_override = (T(torch, noise_c), T(torch, u_f) if Nf > 0 else None)
+    rgb, depth, wsum, valid = ren(T(torch, planes), make_decoder(torch, dec_np), o, d, opts(Nc, Nf))
+    torch.cuda.synchronize()
+    return rgb, depth, wsum, valid
+
+
+@pytest.mark.parametrize("name", ["render_g_r512_48p0", "render_h_r512_48p48_sr"])
+def test_render_r512_golden(torch_cuda, name):
+    """All 262 144 rays are rendered; the fixture holds the reference's values on every 8th row / column (the global couplings -- fix-up
+    limits, depth clamp -- come from the full render on both sides).  Backs bench.py's `alt_neural_render_512`."""
+    torch = torch_cuda
+    g = load_golden(name)
+    rgb, depth, wsum, valid = _render_r512(torch, g)
+    idx = torch.from_numpy(g["ray_index"]).cuda()
+    assert np.array_equal(valid[:, idx].cpu().numpy(), g["valid"])
+    assert abs(float(valid.float().mean()) - float(g["valid_frac"])) < 1e-7
+    e_rgb = np.abs(rgb[:, idx].cpu().numpy() - g["rgb"]).max()
+    e_w = np.abs(wsum[:, idx].cpu().numpy() - g["wsum"]).max()
+    e_d = np.abs(depth[:, idx].cpu().numpy() - g["depth"]).max()
+    print("%s: rgb %.2e wsum %.2e depth %.2e" % (name, e_rgb, e_w, e_d))
+    assert e_rgb <= RGB_TOL and e_w <= RGB_TOL and e_d <= DEPTH_TOL
+    assert abs(float(depth.min()) - float(g["depth_min"])) <= DEPTH_TOL and abs(float(depth.max()) - float(g["depth_max"])) <= DEPTH_TOL
+    if "sr_strided" in g:
+        # ... and the 512^2 feature image through SuperresolutionHybrid8XDC, whose first step resamples any R != 128 input to 128^2
+        # (superresolution.py:351-355; here r3d_resize_bilinear).  The SR input is OUR render: end-to-end tolerance of the clamped image.
+        from real3dportrait_amd import SuperresolutionHybrid8XDC, synth
+        params = synth.synth_sr_params(int(g["sr_seed"]))
+        sr = SuperresolutionHybrid8XDC(channels=32, img_resolution=512, sr_num_fp16_res=0, sr_antialias=True).cuda()
+        load_block(torch, sr.block0, params[0]); load_block(torch, sr.block1, params[1])
+        R = int(g["R"])
+        feat = rgb.permute(0, 2, 1).reshape(1, 32, R, R).contiguous()
+        img = sr(feat[:, :3].contiguous(), feat, torch.ones(1, 14, 512, device="cuda"), noise_mode="none").cpu().numpy()
+        tol = 5 * SR_TOL * max(1.0, np.abs(g["sr_strided"]).max())
+        e = max(np.abs(img[:, :, ::4, ::4] - g["sr_strided"]).max(), np.abs(img[:, :, :96, :96] - g["sr_corner"]).max())
+        print("   SR of the R=512 render: max err %.2e (tol %.1e, max|ref| %.2f)" % (e, tol, np.abs(g["sr_strided"]).max()))
+        assert e <= tol
+
+
+@pytest.mark.parametrize("tag", ["down", "up"])
+def test_sr_resize_golden(torch_cuda, tag):
+    """SuperresolutionHybrid8XDC fed with a 192^2 / 80^2 neural render: the reference resamples x and rgb to 128^2 with the antialiased
+    bilinear filter first (superresolution.py:351-355); ours runs r3d_resize_bilinear (no ATen op on the path)."""
+    torch = torch_cuda
+    from real3dportrait_amd import SuperresolutionHybrid8XDC, synth
+    g = load_golden("sr_resize_a")
+    seed, r = int(g["seed"]), int(g["r_" + tag])
+    params = synth.synth_sr_params(seed)
+    sr = SuperresolutionHybrid8XDC(channels=32, img_resolution=512, sr_num_fp16_res=0, sr_antialias=True).cuda()
+    load_block(torch, sr.block0, params[0]); load_block(torch, sr.block1, params[1])
+    x = T(torch, synth.hash_unitvar(seed, (1, 32, r, r), stream=3 if tag == "down" else 4))
+    out = sr(x[:, :3].contiguous(), x, torch.ones(1, 14, 512, device="cuda"), noise_mode="none").cpu().numpy()
+    tol = SR_TOL * max(1.0, np.abs(g["strided_" + tag]).max())
+    e = max(np.abs(out[:, :, ::4, ::4] - g["strided_" + tag]).max(), np.abs(out[:, :, :64, :64] - g["corner_" + tag]).max())
+    print("sr_resize %s (%d^2 -> 128^2): max err %.2e (tol %.1e)" % (tag, r, e, tol))
+    assert e <= tol

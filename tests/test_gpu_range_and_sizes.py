@@ -433,3 +433,127 @@ def test_rccl_gather_frames_single_rank(torch_cuda):
     assert torch.equal(root, local)
     assert lib.r3d_gather_frames(comm, _lib.ptr(local), local.numel(), None, 0, _lib.stream_ptr()) == -1     # root without a buffer
     _lib.check(lib.r3d_comm_destroy(comm), "comm_destroy")
+
+
+# ---- the renderer's decoder on the f16 matrix pipe: exact power-of-two range fold (csrc/r3d_render.hip decoder_fold_kernel) ----------------
+def _render_case(torch, planes, dec_np, Nc=24, Nf=24, R=16, tagged=True):
+    from real3dportrait_amd import ImportanceRenderer, OSGDecoder, RaySampler, synth
+    cam = torch.from_numpy(synth.look_at_camera(0.1, -0.05)[None]).cuda()
+    o, d = RaySampler()(cam[:, :16].view(-1, 4, 4), cam[:, 16:].view(-1, 3, 3), R)
+    dec = OSGDecoder().cuda()
+    with torch.no_grad():
+        dec.net[0].weight.copy_(torch.from_numpy(dec_np[0])); dec.net[0].bias.copy_(torch.from_numpy(dec_np[1]))
+        dec.net[2].weight.copy_(torch.from_numpy(dec_np[2])); dec.net[2].bias.copy_(torch.from_numpy(dec_np[3]))
+    ren = ImportanceRenderer(hp={})
+    noise_c = synth.synth_noise(31, (1, R * R, Nc, 1)); u_f = synth.synth_noise(32, (R * R, Nf))
+    ren.noise_override = (torch.from_numpy(noise_c).cuda(), torch.from_numpy(u_f).cuda())
+    options = {"ray_start": "auto", "ray_end": "auto", "box_warp": 1.0, "depth_resolution": Nc, "depth_resolution_importance": Nf,
+               "disparity_space_sampling": False, "clamp_mode": "softplus", "white_back": False}
+    p = torch.from_numpy(planes).cuda()
+    if not tagged:          # a caller that did its own layout: no |max| partials, the bound is measured inside r3d_render_forward
+        nhwc = ren.prepare_planes(p).clone()
+        nhwc._r3d_nhwc = True
+        p = nhwc
+    rgb, depth, wsum, valid = ren(p, dec, o, d, options)
+    torch.cuda.synchronize()
+    return (rgb.cpu().numpy(), depth.cpu().numpy(), wsum.cpu().numpy()), (o.cpu().numpy(), d.cpu().numpy(), noise_c, u_f)
+
+
+@pytest.mark.parametrize("k", [-16, -12, -8, -4, 0, 4, 8, 12])
+def test_render_range_sweep_planes_vs_first_layer(torch_cuda, oracle, k):
+    """planes * 2^k with decoder.net.0.weight * 2^-k is the same function (exact power-of-two factors: the fp32 reference / oracle gives
+    bit-identical pre-activations for every k).  Without the range fold the fp16 hi/lo split of the gathered features (k = -16: the lo
+    terms fall under the fp16 subnormal step) or of the weights loses up to 2e-3; with it every k must match the oracle like k = 0."""
+    torch = torch_cuda
+    from real3dportrait_amd import synth
+    planes = synth.synth_planes(41, N=1, H=64, W=64)
+    dec = list(synth.synth_decoder(42, sigma_bias=3.0))
+    s = np.float32(2.0 ** k)
+    dec_k = [dec[0] / s, dec[1], dec[2], dec[3]]
+    (rgb, depth, wsum), (o, d, noise_c, u_f) = _render_case(torch, planes * s, dec_k, tagged=(k % 8 != 4))
+    ref = oracle.render(planes, tuple(dec), o, d, 24, 24, noise_c, u_f)
+    e_rgb, e_d, e_w = np.abs(rgb - ref[0]).max(), np.abs(depth - ref[1]).max(), np.abs(wsum - ref[2]).max()
+    print("k=%+d: rgb %.2e depth %.2e wsum %.2e" % (k, e_rgb, e_d, e_w))
+    assert e_rgb <= 2e-5 and e_w <= 2e-5 and e_d <= 2e-5
+
+
+def _run_model_fp64(planes, dec, coords, box_warp=1.0):
+    """Point queries in float64 numpy (sample_from_planes + OSGDecoder, renderer.py:49-75, models/triplane.py:177-189), plus a bound on the
+    error allowed: 64 fp32 ulp of the absolute accumulations, propagated through both layers (an fp32 evaluation carries ~8; the 3-term
+    fp16 split represents each operand to 2^-22 and drops the lo*lo products, i.e. ~2^-21 relative per dot product)."""
+    P = planes.astype(np.float64)
+    N, _, C, H, W = P.shape
+    w1, b1, w2, b2 = (a.astype(np.float64) for a in dec)
+    q = coords.astype(np.float64) * (2.0 / box_warp)
+    uv = [(q[..., 0], q[..., 1]), (q[..., 0], q[..., 2]), (q[..., 2], q[..., 0])]
+    feat = np.zeros(q.shape[:2] + (C,))
+    for p, (u, v) in enumerate(uv):
+        ix, iy = ((u + 1) * W - 1) / 2, ((v + 1) * H - 1) / 2
+        x0, y0 = np.floor(ix).astype(np.int64), np.floor(iy).astype(np.int64)
+        for dy in (0, 1):
+            for dx in (0, 1):
+                xx, yy = x0 + dx, y0 + dy
+                wgt = (1 - np.abs(ix - xx)) * (1 - np.abs(iy - yy))
+                ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
+                for n in range(N):
+                    t = P[n, p][:, np.clip(yy[n], 0, H - 1), np.clip(xx[n], 0, W - 1)].T          # [npts, C]
+                    feat[n] += np.where(ok[n][:, None], t * wgt[n][:, None], 0.0)
+    x = feat / 3.0
+    pre = x @ (w1.T / np.sqrt(32.0)) + b1
+    h = np.logaddexp(0.0, pre)
+    y = h @ (w2.T / 8.0) + b2
+    eps = 64 * 2.0 ** -24
+    dpre = eps * (np.abs(x) @ np.abs(w1.T / np.sqrt(32.0)) + np.abs(b1))
+    dy = eps * (np.abs(h) @ np.abs(w2.T / 8.0) + np.abs(b2)) + dpre @ np.abs(w2.T / 8.0)
+    rgb = 1.002 / (1.0 + np.exp(-y[..., 1:])) - 0.001
+    return rgb, y[..., :1], 0.2505 * dy[..., 1:], dy[..., :1]
+
+
+@pytest.mark.parametrize("which,k", [("w1", 10), ("w1", 15), ("w1", -14), ("w2", -16), ("w2", 9), ("w2", 16), ("b1", 14), ("planes", 18), ("planes", -30),
+                                     ("none", 0)])
+def test_decoder_range_sweep_magnitudes_fp64(torch_cuda, which, k):
+    """One operand scaled on its own (a different function each time): point queries against a float64 evaluation, with the tolerance an
+    fp32 evaluation of the same formulas is entitled to (the reference computes in fp32).  Exercises the optional factors of the fold:
+    hidden values above 2^15 (2^c), colour rows above 2^15 (2^d), plane / weight magnitudes far from 1 -- no clamping, no overflow."""
+    torch = torch_cuda
+    from real3dportrait_amd import ImportanceRenderer, OSGDecoder, synth
+    planes = synth.synth_planes(43, N=2, H=32, W=32)
+    dec = list(synth.synth_decoder(44, sigma_bias=2.0))
+    coords = ((synth.synth_noise(48, (2, 700, 3)) - 0.5) * 1.2).astype(np.float32)
+    s = np.float32(2.0 ** k)
+    if which == "planes":
+        planes = planes * s
+    elif which != "none":
+        i = {"w1": 0, "b1": 1, "w2": 2}[which]
+        dec[i] = dec[i] * s
+    decm = OSGDecoder().cuda()
+    with torch.no_grad():
+        decm.net[0].weight.copy_(torch.from_numpy(dec[0])); decm.net[0].bias.copy_(torch.from_numpy(dec[1]))
+        decm.net[2].weight.copy_(torch.from_numpy(dec[2])); decm.net[2].bias.copy_(torch.from_numpy(dec[3]))
+    out = ImportanceRenderer(hp={}).run_model(torch.from_numpy(planes).cuda(), decm, torch.from_numpy(coords).cuda(), None, {"box_warp": 1.0})
+    rgb, sig = out["rgb"].cpu().numpy().astype(np.float64), out["sigma"].cpu().numpy().astype(np.float64)
+    assert np.isfinite(rgb).all() and np.isfinite(sig).all()
+    r_rgb, r_sig, t_rgb, t_sig = _run_model_fp64(planes, dec, coords)
+    e_rgb, e_sig = np.abs(rgb - r_rgb), np.abs(sig - r_sig)
+    worst_rgb, worst_sig = (e_rgb / (2e-6 + t_rgb)).max(), (e_sig / (2e-6 + t_sig)).max()
+    print("%s * 2^%+d: rgb err %.2e (%.2f of the allowance), sigma err %.2e (%.2f)" % (which, k, e_rgb.max(), worst_rgb, e_sig.max(), worst_sig))
+    assert worst_rgb <= 1.0 and worst_sig <= 1.0
+
+
+@pytest.mark.parametrize("k", [-16, 0, 12])
+def test_run_model_range_sweep(torch_cuda, oracle, k):
+    torch = torch_cuda
+    from real3dportrait_amd import ImportanceRenderer, OSGDecoder, synth
+    planes = synth.synth_planes(45, N=2, H=32, W=32)
+    dec = list(synth.synth_decoder(46))
+    coords = ((synth.synth_noise(47, (2, 500, 3)) - 0.5) * 1.2).astype(np.float32)
+    s = np.float32(2.0 ** k)
+    decm = OSGDecoder().cuda()
+    with torch.no_grad():
+        decm.net[0].weight.copy_(torch.from_numpy(dec[0] / s)); decm.net[0].bias.copy_(torch.from_numpy(dec[1]))
+        decm.net[2].weight.copy_(torch.from_numpy(dec[2])); decm.net[2].bias.copy_(torch.from_numpy(dec[3]))
+    out = ImportanceRenderer(hp={}).run_model(torch.from_numpy(planes * s).cuda(), decm, torch.from_numpy(coords).cuda(), None, {"box_warp": 1.0})
+    ref = oracle.run_model(planes, tuple(dec), coords)
+    e_rgb, e_s = np.abs(out["rgb"].cpu().numpy() - ref[0]).max(), np.abs(out["sigma"].cpu().numpy().reshape(ref[1].shape) - ref[1]).max()
+    print("run_model k=%+d: rgb %.2e sigma %.2e" % (k, e_rgb, e_s))
+    assert e_rgb <= 2e-5 and e_s <= 2e-4
