@@ -89,42 +89,60 @@ def cpu_baseline(seed=7):
     cam = synth.camera_sweep(64, -0.4, 0.4)[:1]
     R, Nc, Nf = 128, 48, 48
     noise_c = synth.synth_noise(seed, (1, R * R, Nc, 1)); u_f = synth.synth_noise(seed + 1, (R * R, Nf))
-    t0 = time.perf_counter()
-    o, d = orc.raygen(cam[:, :16], cam[:, 16:], R)
-    rgb, depth, wsum, valid = orc.render(planes, dec, o, d, Nc, Nf, noise_c, u_f)
-    t_render = time.perf_counter() - t0
-    feat = np.ascontiguousarray(rgb[0].T.reshape(32, R, R))
     ws = np.ones((14, 512), np.float32)
-    # bounded: time the SR on the top-left 64^2 quarter first (1/4 of the conv work)
-    t0 = time.perf_counter()
-    orc.superresolution(np.ascontiguousarray(feat[:3, :64, :64]), np.ascontiguousarray(feat[:, :64, :64]), sr, ws)
-    t_q = time.perf_counter() - t0
-    if t_render + 4 * t_q <= 45.0:
+
+    def frame():
         t0 = time.perf_counter()
+        o, d = orc.raygen(cam[:, :16], cam[:, 16:], R)
+        rgb, depth, wsum, valid = orc.render(planes, dec, o, d, Nc, Nf, noise_c, u_f)
+        t1 = time.perf_counter()
+        feat = np.ascontiguousarray(rgb[0].T.reshape(32, R, R))
         orc.superresolution(np.ascontiguousarray(feat[:3]), feat, sr, ws)
-        t_sr = time.perf_counter() - t0
-        sample = "1 full frame: render R=128 48+48 (%.2fs) + SR 128^2->512^2 (%.2fs)" % (t_render, t_sr)
-    else:
-        t_sr = 4 * t_q
-        sample = "render R=128 48+48 (%.2fs) + SR on a 64^2 quarter x4 (%.2fs extrapolated)" % (t_render, t_sr)
+        return t1 - t0, time.perf_counter() - t1
+    t_render, t_sr = frame()                      # first call: page faults of the oracle's scratch buffers, OpenMP thread start
+    runs = 1
+    if t_render + t_sr <= 12.0:                   # bounded sample: at most ~30 s of CPU work
+        for _ in range(2):
+            r, q = frame()
+            runs += 1
+            if r + q < t_render + t_sr:
+                t_render, t_sr = r, q
+    sample = "1 full frame, best of %d: render R=128 48+48 (%.2fs) + SR 128^2->512^2 (%.2fs)" % (runs, t_render, t_sr)
     return {"value": 1.0 / (t_render + t_sr), "unit": "frames/s", "cores": orc.num_threads, "kind": "port",
             "sample": sample}
 
 
 def cpu_baseline_reference():
-    """The REFERENCE's own PyTorch CPU renderer + SR on the same frame (scripts/time_reference_cpu.py).  It can only run where the
-    reference checkout exists (the build container, not the GPU box), so the committed measurement is reported, with where / when /
-    how many cores stated -- next to `cpu_baseline` (the C port timed on THIS box in THIS run)."""
-    path = os.path.join(ROOT, "profiles", "cpu_reference_r02.json")
-    try:
-        r = json.load(open(path))
-    except Exception:
+    """The REFERENCE's own PyTorch CPU renderer + SR on the same frame (modules/eg3ds/volumetric_rendering/renderer.py:118-167 +
+    models/superresolution.py:348-359), timed IN THIS RUN on this box's host cores whenever a reference checkout is reachable
+    (R3D_REFERENCE or /root/reference; scripts/time_reference_cpu.py in a subprocess, so that its torch thread settings and module
+    stand-ins stay out of this process).  The GPU box of the driver has no checkout: the committed measurement of the build container
+    is then reported, and says so."""
+    ref = os.environ.get("R3D_REFERENCE", "/root/reference")
+    r, measured = None, None
+    if os.path.isdir(os.path.join(ref, "modules", "eg3ds")):
+        try:
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "time_reference_cpu.py")], capture_output=True, text=True,
+                                 timeout=900, cwd="/tmp", env={**os.environ, "PYTHONDONTWRITEBYTECODE": "1", "R3D_REFERENCE": ref})
+            r = json.loads(out.stdout)
+            measured = "in this run, on this box's %d host cores (reference checkout %s)" % (r["cores"], ref)
+        except Exception as e:      # noqa: BLE001
+            r, measured = None, "in-run measurement failed (%s)" % type(e).__name__
+    if r is None:
+        for name in ("cpu_reference_r03.json", "cpu_reference_r02.json"):
+            try:
+                r = json.load(open(os.path.join(ROOT, "profiles", name)))
+            except Exception:       # noqa: BLE001
+                continue
+            measured = "NOT in this run: no reference checkout on this box; committed measurement profiles/%s (%s, %s, %d cores)%s" % (
+                name, r.get("where", "?"), r.get("when", "?"), r["cores"], "" if measured is None else "; " + measured)
+            break
+    if r is None:
         return None
     return {"value": round(r["value"], 4), "unit": r["unit"], "cores": r["cores"], "kind": "reference",
             "sample": "1 full frame: reference ImportanceRenderer.forward R=128 48+48 (%.2fs) + SuperresolutionHybrid8XDC.forward "
-                      "128^2->512^2 (%.2fs), torch %s CPU" % (r["render_s"], r["sr_s"], r["torch"]),
-            "measured": "%s, %s, %d cores; committed as profiles/cpu_reference_r02.json (the GPU box has no reference checkout)"
-                        % (r["where"], r["when"], r["cores"])}
+                      "128^2->512^2 (%.2fs), torch %s CPU, best of 3" % (r["render_s"], r["sr_s"], r["torch"]),
+            "measured": measured}
 
 
 def build_torso_frame(torch, dev, G, seed=7):
@@ -195,6 +213,97 @@ def build_torso_frame(torch, dev, G, seed=7):
     fl += 2 * 2 * 9 * 256 * 256 * px                                                               # head_torso_block conv0 + conv1
     fl += 2 * 512 * 64 * px + 2 * 9 * 64 * 256 * px + 2 * 9 * 256 * 256 * px                      # fuse_fg_bg_convs
     return frame, fl
+
+
+def clip125(torch, dev, G, scene, clip, streams):
+    """BASELINE configs[2] on ONE GPU: the 125 frames of a 5 s clip @ 25 fps through the stream pipeline into a device ring (the 8-GPU
+    run shards the same clip: bench.py --gpus 8 --clip 125)."""
+    from real3dportrait_amd.frames import PipelinedClipRenderer
+    cano, residuals, cams = scene
+    n = 125
+    import numpy as np
+    from real3dportrait_amd import synth
+    cams125 = torch.from_numpy(np.ascontiguousarray(synth.camera_sweep(n, -0.4, 0.4))).to(dev)
+    pipe = PipelinedClipRenderer(G, cano, residuals, cams125, clip.ws, base_seed=clip.base_seed, n_streams=max(1, streams))
+    ring = torch.zeros(n, 512, 512, 3, dtype=torch.uint8, device=dev)
+    best = 1e9
+    for rep in range(3):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for t in range(n):
+            pipe.render_u8(t, out=ring[t:t + 1])
+        pipe.sync(); torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t1)
+    return {"what": "125-frame clip (5 s @ 25 fps) on one GPU, %d streams, uint8 ring; best of 3" % max(1, streams), "ms_per_clip": round(best * 1e3, 2),
+            "fps": round(n / best, 1), "realtime_factor": round(n / best / 25.0, 1)}
+
+
+def cfg5_stress(torch, dev, lib):
+    """BASELINE configs[4]: N = 8 novel-view cameras of one tri-plane per batch, R = 256, 96 + 96 samples, SR 256^2 -> 512^2 -> 1024^2 (the
+    reference SR asserts a 512 output, superresolution.py:334: as SURVEY 8(d) defines it, the same two SynthesisBlocks at twice the size)."""
+    import ctypes
+    import numpy as np
+    from real3dportrait_amd import ImportanceRenderer, OSGDecoder, RaySampler, SynthesisBlock, synth, _lib
+    from real3dportrait_amd.superresolution import chain_fold, const_bound
+    N, R, Nc, Nf = 8, 256, 96, 96
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    planes = T(synth.synth_planes(7, N=1)).repeat(N, 1, 1, 1, 1)
+    dn = synth.synth_decoder(7, sigma_bias=4.0)
+    dec = OSGDecoder().to(dev)
+    with torch.no_grad():
+        dec.net[0].weight.copy_(T(dn[0])); dec.net[0].bias.copy_(T(dn[1])); dec.net[2].weight.copy_(T(dn[2])); dec.net[2].bias.copy_(T(dn[3]))
+    cams = T(synth.camera_sweep(N, -0.4, 0.4))
+    b0 = SynthesisBlock(32, 256, w_dim=512, resolution=512, img_channels=3, is_last=False, conv_clamp=None).to(dev)
+    b1 = SynthesisBlock(256, 128, w_dim=512, resolution=1024, img_channels=3, is_last=True, conv_clamp=None).to(dev)
+    with torch.no_grad():
+        for blk, p in zip((b0, b1), synth.synth_sr_params(7)):
+            for name in ("conv0", "conv1", "torgb"):
+                l = getattr(blk, name); w, b, aw, ab = p[name]
+                l.weight.copy_(T(w)); l.bias.copy_(T(b)); l.affine.weight.copy_(T(aw)); l.affine.bias.copy_(T(ab))
+    b0.out_format = "split"; b1.return_x = False
+    ren = ImportanceRenderer(hp={}); ren.noise_mode = "hash"; ren.seed = 5
+    opts = {"ray_start": "auto", "ray_end": "auto", "box_warp": 1.0, "depth_resolution": Nc, "depth_resolution_importance": Nf,
+            "disparity_space_sampling": False, "clamp_mode": "softplus", "white_back": False}
+    ws = torch.ones(N, 3, 512, device=dev)
+    rs = RaySampler()
+    nhwc = ren.prepare_planes(planes)
+
+    def batch():
+        o, d = rs(cams[:, :16].view(-1, 4, 4), cams[:, 16:].view(-1, 3, 3), R)
+        feat, depth, wsum, valid = ren(nhwc, dec, o, d, opts)
+        fimg = feat.permute(0, 2, 1).reshape(N, 32, R, R).contiguous()
+        prep0, prep1 = b0.prepare(ws, dev), b1.prepare(ws, dev)
+        b0._depth_in, b1._depth_in = 0, 2
+        chain_fold([b0.chain_op(-1), b1.chain_op(0)], N, [const_bound(1.01, N, dev)])
+        x, rgb = b0(fimg, fimg[:, :3].contiguous(), ws, noise_mode="none", _prepared=prep0, _next=b1, _folded=True)
+        return b1(x, rgb, ws, noise_mode="none", _prepared=prep1, _folded=True)[1]
+    for _ in range(2):
+        img = batch()
+    torch.cuda.synchronize()
+    assert tuple(img.shape) == (N, 3, 1024, 1024) and bool(torch.isfinite(img).all())
+    lib.r3d_profile_configure(0x7F); lib.r3d_profile_reset()
+    reps = 4
+    t1 = time.perf_counter()
+    for _ in range(reps):
+        batch()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t1) / reps
+    ms, cnt = ctypes.c_double(0), ctypes.c_int(0)
+    fam = {}
+    for j, nme in enumerate(["render", "conv_mfma", "upconv_fir", "torgb", "sr_pack", "layout", "misc"]):
+        _lib.check(lib.r3d_profile_read(j, ctypes.byref(ms), ctypes.byref(cnt)), "profile_read")
+        fam[nme] = round(ms.value / reps, 4)
+    lib.r3d_profile_configure(0)
+    flops = N * sum(conv_flops_per_frame(256))
+    conv_ms = fam["conv_mfma"] + fam["upconv_fir"]
+    S = N * R * R * (Nc + Nf)
+    return {"what": "N=8 cameras per batch, R=256, 96+96 samples, SR 256^2 -> 1024^2 (f16x3), one stream",
+            "ms_per_batch": round(dt * 1e3, 3), "fps": round(N / dt, 1), "breakdown_ms_per_batch": fam,
+            "roofline": {"bound": "mfma", "achieved": round(flops / (conv_ms * 1e-3) / 1e12, 2), "peak": PEAK_F16_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(flops / (conv_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4), "conv_gflop_per_batch": round(flops / 1e9, 1),
+                         "note": "all four SR convolutions of the batch (algorithmic FLOPs / summed conv kernel time)"},
+            "render_kernel": {"ms": fam["render"], "algorithmic_GBps": round(S * 1536 / (fam["render"] * 1e-3) / 1e9, 1),
+                              "note": "gather-bound view (SURVEY 8d): S * 1536 B of taps, served by L1 / L2"}}
 
 
 def main():
@@ -271,24 +380,29 @@ def main():
         step(i % K)
     if pipe is not None:
         pipe.sync()
-    from real3dportrait_amd.frames import gather_frames
+    from real3dportrait_amd.frames import ClipGatherer
     total_frames = args.clip if args.clip > 0 else K * world
+    # clip assembly on rank 0: r3d_gather_frames behind the C ABI (grouped ncclSend / ncclRecv over RCCL) into ONE pre-allocated buffer
+    gatherer = ClipGatherer(K, (512, 512), dev, backend="r3d" if use_dist else "torch")
     if use_dist:                                         # warm the gather path too
-        clip_out = gather_frames(ring, total_frames)
+        clip_out = gatherer.gather(ring, total_frames)
     import ctypes
     lib.r3d_profile_configure(1 << 1); lib.r3d_profile_reset()      # event pairs around the dominant kernel, on its launch stream
-    barrier()
-    t0 = time.perf_counter()
-    for i in range(K_mine):
-        step(i)
-    if pipe is not None:
-        pipe.sync()
-    if use_dist:
-        clip_out = gather_frames(ring, total_frames)
-        if rank == 0:
-            assert clip_out.shape == (total_frames, 512, 512, 3)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def timed_region():
+        barrier()
+        t0 = time.perf_counter()
+        for i in range(K_mine):
+            step(i)
+        if pipe is not None:
+            pipe.sync()
+        if use_dist:
+            clip_out = gatherer.gather(ring, total_frames)
+            if rank == 0:
+                assert clip_out.shape == (total_frames, 512, 512, 3)
+        barrier()
+        return time.perf_counter() - t0
+
+    elapsed = timed_region()                             # THE measurement (`value`): W warm-up steps, then exactly K timed steps
     lib.r3d_profile_configure(0)
     tms, tcnt = ctypes.c_double(0), ctypes.c_int(0)
     _lib.check(lib.r3d_profile_read(1, ctypes.byref(tms), ctypes.byref(tcnt)), "profile_read")
@@ -297,6 +411,13 @@ def main():
     if use_dist:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
+    # the same K-step region four more times, back to back (run-to-run spread of a 15 ms measurement; `value` stays the first one)
+    rep_s = [elapsed]
+    for _ in range(4):
+        e = torch.tensor([timed_region()], device=dev, dtype=torch.float64)
+        if use_dist:
+            dist.all_reduce(e, op=dist.ReduceOp.MAX)
+        rep_s.append(float(e.item()))
 
     # ---- roofline of the dominant kernel (conv_mfma_f16x3_kernel: the two plain 3x3 convs of a frame), MFMA-bound ----
     # HIP event pairs recorded on the launch stream around every conv launch.  With frames pipelined over several
@@ -381,6 +502,10 @@ def main():
                                             "triplane.py:131-132) are computed once per clip; every per-frame input (planes = cano + residual_t, camera, "
                                             "sampling noise) is processed inside the timed region"},
                "roofline": roofline}
+        rep_fps = sorted(total_frames / t for t in rep_s)
+        out["repeats"] = {"n": len(rep_s), "what": "the timed region run 5 times back to back (the first one is `value`)",
+                          "fps": [round(total_frames / t, 1) for t in rep_s], "median": round(rep_fps[len(rep_fps) // 2], 1),
+                          "min": round(rep_fps[0], 1), "max": round(rep_fps[-1], 1)}
         if single_stream_fps is not None:
             out["value_single_stream"] = round(single_stream_fps, 2)
             out["stream_pipelining_gain"] = round(fps / world / single_stream_fps, 4)
@@ -421,6 +546,39 @@ def main():
             alt["R512_48+%d_fps" % nf] = round(5 / (time.perf_counter() - t1), 2)
         out["alt_neural_render_512"] = alt
 
+        # ---- the same frames through the drop-in API: TriPlaneGenerator.synthesis(ws, camera, use_cached_backbone=True) on a generator
+        # whose operators were installed by patch_model() -- what inference/real3d_infer.py:486-492 gets per frame: planes handed over
+        # NCHW as `cano + secc` (secc_img2plane.py:76-77), depth image + global clamp, image_raw, image_feature, the fp32 image, the dict.
+        from real3dportrait_amd import patch_model
+        from real3dportrait_amd.frames import clone_generator_shell, frame_seed
+        G_api = patch_model(clone_generator_shell(G))
+        G_api.renderer.noise_mode = "hash"
+        ws_api = torch.ones(1, 14, 512, device=dev)
+
+        def api_frame(t):
+            G_api.renderer.seed = frame_seed(clip.base_seed, t)
+            G_api._last_planes = (cano + residuals[t % len(residuals)]).view(1, 96, 256, 256)
+            return G_api.synthesis(ws_api, cams[t:t + 1], use_cached_backbone=True, noise_mode="none")
+        for i in range(4):
+            ret = api_frame(i)
+        torch.cuda.synchronize()
+        assert tuple(ret["image"].shape) == (1, 3, 512, 512) and tuple(ret["image_raw"].shape) == (1, 3, 128, 128) \
+            and tuple(ret["image_depth"].shape) == (1, 1, 128, 128) and tuple(ret["image_feature"].shape) == (1, 29, 128, 128)
+        ref_u8 = clip.render_u8(3).clone()
+        api_u8 = ((ret["image"][0].permute(1, 2, 0) + 1) / 2 * 255).int().clamp(0, 255).to(torch.uint8)
+        api_equal = bool(torch.equal(api_u8, ref_u8))
+        nb = 40
+        t1 = time.perf_counter()
+        for i in range(nb):
+            ret = api_frame(i)
+        torch.cuda.synchronize()
+        t_api = (time.perf_counter() - t1) / nb
+        out["value_synthesis_api"] = {
+            "what": "TriPlaneGenerator.synthesis() per frame on ONE stream through patch_model()'d operators: `cano + secc` add (torch), layout, rays, "
+                    "fused ray kernel WITH the depth image + clamp, SR with the fp32 image, clamps, the reference's output dict",
+            "value": round(1.0 / t_api, 2), "ms_per_frame": round(t_api * 1e3, 4), "vs_value_single_stream": round(1.0 / t_api / single_stream_fps, 4) if single_stream_fps else None,
+            "frame_equals_uint8_ring_frame": api_equal}
+
         # the same W + K measurement from an idle (cold-clock) GPU, i.e. without the device warm-up: what the first K frames after a pause cost
         if pipe is not None and args.device_warmup_ms > 0:
             torch.cuda.synchronize(); time.sleep(0.25)
@@ -432,6 +590,8 @@ def main():
                 step(i)
             pipe.sync(); torch.cuda.synchronize()
             out["value_cold_start"] = round(K / (time.perf_counter() - t1), 2)
+            out["value_r01_protocol"] = {"value": out["value_cold_start"], "note": "no device warm-up in front of the W + K steps: the protocol of the round-1 "
+                                         "number (1 052); compare rounds on this field, `value` carries the warm-up described in config.device_warmup"}
 
     # ---- BASELINE config 4 surrogate: the per-frame hot path of the shipped torso model (extra, rank 0 of a 1-GPU run) ----
     if rank == 0 and world == 1 and not args.no_extras:
@@ -474,6 +634,11 @@ def main():
                               "roofline": {"bound": "mfma", "achieved": round(tf_flops / (conv_ms * 1e-3) / 1e12, 2), "peak": PEAK_F16_MFMA_TFLOPS,
                                            "unit": "TFLOP/s", "frac": round(tf_flops / (conv_ms * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS, 4),
                                            "note": "all conv kernels of the frame (algorithmic FLOPs / summed conv time)"}}
+
+    # ---- BASELINE configs[2] on one GPU and configs[4] (stress) -- extras, rank 0 of a 1-GPU run ----------------------------------------
+    if rank == 0 and world == 1 and not args.no_extras:
+        out["clip125_1gpu"] = clip125(torch, dev, G, scene, clip, args.streams)
+        out["cfg5_stress"] = cfg5_stress(torch, dev, lib)
 
     # ---- the opt-in R3D_SR_F16MX precision (fp8 block-scaled MFMA for the conv correction products): same frames, own parity tier ----
     if rank == 0 and world == 1 and not args.no_extras and prec == "f16x3":

@@ -496,33 +496,71 @@ static void modulate(const float* Wt /*[Co][Ci][k][k]*/, const float* styles, in
 /* plain 3x3 correlation, pad 1 (F.conv2d; conv2d_resample.py:139-141 fast path) NCHW one image.
  * Output-stationary bands of BAND rows x one output channel (the band of y stays in L1 while all input channels and taps stream
  * past); every output element is still accumulated in the order (c, ky, kx), so the result does not depend on BAND or threads. */
+/* Grow-only scratch buffers that survive between calls (the oracle is single-caller test infrastructure): a fresh 270 MB calloc per
+ * convolution costs more page faults than the convolution costs arithmetic on a many-core host. */
+static float* scratch_buf(int slot, size_t floats)
+{
+    static float* buf[4];
+    static size_t cap[4];
+    if (cap[slot] < floats) {
+        free(buf[slot]);
+        buf[slot] = (float*)malloc(sizeof(float) * floats);
+        cap[slot] = buf[slot] ? floats : 0;
+    }
+    return buf[slot];
+}
+/* zero-padded copy [C][H + 2][Wp] of x [C][H][W] (interior at row + 1, column + 1) */
+static float* padded_copy(int slot, const float* x, int Ci, int Hh, int Ww, int Wp)
+{
+    const int Hp = Hh + 2;
+    float* xp = scratch_buf(slot, (size_t)Ci * Hp * Wp);
+    if (!xp) return NULL;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int c = 0; c < Ci; ++c)
+        for (int yy = 0; yy < Hp; ++yy) {
+            float* row = xp + ((size_t)c * Hp + yy) * Wp;
+            if (yy == 0 || yy == Hp - 1) { memset(row, 0, sizeof(float) * (size_t)Wp); continue; }
+            row[0] = 0.0f;
+            memcpy(row + 1, x + ((size_t)c * Hh + yy - 1) * Ww, sizeof(float) * (size_t)Ww);
+            memset(row + 1 + Ww, 0, sizeof(float) * (size_t)(Wp - 1 - Ww));
+        }
+    return xp;
+}
+
 #define R3D_BAND 8
+#define R3D_OB 4          /* output channels per register tile */
+#define R3D_XB 16         /* pixels per register tile */
+/* Register-tiled: a tile of R3D_OB output channels x R3D_XB pixels of one row stays in registers while all input channels and taps stream
+ * past a zero-padded copy of the input (so the taps need no bounds tests; an out-of-image tap adds w * 0).  Every output element is still
+ * accumulated from zero in the order (c, ky, kx): the result is bit-identical to the plain loop nest and independent of the tiling. */
 static void conv3x3(const float* x, int Ci, int Hh, int Ww, const float* w /*[Co][Ci][3][3]*/, int Co, float* y)
 {
-    const int nb = (Hh + R3D_BAND - 1) / R3D_BAND;
+    const int Hp = Hh + 2, Wp = Ww + 2 + R3D_XB;        /* + R3D_XB: the last (partial) pixel tile reads past the row end inside the copy */
+    float* xp = padded_copy(0, x, Ci, Hh, Ww, Wp);
+    if (!xp) return;
+    const int nob = (Co + R3D_OB - 1) / R3D_OB;
 #pragma omp parallel for collapse(2) schedule(static)
-    for (int o = 0; o < Co; ++o)
-        for (int b = 0; b < nb; ++b) {
-            const int r0 = b * R3D_BAND, r1 = r0 + R3D_BAND < Hh ? r0 + R3D_BAND : Hh;
-            float* yo = y + (size_t)o * Hh * Ww;
-            memset(yo + (size_t)r0 * Ww, 0, sizeof(float) * (size_t)(r1 - r0) * Ww);
-            for (int c = 0; c < Ci; ++c) {
-                const float* xc = x + (size_t)c * Hh * Ww;
-                const float* wk = w + ((size_t)o * Ci + c) * 9;
-                for (int ky = 0; ky < 3; ++ky)
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const float wv = wk[ky * 3 + kx];
-                        const int dy = ky - 1, dx = kx - 1;
-                        int y0 = dy < 0 ? -dy : 0, y1 = dy > 0 ? Hh - dy : Hh;
-                        const int x0 = dx < 0 ? -dx : 0, x1 = dx > 0 ? Ww - dx : Ww;
-                        if (y0 < r0) y0 = r0;
-                        if (y1 > r1) y1 = r1;
-                        for (int yy = y0; yy < y1; ++yy) {
-                            float* yr = yo + (size_t)yy * Ww;
-                            const float* xr = xc + (size_t)(yy + dy) * Ww + dx;
-                            for (int xx = x0; xx < x1; ++xx) yr[xx] += wv * xr[xx];
+    for (int ob = 0; ob < nob; ++ob)
+        for (int yy = 0; yy < Hh; ++yy) {
+            const int o0 = ob * R3D_OB, on = o0 + R3D_OB <= Co ? R3D_OB : Co - o0;
+            for (int xb = 0; xb < Ww; xb += R3D_XB) {
+                float acc[R3D_OB][R3D_XB];
+                for (int o = 0; o < R3D_OB; ++o)
+                    for (int i = 0; i < R3D_XB; ++i) acc[o][i] = 0.0f;
+                for (int c = 0; c < Ci; ++c) {
+                    const float* xc = xp + ((size_t)c * Hp + yy) * Wp + xb;
+                    for (int ky = 0; ky < 3; ++ky)
+                        for (int kx = 0; kx < 3; ++kx) {
+                            const float* xr = xc + (size_t)ky * Wp + kx;
+                            for (int o = 0; o < on; ++o) {
+                                const float wv = w[((size_t)(o0 + o) * Ci + c) * 9 + ky * 3 + kx];
+#pragma omp simd
+                                for (int i = 0; i < R3D_XB; ++i) acc[o][i] += wv * xr[i];
+                            }
                         }
-                    }
+                }
+                const int nx = xb + R3D_XB <= Ww ? R3D_XB : Ww - xb;
+                for (int o = 0; o < on; ++o) memcpy(y + ((size_t)(o0 + o) * Hh + yy) * Ww + xb, acc[o], sizeof(float) * (size_t)nx);
             }
         }
 }
@@ -538,31 +576,44 @@ static void upconv3x3(const float* x, int Ci, int Hh, int Ww, const float* w /*[
     static const float f1[4] = { 1.0f, 3.0f, 3.0f, 1.0f };
     float f2[4][4];
     for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) f2[a][b] = (f1[a] * f1[b] / 64.0f) * 4.0f;
-    float* Tall = (float*)malloc(sizeof(float) * (size_t)Co * Th * Tw);
+    float* Tall = scratch_buf(1, (size_t)Co * Th * Tw);
     if (!Tall) return;
-    const int tband = 2 * R3D_BAND, nb = (Th + tband - 1) / tband;
+    /* T[o][2 iy + ky][2 ix + kx] += w[o][c][ky][kx] * x[c][iy][ix].  Register-tiled like conv3x3: one T row of R3D_OB output channels is
+     * built in two column-parity halves (even columns take kx = 0 from ix = j and kx = 2 from ix = j - 1; odd columns kx = 1), from a
+     * zero-padded copy of x; per T element the terms arrive in the order (c, ky, kx), as in the plain scatter loop. */
+    const int Hp = Hh + 2, Wp = Ww + 2 + R3D_XB;
+    float* xp = padded_copy(2, x, Ci, Hh, Ww, Wp);
+    if (!xp) return;
+    const int nob = (Co + R3D_OB - 1) / R3D_OB;
+    const int ne = Ww + 1;                               /* even columns tx = 2 j, j = 0..Ww; odd columns tx = 2 j + 1, j = 0..Ww-1 */
 #pragma omp parallel for collapse(2) schedule(static)
-    for (int o = 0; o < Co; ++o)
-        for (int b = 0; b < nb; ++b) {
-            const int t0 = b * tband, t1 = t0 + tband < Th ? t0 + tband : Th;
-            float* T = Tall + (size_t)o * Th * Tw;
-            memset(T + (size_t)t0 * Tw, 0, sizeof(float) * (size_t)(t1 - t0) * Tw);
-            for (int c = 0; c < Ci; ++c) {
-                const float* xc = x + (size_t)c * Hh * Ww;
-                const float* wk = w + ((size_t)o * Ci + c) * 9;
-                for (int ky = 0; ky < 3; ++ky)
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const float wv = wk[ky * 3 + kx];
-                        /* T row 2*iy + ky in [t0, t1) */
-                        int i0 = (t0 - ky + 1) / 2, i1 = (t1 - ky + 1) / 2;
-                        if (i0 < 0) i0 = 0;
-                        if (i1 > Hh) i1 = Hh;
-                        for (int iy = i0; iy < i1; ++iy) {
-                            float* tr = T + (size_t)(2 * iy + ky) * Tw + kx;
-                            const float* xr = xc + (size_t)iy * Ww;
-                            for (int ix = 0; ix < Ww; ++ix) tr[2 * ix] += wv * xr[ix];
+    for (int ob = 0; ob < nob; ++ob)
+        for (int ty = 0; ty < Th; ++ty) {
+            const int o0 = ob * R3D_OB, on = o0 + R3D_OB <= Co ? R3D_OB : Co - o0;
+            /* rows of x feeding this T row: ky with (ty - ky) even and 0 <= (ty - ky) / 2 < Hh; padded row index = iy + 1 */
+            int kys[2], iys[2], nk = 0;
+            for (int ky = 0; ky < 3; ++ky) { const int d = ty - ky; if (d >= 0 && !(d & 1) && d / 2 < Hh) { kys[nk] = ky; iys[nk] = d / 2; ++nk; } }
+            for (int jb = 0; jb < ne; jb += R3D_XB) {
+                float ae[R3D_OB][R3D_XB], ao[R3D_OB][R3D_XB];
+                for (int o = 0; o < R3D_OB; ++o)
+                    for (int i = 0; i < R3D_XB; ++i) { ae[o][i] = 0.0f; ao[o][i] = 0.0f; }
+                for (int c = 0; c < Ci; ++c)
+                    for (int k = 0; k < nk; ++k) {
+                        const float* xr = xp + ((size_t)c * Hp + iys[k] + 1) * Wp + 1 + jb;       /* xr[i] = x[c][iy][jb + i], xr[-1] = left neighbour / 0 */
+                        for (int o = 0; o < on; ++o) {
+                            const float* wk = w + ((size_t)(o0 + o) * Ci + c) * 9 + kys[k] * 3;
+                            const float w0 = wk[0], w1 = wk[1], w2 = wk[2];
+#pragma omp simd
+                            for (int i = 0; i < R3D_XB; ++i) { ae[o][i] += w0 * xr[i]; ae[o][i] += w2 * xr[i - 1]; ao[o][i] += w1 * xr[i]; }
                         }
                     }
+                for (int o = 0; o < on; ++o) {
+                    float* tr = Tall + ((size_t)(o0 + o) * Th + ty) * Tw;
+                    for (int i = 0; i < R3D_XB && jb + i < ne; ++i) {
+                        tr[2 * (jb + i)] = ae[o][i];
+                        if (jb + i < Ww) tr[2 * (jb + i) + 1] = ao[o][i];
+                    }
+                }
             }
         }
 #pragma omp parallel for collapse(2) schedule(static)
@@ -584,7 +635,6 @@ static void upconv3x3(const float* x, int Ci, int Hh, int Ww, const float* w /*[
                 yo[(size_t)yy * Ow + xx] = acc;
             }
         }
-    free(Tall);
 }
 
 /* bias_act: lrelu(alpha .2)*sqrt(2) or linear  (bias_act.py:93-122; networks_stylegan2.py:339-341) */
@@ -684,6 +734,20 @@ R3D_API int r3d_oracle_upsample2x_bilinear(const float* x, int Cc, int Hh, int W
     return 0;
 }
 
+/* toRGB 1x1 mod-conv for a chunk of pixels: acc[i] = sum_c x[c][i] * w[c], every pixel accumulated from zero in channel order (as the
+ * per-pixel loop did), but walking each channel plane contiguously */
+#define R3D_PXB 256
+static void torgb_chunk(const float* x, size_t plane, const float* w, int Cc, size_t n, float* acc)
+{
+    for (size_t i = 0; i < n; ++i) acc[i] = 0.0f;
+    for (int c = 0; c < Cc; ++c) {
+        const float wv = w[c];
+        const float* xc = x + (size_t)c * plane;
+#pragma omp simd
+        for (size_t i = 0; i < n; ++i) acc[i] += xc[i] * wv;
+    }
+}
+
 /* One SynthesisBlockNoUp (architecture 'skip', in_channels != 0)  modules/eg3ds/models/superresolution.py:215-250:
  *   conv0 :233 and conv1 :234 are both up=1 SynthesisLayers, img.add_(torgb(x)) :247 with no upsample (:241-243).
  * x [Ci][H][W], img [3][H][W] -> x_out [Co][H][W], img_out [3][H][W]. */
@@ -720,12 +784,15 @@ R3D_API int r3d_oracle_sr_block_noup(const float* x, const float* img, int Ci, i
         float* yo = img_out + (size_t)o * hw;
         const float* io = img + (size_t)o * hw;
 #pragma omp parallel for schedule(static)
-        for (size_t i = 0; i < hw; ++i) {
-            float acc = 0.0f;
-            for (int c = 0; c < Co; ++c) acc += x_out[(size_t)c * hw + i] * wm2[(size_t)o * Co + c];
-            float v = acc + rgb_b[o];
-            if (clampv >= 0.0f) { if (v > clampv) v = clampv; if (v < -clampv) v = -clampv; }
-            yo[i] = io[i] + v;
+        for (size_t i0 = 0; i0 < hw; i0 += R3D_PXB) {
+            float accv[R3D_PXB];
+            const size_t n = i0 + R3D_PXB <= hw ? R3D_PXB : hw - i0;
+            torgb_chunk(x_out + i0, hw, wm2 + (size_t)o * Co, Co, n, accv);
+            for (size_t i = 0; i < n; ++i) {
+                float v = accv[i] + rgb_b[o];
+                if (clampv >= 0.0f) { if (v > clampv) v = clampv; if (v < -clampv) v = -clampv; }
+                yo[i0 + i] = io[i0 + i] + v;
+            }
         }
     }
     free(st); free(wm0); free(wm1); free(wm2); free(t0);
@@ -771,12 +838,15 @@ R3D_API int r3d_oracle_sr_block(const float* x, const float* img, int Ci, int Co
     for (int o = 0; o < 3; ++o) {
         float* yo = img_out + (size_t)o * ohw;
 #pragma omp parallel for schedule(static)
-        for (size_t i = 0; i < ohw; ++i) {
-            float acc = 0.0f;
-            for (int c = 0; c < Co; ++c) acc += x_out[(size_t)c * ohw + i] * wm2[(size_t)o * Co + c];
-            float v = acc + rgb_b[o];
-            if (clampv >= 0.0f) { if (v > clampv) v = clampv; if (v < -clampv) v = -clampv; }
-            yo[i] += v;
+        for (size_t i0 = 0; i0 < ohw; i0 += R3D_PXB) {
+            float accv[R3D_PXB];
+            const size_t n = i0 + R3D_PXB <= ohw ? R3D_PXB : ohw - i0;
+            torgb_chunk(x_out + i0, ohw, wm2 + (size_t)o * Co, Co, n, accv);
+            for (size_t i = 0; i < n; ++i) {
+                float v = accv[i] + rgb_b[o];
+                if (clampv >= 0.0f) { if (v > clampv) v = clampv; if (v < -clampv) v = -clampv; }
+                yo[i0 + i] += v;
+            }
         }
     }
     free(st); free(wm0); free(wm1); free(wm2); free(t0);

@@ -24,21 +24,78 @@ def frame_seed(base_seed, frame_index):
     return (int(base_seed) * 0x9E3779B97F4A7C15 + int(frame_index) * 0xD1B54A32D192ED03 + 1) & 0xFFFFFFFFFFFFFFFF
 
 
+class ClipGatherer:
+    """Re-assembles a frame-sharded clip on rank 0 into ONE pre-allocated buffer [world, per, H, W, 3] (no per-call allocation, no
+    concatenation: with contiguous chunks of `per` frames, frame t of the clip is row t of the flattened buffer).
+
+    backend 'r3d'   : r3d_gather_frames behind the C ABI (grouped ncclSend / ncclRecv on the caller's stream, csrc/r3d_comm.hip); the
+                      RCCL communicator is created here, its 128-byte id travels over the torch.distributed process group;
+    backend 'torch' : torch.distributed.gather into views of the same buffer (any backend; gloo in the CPU tests).
+    Without an initialised process group the local ring is the clip."""
+
+    def __init__(self, per, frame_hw=(512, 512), device="cuda", backend="torch", group=None):
+        self.per, self.hw, self.group, self.backend = int(per), tuple(frame_hw), group, backend
+        self.dist = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.dist else 1
+        self.rank = dist.get_rank(group) if self.dist else 0
+        self.root_buf, self._comm, self._lib = None, None, None
+        if not self.dist:
+            return
+        if self.rank == 0:
+            self.root_buf = torch.empty(self.world, self.per, self.hw[0], self.hw[1], 3, dtype=torch.uint8, device=device)
+        if backend == "r3d":
+            import ctypes
+            from . import _lib
+            self._lib = _lib
+            lib = _lib.load()
+            uid = (ctypes.c_char * 128)()
+            if self.rank == 0:
+                _lib.check(lib.r3d_comm_unique_id(ctypes.cast(uid, ctypes.c_void_p)), "comm_unique_id")
+            box = [bytes(uid.raw)]
+            dist.broadcast_object_list(box, src=0, group=group)
+            uid = (ctypes.c_char * 128).from_buffer_copy(box[0])
+            comm = ctypes.c_void_p()
+            _lib.check(lib.r3d_comm_init(ctypes.cast(uid, ctypes.c_void_p), self.rank, self.world, ctypes.byref(comm)), "comm_init")
+            self._comm = comm
+        elif backend != "torch":
+            raise ValueError("backend must be 'r3d' or 'torch'")
+
+    def gather(self, local, num_frames):
+        """local: uint8 [per, H, W, 3] on every rank (tail rows of the last chunks unused).  Returns the clip [num_frames, H, W, 3] (a
+        view of the pre-allocated buffer) on rank 0, None elsewhere."""
+        assert tuple(local.shape) == (self.per, self.hw[0], self.hw[1], 3) and local.dtype == torch.uint8 and local.is_contiguous()
+        if not self.dist:
+            return local[:num_frames]
+        if self.backend == "r3d":
+            lib = self._lib.load()
+            self._lib.check(lib.r3d_gather_frames(self._comm, local.data_ptr(), local.numel(),
+                                                  None if self.root_buf is None else self.root_buf.data_ptr(), 0, self._lib.stream_ptr()),
+                            "gather_frames")
+        else:
+            dist.gather(local, [self.root_buf[r] for r in range(self.world)] if self.rank == 0 else None, dst=0, group=self.group)
+        if self.rank != 0:
+            return None
+        return self.root_buf.view(self.world * self.per, self.hw[0], self.hw[1], 3)[:num_frames]
+
+    def close(self):
+        if self._comm is not None:
+            self._lib.load().r3d_comm_destroy(self._comm)
+            self._comm = None
+
+
+_GATHERERS = {}
+
+
 def gather_frames(local, num_frames, group=None):
-    """local: uint8 [per, H, W, 3] on every rank (per = ceil(T/W), tail rows unused).
-    Returns uint8 [T, H, W, 3] on rank 0 and None elsewhere."""
+    """local: uint8 [per, H, W, 3] on every rank (per = ceil(T/W), tail rows unused).  Returns uint8 [T, H, W, 3] on rank 0 (a view of a
+    buffer that is allocated once per shape and reused by the next call) and None elsewhere."""
     if not (dist.is_available() and dist.is_initialized()):
         return local[:num_frames]
-    world, rank = dist.get_world_size(group), dist.get_rank(group)
-    bufs = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
-    dist.gather(local, bufs, dst=0, group=group)
-    if rank != 0:
-        return None
-    parts = []
-    for r in range(world):
-        lo, hi = shard_frames(num_frames, world, r)
-        parts.append(bufs[r][: hi - lo])
-    return torch.cat(parts, dim=0)
+    key = (tuple(local.shape), str(local.device), id(group))
+    g = _GATHERERS.get(key)
+    if g is None:
+        g = _GATHERERS[key] = ClipGatherer(local.shape[0], local.shape[1:3], local.device, "torch", group)
+    return g.gather(local.contiguous(), num_frames)
 
 
 def render_clip_sharded(render_frame, num_frames, frame_hw=(512, 512), device="cuda", group=None):

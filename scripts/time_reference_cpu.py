@@ -77,7 +77,7 @@ def main():
         "value": 1.0 / (t_render + t_sr), "unit": "frames/s", "cores": cores, "torch_threads": torch.get_num_threads(),
         "render_s": t_render, "sr_s": t_sr, "render_runs_s": all_r, "sr_runs_s": all_s,
         "torch": torch.__version__, "machine": platform.processor() or platform.machine(),
-        "where": "build container (the GPU box has no /root/reference)", "when": time.strftime("%Y-%m-%d"),
+        "where": "host %s" % platform.node(), "when": time.strftime("%Y-%m-%d"),
         "kind": "reference",
     }
     print(json.dumps(out, indent=1))

@@ -81,3 +81,60 @@ def test_torso_frames_on_three_streams_are_bit_identical():
         for t in range(6):
             assert torch.equal(out[t], ref[t]), (rep, t, float((out[t] - ref[t]).abs().max()))
     assert float(ref[0].std()) > 1e-3
+
+
+def test_warp_sr_forward_v2_batch_of_two_equals_two_singles():
+    """N = 2 through the fused forward (the per-sample bounds of a tagged activation sit one scales record apart: consumers need them
+    dense): a batch whose two samples differ in magnitude by 2^6 must equal the two samples run one by one."""
+    import torch
+    import warp_mock
+    from real3dportrait_amd.sr_with_ref import SuperresolutionHybrid8XDC_Warp
+    sr = SuperresolutionHybrid8XDC_Warp(32, 512, 0, True, torso_model=warp_mock.MockTorso(), hparams={"htbsr_head_threshold": 0.9}).cuda()
+    warp_mock.load_warp_params(sr, lambda blk, p: load_block(torch, blk, p), to=lambda a: T(torch, a))
+    i = {k: T(torch, v) for k, v in warp_mock.warp_inputs(N=2).items()}
+    i["x"][1] *= 64.0                                                      # per-sample range folding must not couple the samples
+    call = lambda sl: sr(i["x"][sl, :3].contiguous(), i["x"][sl].contiguous(), i["ws"][sl].contiguous(), i["ref_torso_rgb"][sl].contiguous(),
+                         i["ref_bg_rgb"][sl].contiguous(), i["weights_img"][sl].contiguous(), None, None, None, noise_mode="none")[0]
+    both = call(slice(0, 2)).cpu().numpy()
+    assert both.shape == (2, 3, 512, 512) and np.isfinite(both).all()
+
+    for n in range(2):
+        sr.torso_model = _PerSample(warp_mock.MockTorso(), n)
+        one = call(slice(n, n + 1)).cpu().numpy()
+        tol = 2e-5 * max(1.0, float(np.abs(both[n]).max()))
+        e = np.abs(one[0] - both[n]).max()
+        print("sample %d: batch vs single max diff %.2e (tol %.1e)" % (n, e, tol))
+        assert e <= tol
+
+
+def _PerSample(inner, n):
+    """Runs the stand-in torso network on a 2-sample batch built from the single sample and returns row n, so that a single-sample call
+    sees exactly the tensors sample n of the batch saw (the stand-in's noise depends on the batch index)."""
+    import torch
+
+    class PerSample(torch.nn.Module):
+        def forward(self, ref_torso_rgb_256, segmap, kp_s, kp_d, rgb_256, weights_256=None, cal_loss=True, target_torso_mask=None):
+            rep = lambda t: t.expand(2, -1, -1, -1).contiguous()
+            rgb_torso, ret = inner.forward(rep(ref_torso_rgb_256), segmap, kp_s, kp_d, rep(rgb_256), rep(weights_256), cal_loss, target_torso_mask)
+            return rgb_torso[n:n + 1].contiguous(), {k: v[n:n + 1].contiguous() for k, v in ret.items()}
+    return PerSample()
+
+
+def test_conv_to_convstack_chain_batch_of_two():
+    """Conv2d -> ConvStack with N = 2: the tagged bound of the first conv's output feeds the stack's fold (dense float[N] required)."""
+    import torch
+    from real3dportrait_amd.superresolution import Conv2d, ConvStack
+    torch.manual_seed(3)
+    c0 = Conv2d(16, 128, 3, 1, padding=1).cuda()
+    st = ConvStack(Conv2d(128, 128, 3, 1, padding=1), torch.nn.LeakyReLU(0.2), Conv2d(128, 128, 3, 1, padding=1)).cuda()
+    x = torch.randn(2, 16, 40, 40, device="cuda")
+    x[1] *= 300.0
+    y = st(c0(x, out_format="cb8"))
+    ref = torch.nn.functional.conv2d(x.double(), c0.weight.double(), c0.bias.double(), padding=1)
+    convs = [m for m in st if hasattr(m, "weight")]
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(ref, convs[0].weight.double(), convs[0].bias.double(), padding=1), 0.2)
+    ref = torch.nn.functional.conv2d(ref, convs[1].weight.double(), convs[1].bias.double(), padding=1)
+    for n in range(2):
+        e = float((y[n].double() - ref[n]).abs().max()) / float(ref[n].abs().max())
+        print("sample %d: rel err %.2e" % (n, e))
+        assert e <= 2e-5
