@@ -166,6 +166,110 @@ __global__ void raygen_kernel(const float* __restrict__ c2w, const float* __rest
     dirs[o] = dx / nrm; dirs[o + 1] = dy / nrm; dirs[o + 2] = dz / nrm;
 }
 
+// ray_marcher.py:46-50: nan_to_num(inf) then clamp to the global [min, max] of all depths of the call
+__global__ void depth_clamp_kernel(float* __restrict__ depth, int nrays, const int* __restrict__ gstate)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrays) return;
+    const float lo = ord2f(gstate[3]), hi = ord2f(gstate[4]);
+    float v = depth[r];
+    if (v != v) v = INFINITY;
+    depth[r] = fminf(fmaxf(v, lo), hi);
+}
+
+// -------------------------------------------------------------------------------------------------
+// Decoder weights staged in LDS in MFMA A-fragment order (shared by the block's waves)
+// -------------------------------------------------------------------------------------------------
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+// ---- fp16 range fold of the decoder (exact powers of two; the SR's counterpart is r3d_chain_fold) -------------------------------
+// The decoder runs on the f16 matrix pipe with every fp32 operand split into fp16 hi + lo: exact to ~2^-22 only while an operand sits
+// inside the fp16 window (max < 65504, typical values well above the 2^-24 subnormal step).  The reference computes in fp32 with no range
+// limit, so one launch per call derives exact power-of-two factors from guaranteed bounds:
+//   * features x (a convex combination of plane texels: |x| <= Bx = max |planes|) and W1' = W1 / sqrt(32) * log2(e) share ONE degree of
+//     freedom, x * 2^b and W1' * 2^-b (the product is untouched, so nothing is undone on the accumulators and the kernel pays nothing:
+//     2^b rides in the 1/3 of the plane mean, 2^-b is applied when the weights are staged): b = floor((log2 Bw1 - log2 Bx) / 2) puts both
+//     at sqrt(Bx * Bw1) -- inside the window whenever the pre-activations themselves are sane;
+//   * hidden values h in [0, Bh], Bh = 1 + max_u log2(e) (|b1[u]| + ||W1[u]||_1 / sqrt(32) * Bx): times 2^c only when Bh >= 2^15 (c < 0);
+//   * colour rows W2' * 2^-c * 2^-d with d > 0 only when they would reach 2^15; the accumulators are then multiplied by 2^d.
+// c = d = 0 (a wave-uniform branch not taken) for every sane checkpoint.
+struct DecFold { float xs, w1s, hs, w2s, ys, b2s; float bx, bh; };
+
+__device__ __forceinline__ float pow2i(int e) { return __int_as_float((min(max(e, -126), 127) + 127) << 23); }
+__device__ __forceinline__ int ilog2_floor(float x) { return (int)((__float_as_uint(x) >> 23) & 0xFF) - 127; }     // x > 0, normal
+
+__device__ __forceinline__ float absmax4(const float4 v) { return fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w))); }
+
+// one block of 256 threads (its own launch for r3d_run_model; the LAST block of ray_limits_kernel's launch for r3d_render_forward)
+__device__ __forceinline__ void decoder_fold_block(const float* __restrict__ part, int npart, const float* __restrict__ w1,
+                                                   const float* __restrict__ b1, const float* __restrict__ w2, DecFold* __restrict__ out)
+{
+    __shared__ float red[3][4];
+    const int tid = threadIdx.x;
+    float bx = 0.f, bw1 = 0.f, bw2 = 0.f;
+    // 16-byte loads, several in flight per thread (a one-block kernel is pure latency: scalar loads in a loop cost ~0.8 us per trip)
+    if ((((uintptr_t)part | (uintptr_t)w1 | (uintptr_t)w2) & 15) == 0) {
+        const float4* p4 = reinterpret_cast<const float4*>(part);
+        const int n4 = npart >> 2;
+#pragma unroll 4
+        for (int i = tid; i < n4; i += 256) bx = fmaxf(bx, absmax4(p4[i]));
+        for (int i = 4 * n4 + tid; i < npart; i += 256) bx = fmaxf(bx, part[i]);
+        const float4* a4 = reinterpret_cast<const float4*>(w1);
+#pragma unroll
+        for (int i = tid; i < R3D_HIDDEN * R3D_FEATURES / 4; i += 256) bw1 = fmaxf(bw1, absmax4(a4[i]));
+        const float4* c4 = reinterpret_cast<const float4*>(w2 + R3D_HIDDEN);                                      // colour rows 1..32
+#pragma unroll
+        for (int i = tid; i < (R3D_DECODER_OUT - 1) * R3D_HIDDEN / 4; i += 256) bw2 = fmaxf(bw2, absmax4(c4[i]));
+    } else {
+        for (int i = tid; i < npart; i += 256) bx = fmaxf(bx, part[i]);
+        for (int i = tid; i < R3D_HIDDEN * R3D_FEATURES; i += 256) bw1 = fmaxf(bw1, fabsf(w1[i]));
+        for (int i = R3D_HIDDEN + tid; i < R3D_DECODER_OUT * R3D_HIDDEN; i += 256) bw2 = fmaxf(bw2, fabsf(w2[i]));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { bx = fmaxf(bx, __shfl_xor(bx, d)); bw1 = fmaxf(bw1, __shfl_xor(bw1, d)); bw2 = fmaxf(bw2, __shfl_xor(bw2, d)); }
+    if ((tid & 63) == 0) { red[0][tid >> 6] = bx; red[1][tid >> 6] = bw1; red[2][tid >> 6] = bw2; }
+    __shared__ float rowb[R3D_HIDDEN];
+    if (tid < R3D_HIDDEN) {                              // |b1[u]| and ||W1[u]||_1 of hidden unit u (the Bx-dependent part is finished by thread 0)
+        float a = 0.f;
+        const float4* r4 = reinterpret_cast<const float4*>(w1 + tid * R3D_FEATURES);
+#pragma unroll
+        for (int c = 0; c < R3D_FEATURES / 4; ++c) { const float4 v = r4[c]; a += fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w); }
+        rowb[tid] = a;
+    }
+    __shared__ float rowbias[R3D_HIDDEN];
+    if (tid < R3D_HIDDEN) rowbias[tid] = fabsf(b1[tid]);
+    __syncthreads();
+    if (tid >= 64) return;
+    bx = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    bw1 = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3])) * (0.17677669529663687f * 1.4426950408889634f);
+    bw2 = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3])) * 0.125f;
+    const float kTiny = 1e-30f, kHuge = 1e30f;
+    int b = 0;
+    if (bx > kTiny && bx < kHuge && bw1 > kTiny && bw1 < kHuge) b = (ilog2_floor(bw1) - ilog2_floor(bx)) >> 1;     // arithmetic shift = floor
+    b = min(max(b, -100), 100);
+    const float bxs = (bx < kHuge) ? bx : kHuge;
+    float bh = 1.4426950408889634f * (rowbias[tid] + rowb[tid] * 0.17677669529663687f * bxs);     // wave 0: one hidden unit per lane
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) bh = fmaxf(bh, __shfl_xor(bh, d));
+    if (tid != 0) return;
+    bh += 1.0f;
+    int c = 0;
+    if (bh >= 32768.f && bh < kHuge) c = 14 - (ilog2_floor(bh) + 1);
+    int d = 0;
+    const float bw2c = bw2 * pow2i(-c);
+    if (bw2c >= 32768.f && bw2c < kHuge) d = (ilog2_floor(bw2c) + 1) - 14;
+    DecFold f;
+    f.xs = pow2i(b); f.w1s = pow2i(-b); f.hs = pow2i(c); f.w2s = pow2i(-c - d); f.ys = pow2i(d); f.b2s = pow2i(-d);
+    f.bx = bx; f.bh = bh;
+    *out = f;
+}
+
+__global__ __launch_bounds__(256) void decoder_fold_kernel(const float* __restrict__ part, int npart, const float* __restrict__ w1,
+                                                          const float* __restrict__ b1, const float* __restrict__ w2, DecFold* __restrict__ out)
+{
+    decoder_fold_block(part, npart, w1, b1, w2, out);
+}
+
 // -------------------------------------------------------------------------------------------------
 // A2 ray/box limits (math_utils.py:46-98) + global min/max of valid ray starts (renderer.py:123-126)
 // gstate: [3] ord(min depth), [4] ord(max depth) (depth range for ray_marcher.py:50; initialised here by block 0, accumulated by the
@@ -175,10 +279,15 @@ __global__ void raygen_kernel(const float* __restrict__ c2w, const float* __rest
 static constexpr int kLimitsBlock = 256;
 static constexpr int kStateHeader = 8;                  // ints in front of the per-block partials
 
+// The launch carries ONE extra block (the last one) that computes the decoder's range fold for the render kernel that follows
+// (decoder_fold_block): no launch of its own, and its ~4 us of load latency run next to the limit blocks.
 __global__ __launch_bounds__(kLimitsBlock) void ray_limits_kernel(const float* __restrict__ origins, const float* __restrict__ dirs,
                                   int nrays, float half, float* __restrict__ ray_start,
-                                  float* __restrict__ ray_end, uint8_t* __restrict__ valid, int* gstate)
+                                  float* __restrict__ ray_end, uint8_t* __restrict__ valid, int* gstate,
+                                  const float* __restrict__ fold_part, int fold_npart, const float* __restrict__ w1,
+                                  const float* __restrict__ b1, const float* __restrict__ w2, DecFold* __restrict__ fold_out)
 {
+    if (fold_out && blockIdx.x == gridDim.x - 1) { decoder_fold_block(fold_part, fold_npart, w1, b1, w2, fold_out); return; }
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (blockIdx.x == 0 && threadIdx.x == 0) { gstate[3] = 0x7fffffff; gstate[4] = (int)0x80000000; }
     float tmin = 0.f, tmax = 0.f;
@@ -220,80 +329,6 @@ __global__ __launch_bounds__(kLimitsBlock) void ray_limits_kernel(const float* _
         p[1] = max(max(red[1][0], red[1][1]), max(red[1][2], red[1][3]));
         p[2] = red[2][0] | red[2][1] | red[2][2] | red[2][3];
     }
-}
-
-// ray_marcher.py:46-50: nan_to_num(inf) then clamp to the global [min, max] of all depths of the call
-__global__ void depth_clamp_kernel(float* __restrict__ depth, int nrays, const int* __restrict__ gstate)
-{
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nrays) return;
-    const float lo = ord2f(gstate[3]), hi = ord2f(gstate[4]);
-    float v = depth[r];
-    if (v != v) v = INFINITY;
-    depth[r] = fminf(fmaxf(v, lo), hi);
-}
-
-// -------------------------------------------------------------------------------------------------
-// Decoder weights staged in LDS in MFMA A-fragment order (shared by the block's waves)
-// -------------------------------------------------------------------------------------------------
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-
-// ---- fp16 range fold of the decoder (exact powers of two; the SR's counterpart is r3d_chain_fold) -------------------------------
-// The decoder runs on the f16 matrix pipe with every fp32 operand split into fp16 hi + lo: exact to ~2^-22 only while an operand sits
-// inside the fp16 window (max < 65504, typical values well above the 2^-24 subnormal step).  The reference computes in fp32 with no range
-// limit, so one launch per call derives exact power-of-two factors from guaranteed bounds:
-//   * features x (a convex combination of plane texels: |x| <= Bx = max |planes|) and W1' = W1 / sqrt(32) * log2(e) share ONE degree of
-//     freedom, x * 2^b and W1' * 2^-b (the product is untouched, so nothing is undone on the accumulators and the kernel pays nothing:
-//     2^b rides in the 1/3 of the plane mean, 2^-b is applied when the weights are staged): b = floor((log2 Bw1 - log2 Bx) / 2) puts both
-//     at sqrt(Bx * Bw1) -- inside the window whenever the pre-activations themselves are sane;
-//   * hidden values h in [0, Bh], Bh = 1 + max_u log2(e) (|b1[u]| + ||W1[u]||_1 / sqrt(32) * Bx): times 2^c only when Bh >= 2^15 (c < 0);
-//   * colour rows W2' * 2^-c * 2^-d with d > 0 only when they would reach 2^15; the accumulators are then multiplied by 2^d.
-// c = d = 0 (a wave-uniform branch not taken) for every sane checkpoint.
-struct DecFold { float xs, w1s, hs, w2s, ys, b2s; float bx, bh; };
-
-__device__ __forceinline__ float pow2i(int e) { return __int_as_float((min(max(e, -126), 127) + 127) << 23); }
-__device__ __forceinline__ int ilog2_floor(float x) { return (int)((__float_as_uint(x) >> 23) & 0xFF) - 127; }     // x > 0, normal
-
-__global__ __launch_bounds__(256) void decoder_fold_kernel(const float* __restrict__ part, int npart, const float* __restrict__ w1,
-                                                          const float* __restrict__ b1, const float* __restrict__ w2, DecFold* __restrict__ out)
-{
-    __shared__ float red[3][4];
-    const int tid = threadIdx.x;
-    float bx = 0.f, bw1 = 0.f, bw2 = 0.f;
-    for (int i = tid; i < npart; i += 256) bx = fmaxf(bx, part[i]);
-    for (int i = tid; i < R3D_HIDDEN * R3D_FEATURES; i += 256) bw1 = fmaxf(bw1, fabsf(w1[i]));
-    for (int i = R3D_HIDDEN + tid; i < R3D_DECODER_OUT * R3D_HIDDEN; i += 256) bw2 = fmaxf(bw2, fabsf(w2[i]));      // colour rows 1..32
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { bx = fmaxf(bx, __shfl_xor(bx, d)); bw1 = fmaxf(bw1, __shfl_xor(bw1, d)); bw2 = fmaxf(bw2, __shfl_xor(bw2, d)); }
-    if ((tid & 63) == 0) { red[0][tid >> 6] = bx; red[1][tid >> 6] = bw1; red[2][tid >> 6] = bw2; }
-    __shared__ float rowsum[R3D_HIDDEN];
-    if (tid < R3D_HIDDEN) {
-        float a = 0.f;
-        for (int c = 0; c < R3D_FEATURES; ++c) a += fabsf(w1[tid * R3D_FEATURES + c]);
-        rowsum[tid] = a;
-    }
-    __syncthreads();
-    if (tid != 0) return;
-    bx = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
-    bw1 = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3])) * (0.17677669529663687f * 1.4426950408889634f);
-    bw2 = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3])) * 0.125f;
-    const float kTiny = 1e-30f, kHuge = 1e30f;
-    int b = 0;
-    if (bx > kTiny && bx < kHuge && bw1 > kTiny && bw1 < kHuge) b = (ilog2_floor(bw1) - ilog2_floor(bx)) >> 1;     // arithmetic shift = floor
-    b = min(max(b, -100), 100);
-    float bh = 0.f;
-    const float bxs = (bx < kHuge) ? bx : kHuge;
-    for (int u = 0; u < R3D_HIDDEN; ++u) bh = fmaxf(bh, 1.4426950408889634f * (fabsf(b1[u]) + rowsum[u] * 0.17677669529663687f * bxs));
-    bh += 1.0f;
-    int c = 0;
-    if (bh >= 32768.f && bh < kHuge) c = 14 - (ilog2_floor(bh) + 1);
-    int d = 0;
-    const float bw2c = bw2 * pow2i(-c);
-    if (bw2c >= 32768.f && bw2c < kHuge) d = (ilog2_floor(bw2c) + 1) - 14;
-    DecFold f;
-    f.xs = pow2i(b); f.w1s = pow2i(-b); f.hs = pow2i(c); f.w2s = pow2i(-c - d); f.ys = pow2i(d); f.b2s = pow2i(-d);
-    f.bx = bx; f.bh = bh;
-    *out = f;
 }
 
 // fp32 -> (hi, lo) fp16 pair with hi + lo == x to 2^-24 relative (lo subnormals are kept by the MFMA)
@@ -1254,16 +1289,20 @@ extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
     float* ray_end = ray_start + nrays;
     void* fold_mem = reinterpret_cast<char*>(workspace) + ((render_state_bytes(nrays) + 2 * (size_t)nrays * sizeof(float) + 63) & ~(size_t)63);
 
-    {
-        ProfScope ps(R3D_PROF_MISC, st);
-        hipLaunchKernelGGL(ray_limits_kernel, dim3((nrays + kLimitsBlock - 1) / kLimitsBlock), dim3(kLimitsBlock), 0, st, origins, dirs, nrays,
-                           box_warp * 0.5f, ray_start, ray_end, valid, gstate);
-    }
-
     RenderArgs a;
     {
         ProfScope ps(R3D_PROF_MISC, st);
-        a.fold = launch_decoder_fold(planes_nhwc, (size_t)N * 3 * triplane_depth * H * W * kC, plane_absmax, n_plane_absmax, w1, b1, w2, fold_mem, st);
+        // the decoder's range fold rides as the last block of the ray-limits launch (planes without |max| partials are measured first)
+        DecFold* fold = reinterpret_cast<DecFold*>(fold_mem);
+        if (!plane_absmax || n_plane_absmax <= 0) {
+            float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(fold_mem) + 64);
+            hipLaunchKernelGGL(plane_absmax_kernel, dim3(kAbsmaxBlocks), dim3(256), 0, st, reinterpret_cast<const float4*>(planes_nhwc),
+                               (size_t)N * 3 * triplane_depth * H * W * kC / 4, part);
+            plane_absmax = part; n_plane_absmax = kAbsmaxBlocks;
+        }
+        hipLaunchKernelGGL(ray_limits_kernel, dim3((nrays + kLimitsBlock - 1) / kLimitsBlock + 1), dim3(kLimitsBlock), 0, st, origins, dirs, nrays,
+                           box_warp * 0.5f, ray_start, ray_end, valid, gstate, plane_absmax, n_plane_absmax, w1, b1, w2, fold);
+        a.fold = fold;
     }
     a.planes4 = reinterpret_cast<const float4*>(planes_nhwc); a.N = N; a.H = H; a.W = W; a.M = M; a.D = triplane_depth;
     a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;

@@ -272,7 +272,15 @@ __global__ void absmax_kernel(const float* __restrict__ x, size_t count, unsigne
     if (!n4) for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[(size_t)n * count + i]));
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d));
-    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(&out[n], __float_as_uint(m));     // non-negative floats order like unsigned ints; NaN never wins
+    // ONE atomic per block: atomics on one word serialise in L2 at ~12 ns each -- round 2's one-per-wave version (8 192 atomics for a 16 MB
+    // tensor) took 97 us for a pass that needs 3 us of HBM time
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (m > 0.f) atomicMax(&out[n], __float_as_uint(m));           // non-negative floats order like unsigned ints; NaN never wins
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -782,7 +790,7 @@ extern "C" int r3d_absmax(const float* x, size_t count_per_sample, int N, float*
     using namespace r3d;
     if (!x || !out || N <= 0 || count_per_sample == 0) { set_error("absmax: bad argument"); return R3D_ERR_INVALID_ARG; }
     size_t blocks = (count_per_sample / 4 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;                   // 8 blocks per CU; each lane then streams 4 x 16 B per iteration
+    if (blocks > 512) blocks = 512;                     // 2 blocks per CU, one atomic each; each lane streams 4 x 16 B per iteration
     if (blocks < 1) blocks = 1;
     ProfScope ps(R3D_PROF_LAYOUT, (hipStream_t)stream);
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks, N), dim3(256), 0, (hipStream_t)stream, x, count_per_sample,

@@ -103,9 +103,13 @@ def _tag(y, bound, depth):
 def _keep_tags(x):
     """_f32c (detach) drops python attributes: carry the range tags over."""
     y = _f32c(x)
-    b = getattr(x, "_r3d_bound", None)
-    if b is not None and y is not x:
-        _tag(y, b, int(getattr(x, "_r3d_depth", 0)))
+    if y is not x:
+        b = getattr(x, "_r3d_bound", None)
+        if b is not None:
+            _tag(y, b, int(getattr(x, "_r3d_depth", 0)))
+        fmt = getattr(x, "_r3d_fmt", None)
+        if fmt is not None:
+            y._r3d_fmt = fmt
     return y
 
 
