@@ -246,7 +246,8 @@ __device__ __forceinline__ void decoder_fold_block(const float* __restrict__ par
     const float kTiny = 1e-30f, kHuge = 1e30f;
     int b = 0;
     if (bx > kTiny && bx < kHuge && bw1 > kTiny && bw1 < kHuge) b = (ilog2_floor(bw1) - ilog2_floor(bx)) >> 1;     // arithmetic shift = floor
-    b = min(max(b, -100), 100);
+    if (bx > kTiny && bx < kHuge) b = min(b, 14 - ilog2_floor(bx));     // |x * 2^b| < 2^15 ALWAYS (split8_bounded has no saturation guard); W1 * 2^-b is
+    b = min(max(b, -100), 100);                                          // clamped when staged, which only bites if |W1| |x| itself exceeds ~2^30
     const float bxs = (bx < kHuge) ? bx : kHuge;
     float bh = 1.4426950408889634f * (rowbias[tid] + rowb[tid] * 0.17677669529663687f * bxs);     // wave 0: one hidden unit per lane
 #pragma unroll
@@ -337,6 +338,16 @@ __device__ __forceinline__ void split8(const float (&x)[8], h8& hi, h8& lo)
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const _Float16 a = (_Float16)fminf(fmaxf(x[j], -65504.f), 65504.f);
+        hi[j] = a; lo[j] = (_Float16)(x[j] - (float)a);
+    }
+}
+// the per-sample operands (gathered features, hidden values): |x| < 2^15 is GUARANTEED by the range fold (decoder_fold_block limits 2^b and
+// 2^c from rigorous bounds), so the saturation guard -- a v_med3 + a canonicalising v_max per value, 144 values per ray -- is dropped
+__device__ __forceinline__ void split8_bounded(const float (&x)[8], h8& hi, h8& lo)
+{
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const _Float16 a = (_Float16)x[j];
         hi[j] = a; lo[j] = (_Float16)(x[j] - (float)a);
     }
 }
@@ -584,7 +595,9 @@ __device__ __forceinline__ void decode_tile(const DecoderLds& L, int lane, const
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float x = h[mt][r];
-            const float sp = fmaxf(x, 0.0f) + __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(x)));
+            // max(x, 0) as (x + |x|) / 2 (exact; the |x| is a free source modifier, the halving rides in an fma): fmaxf costs two v_max (hipcc
+            // canonicalises an operand it cannot prove quiet, e.g. an MFMA result) -- 96 softplus per lane and ray
+            const float sp = __builtin_fmaf(x + fabsf(x), 0.5f, __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(x))));
             h[mt][r] = sp;
             sg += sp * L.w2s[16 * mt + 4 * q + r];
         }
@@ -610,7 +623,7 @@ __device__ __forceinline__ void decode_tile(const DecoderLds& L, int lane, const
         const float hv[8] = {h[2 * pp][0], h[2 * pp][1], h[2 * pp][2], h[2 * pp][3],
                              h[2 * pp + 1][0], h[2 * pp + 1][1], h[2 * pp + 1][2], h[2 * pp + 1][3]};
         h8 bh, bl;
-        split8(hv, bh, bl);
+        split8_bounded(hv, bh, bl);
 #pragma unroll
         for (int ot = 0; ot < 2; ++ot) {
             uint4 a0 = L.w2f[ot][pp][0][lane], a1 = L.w2f[ot][pp][1][lane];
@@ -682,7 +695,7 @@ __device__ __forceinline__ int gather_q(int lane) { return lane & 3; }
 __device__ __forceinline__ int gather_s(int lane) { return lane >> 2; }
 __device__ __forceinline__ void gather_to_mfma(XchLds& E, int lane, const float (&X)[8], h8& xh, h8& xl)
 {
-    split8(X, xh, xl);
+    split8_bounded(X, xh, xl);
     const int gs = lane >> 2, gq = lane & 3, q = lane >> 4, s = lane & 15;
     const int wi = gs * 4 + (gq ^ (gs >> 2)), ri = s * 4 + (q ^ (s >> 2));
     E.v[0][wi] = *reinterpret_cast<uint4*>(&xh);
