@@ -1018,7 +1018,10 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
 #endif
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
-    float4* hls0 = reinterpret_cast<float4*>(lds);                  // H: 2 x [pa][half][gy][32] (28 used), column oc in slot ((oc ^ (oc >> 4)) + 8 half) & 31
+    // (Round 3 tried an XOR swizzle of the H columns against the write pattern's even-slot stride and a software pipeline of the four slices
+    // -- hpass(g + 1) in front of vpass(g): both bit-identical and both time-neutral, SQ_LDS_BANK_CONFLICT unchanged (profiles/r03): the
+    // epilogue is VALU-issue bound, ~460 wave64 instructions per slice at 2 waves per SIMD.  Not kept.)
+    float4* hls0 = reinterpret_cast<float4*>(lds);                  // H: 2 x [pa][half][gy][32] (28 used), column swizzled by 8*half
     const int co0 = cg * 32;
     const float* D = a.out_scale + (size_t)n * a.vec_stride_n + co0;
     const float* Bv = a.bias + (size_t)n * a.vec_stride_n + co0;
@@ -1044,10 +1047,8 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
     return;
 #endif
     __syncthreads();                                                // the main loop's LDS reads are done
-    // Software-pipelined over the four 8-cout slices: the horizontal pass of slice g + 1 (registers -> the OTHER slice buffer) is issued in
-    // front of the vertical pass of slice g, so that inside a wave the DPP / VALU work of one covers the LDS-read latency of the other
-    // (at 2 waves per SIMD there is little else to cover it); one barrier per slice as before.
-    auto hpass = [&](int g) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
         float4* hls = hls0 + (g & 1) * 2048;
         const float dv[4] = {dv4[g].x, dv4[g].y, dv4[g].z, dv4[g].w};
         // horizontal pass of this slice: (T[pa][pb=0], T[pa][pb=1]) at this lane's grid point -> (H column 2X, H column 2X+1)
@@ -1072,14 +1073,9 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
                 const int gy = row0 + nt * 2 + prow;
 #pragma unroll
                 for (int dx = 0; dx < 2; ++dx)
-                    // column oc = 2 pcol + dx sits in slot ((oc ^ (oc >> 4)) + 8 h) & 31: a 16-lane write group (dx fixed, pcol = 0..15) would
-                    // otherwise hit the even slots 0..30 only, i.e. every bank group twice (round 2 measured 41 % of this kernel's
-                    // LDS-active cycles as bank conflicts); with bit 0 flipped in the upper half the 16 slots are distinct mod 16
-                    hls[((pa * 2 + h) * 16 + gy) * 32 + ((((2 * pcol + dx) ^ (pcol >> 3)) + 8 * h) & 31)] = make_float4(hx[dx][0], hx[dx][1], hx[dx][2], hx[dx][3]);
+                    hls[((pa * 2 + h) * 16 + gy) * 32 + ((2 * pcol + dx + 8 * h) & 31)] = make_float4(hx[dx][0], hx[dx][1], hx[dx][2], hx[dx][3]);
             }
-    };
-    auto vpass = [&](int g) {
-        float4* hls = hls0 + (g & 1) * 2048;
+        __syncthreads();                                            // (buffer g & 1 was last read by slice g - 2's vertical pass: done before barrier g - 1)
         {   // vertical: item (row pair rp, column oc, half): H rows 2rp+1 .. 2rp+5 -> y rows 2rp, 2rp+1 (4 couts each)
             const float4 b4 = bv4[g], n4 = nv4[g];
             const f2 ba = f2{b4.x, b4.y}, bb = f2{b4.z, b4.w};
@@ -1095,7 +1091,7 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
 #pragma unroll
                 for (int rr = 0; rr < 5; ++rr) {                    // H row 2rp+1+rr = phase (rr+1)&1 at grid row rp + (rr+1)/2
                     const int gyy = min(rp, U_TILE - 1) + ((rr + 1) >> 1);   // (clamped: dead items read valid LDS)
-                    const float4 t4 = hls[((((rr + 1) & 1) * 2 + half) * 16 + gyy) * 32 + (((oc ^ (oc >> 4)) + 8 * half) & 31)];
+                    const float4 t4 = hls[((((rr + 1) & 1) * 2 + half) * 16 + gyy) * 32 + ((oc + 8 * half) & 31)];
                     ha[rr] = f2{t4.x, t4.y}; hb[rr] = f2{t4.z, t4.w};
                 }
 #pragma unroll
@@ -1146,14 +1142,6 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
                 }
             }
         }
-    };
-    hpass(0);
-    __syncthreads();
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        if (g + 1 < 4) hpass(g + 1);                                // buffer (g + 1) & 1 was last read by vpass(g - 1): done before the barrier below it
-        vpass(g);
-        if (g + 1 < 4) __syncthreads();
     }
 #if defined(R3D_ABLATE) && (R3D_ABLATE & 512)
     {
