@@ -102,7 +102,11 @@ int r3d_render_forward(const float* planes_nhwc, int N, int H, int W, int tripla
                        const float* noise_c, const float* u_f, uint64_t seed,
                        float* rgb, int rgb_channel_major, float* depth, float* wsum, uint8_t* valid,
                        const float* plane_absmax, int n_plane_absmax,
+                       const float* cam2world, const float* intrinsics,
                        void* workspace, size_t workspace_bytes, r3d_stream_t stream);
+/* Camera mode (origins = dirs = NULL, cam2world [N,4,4] + intrinsics [N,3,3] given, M = R * R): RaySampler.forward is evaluated inside
+ * the limits pass and the render kernel with r3d_raygen's instruction sequence -- the same pixels as r3d_raygen + the ray arrays, without
+ * the launch and the two [N,M,3] round trips.  cam2world / intrinsics are ignored when origins / dirs are given (pass NULL). */
 
 /* Replaces ImportanceRenderer.run_model(planes, decoder, sample_coordinates, sample_directions, options)
  * (renderer.py:169-188; inference branches) -- the point-query used by .sample() (triplane.py:140-148).

@@ -140,15 +140,11 @@ __global__ __launch_bounds__(256) void plane_absmax_kernel(const float4* __restr
 // -------------------------------------------------------------------------------------------------
 // A1 ray generation (ray_sampler.py:24-63)
 // -------------------------------------------------------------------------------------------------
-__global__ void raygen_kernel(const float* __restrict__ c2w, const float* __restrict__ K, int R,
-                              float* __restrict__ origins, float* __restrict__ dirs)
+// one ray of RaySampler.forward (ray_sampler.py:24-63); used by raygen_kernel and, in camera mode (no origin / direction arrays), by the
+// limits pass and the render kernel themselves -- the same instruction sequence, so both modes render identical pixels
+__device__ __forceinline__ void make_ray(const float* __restrict__ Cm, const float* __restrict__ Kn, int R, int m, float (&o)[3], float (&d)[3])
 {
-    const int n = blockIdx.y;
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    const int M = R * R;
-    if (m >= M) return;
-    const float* Cm = c2w + 16 * n;
-    const float* Kn = K + 9 * n;
+#pragma clang fp contract(off)        // no context-dependent fma formation: the three kernels that inline this produce bit-identical rays
     const float fx = Kn[0], sk = Kn[1], cx = Kn[2], fy = Kn[4], cy = Kn[5];
     const float inv_r = 1.0f / (float)R, half_r = 0.5f / (float)R;
     const int i = m / R, j = m - i * R;
@@ -157,13 +153,26 @@ __global__ void raygen_kernel(const float* __restrict__ c2w, const float* __rest
     const float xl = (xc - cx + cy * sk / fy - sk * yc / fy) / fx;
     const float yl = (yc - cy) / fy;
     const float camx = Cm[3], camy = Cm[7], camz = Cm[11];
-    float dx = Cm[0] * xl + Cm[1] * yl + Cm[2] + Cm[3] - camx;
-    float dy = Cm[4] * xl + Cm[5] * yl + Cm[6] + Cm[7] - camy;
-    float dz = Cm[8] * xl + Cm[9] * yl + Cm[10] + Cm[11] - camz;
+    const float dx = Cm[0] * xl + Cm[1] * yl + Cm[2] + Cm[3] - camx;
+    const float dy = Cm[4] * xl + Cm[5] * yl + Cm[6] + Cm[7] - camy;
+    const float dz = Cm[8] * xl + Cm[9] * yl + Cm[10] + Cm[11] - camz;
     const float nrm = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
+    o[0] = camx; o[1] = camy; o[2] = camz;
+    d[0] = dx / nrm; d[1] = dy / nrm; d[2] = dz / nrm;
+}
+
+__global__ void raygen_kernel(const float* __restrict__ c2w, const float* __restrict__ K, int R,
+                              float* __restrict__ origins, float* __restrict__ dirs)
+{
+    const int n = blockIdx.y;
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    const int M = R * R;
+    if (m >= M) return;
+    float o3[3], d3[3];
+    make_ray(c2w + 16 * n, K + 9 * n, R, m, o3, d3);
     const size_t o = 3 * ((size_t)n * M + m);
-    origins[o] = camx; origins[o + 1] = camy; origins[o + 2] = camz;
-    dirs[o] = dx / nrm; dirs[o + 1] = dy / nrm; dirs[o + 2] = dz / nrm;
+    origins[o] = o3[0]; origins[o + 1] = o3[1]; origins[o + 2] = o3[2];
+    dirs[o] = d3[0]; dirs[o + 1] = d3[1]; dirs[o + 2] = d3[2];
 }
 
 // ray_marcher.py:46-50: nan_to_num(inf) then clamp to the global [min, max] of all depths of the call
@@ -286,7 +295,8 @@ __global__ __launch_bounds__(kLimitsBlock) void ray_limits_kernel(const float* _
                                   int nrays, float half, float* __restrict__ ray_start,
                                   float* __restrict__ ray_end, uint8_t* __restrict__ valid, int* gstate,
                                   const float* __restrict__ fold_part, int fold_npart, const float* __restrict__ w1,
-                                  const float* __restrict__ b1, const float* __restrict__ w2, DecFold* __restrict__ fold_out)
+                                  const float* __restrict__ b1, const float* __restrict__ w2, DecFold* __restrict__ fold_out,
+                                  const float* __restrict__ cam_c2w, const float* __restrict__ cam_K, int cam_R)
 {
     if (fold_out && blockIdx.x == gridDim.x - 1) { decoder_fold_block(fold_part, fold_npart, w1, b1, w2, fold_out); return; }
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -294,11 +304,18 @@ __global__ __launch_bounds__(kLimitsBlock) void ray_limits_kernel(const float* _
     float tmin = 0.f, tmax = 0.f;
     bool v = false;
     if (r < nrays) {
-        float lo[3], hi[3];
+        float lo[3], hi[3], o3[3], d3[3];
+        if (cam_c2w) {                                   // camera mode: the rays are generated here (and again in the render kernel), never stored
+            const int M = cam_R * cam_R, n = r / M;
+            make_ray(cam_c2w + 16 * n, cam_K + 9 * n, cam_R, r - n * M, o3, d3);
+        } else {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { o3[a] = origins[3 * (size_t)r + a]; d3[a] = dirs[3 * (size_t)r + a]; }
+        }
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const float o = origins[3 * (size_t)r + a];
-            const float inv = 1.0f / dirs[3 * (size_t)r + a];
+            const float o = o3[a];
+            const float inv = 1.0f / d3[a];
             const bool neg = inv < 0.0f;
             lo[a] = ((neg ? half : -half) - o) * inv;
             hi[a] = ((neg ? -half : half) - o) * inv;
@@ -753,7 +770,8 @@ __device__ __forceinline__ void march(const float* T, const float* S, float* wv,
 struct RenderArgs {
     const float4* planes4; int N, H, W, M, D;      // D: tri-grid depth (1 = tri-plane)
     const float* w1; const float* b1; const float* w2; const float* b2;
-    const float* origins; const float* dirs;
+    const float* origins; const float* dirs;        // NULL in camera mode: rays from (cam_c2w, cam_K, cam_R), image n = ray / M
+    const float* cam_c2w; const float* cam_K; int cam_R;
     const float* ray_start; const float* ray_end; const uint8_t* valid;
     int* gstate; int nlimit_blocks;
     int Nc, Nf; float scale; int white_back;
@@ -827,8 +845,15 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
         if (!next_ray(a, R, iter, wave, ray)) break;
         const int n = ray / a.M;
         const float4* P = a.planes4 + (size_t)n * 3 * (TRI ? a.D : 1) * a.H * a.W * 8;
-        const float ox = a.origins[3 * (size_t)ray], oy = a.origins[3 * (size_t)ray + 1], oz = a.origins[3 * (size_t)ray + 2];
-        const float dx = a.dirs[3 * (size_t)ray], dy = a.dirs[3 * (size_t)ray + 1], dz = a.dirs[3 * (size_t)ray + 2];
+        float ox, oy, oz, dx, dy, dz;
+        if (a.cam_c2w) {
+            float o3[3], d3[3];
+            make_ray(a.cam_c2w + 16 * n, a.cam_K + 9 * n, a.cam_R, ray - n * a.M, o3, d3);
+            ox = o3[0]; oy = o3[1]; oz = o3[2]; dx = d3[0]; dy = d3[1]; dz = d3[2];
+        } else {
+            ox = a.origins[3 * (size_t)ray]; oy = a.origins[3 * (size_t)ray + 1]; oz = a.origins[3 * (size_t)ray + 2];
+            dx = a.dirs[3 * (size_t)ray]; dy = a.dirs[3 * (size_t)ray + 1]; dz = a.dirs[3 * (size_t)ray + 2];
+        }
         float start = a.ray_start[ray], end = a.ray_end[ray];
         if (!a.valid[ray] && any_valid) { start = gmin_start; end = gmax_start; }   // renderer.py:125-126
 
@@ -1283,10 +1308,12 @@ extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
                                   const float* noise_c, const float* u_f, uint64_t seed,
                                   float* rgb, int rgb_channel_major, float* depth, float* wsum, uint8_t* valid,
                                   const float* plane_absmax, int n_plane_absmax,
+                                  const float* cam2world, const float* intrinsics,
                                   void* workspace, size_t workspace_bytes, r3d_stream_t stream)
 {
-    if (!planes_nhwc || !w1 || !b1 || !w2 || !b2 || !origins || !dirs || !rgb || !wsum || !valid) {
-        set_error("render_forward: NULL pointer"); return R3D_ERR_INVALID_ARG;
+    const bool cam = origins == nullptr && dirs == nullptr && cam2world != nullptr && intrinsics != nullptr;
+    if (!planes_nhwc || !w1 || !b1 || !w2 || !b2 || (!cam && (!origins || !dirs)) || !rgb || !wsum || !valid) {
+        set_error("render_forward: NULL pointer (rays: origins + dirs, or cam2world + intrinsics with origins = dirs = NULL)"); return R3D_ERR_INVALID_ARG;
     }
     if (N <= 0 || M <= 0 || H <= 1 || W <= 1 || triplane_depth < 1 || triplane_depth > 16 || !(box_warp > 0.f)) { set_error("render_forward: bad shape"); return R3D_ERR_INVALID_ARG; }
     if (Nc < 4 || Nc > 96 || Nf < 0 || Nf > 96) {
@@ -1302,6 +1329,9 @@ extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
     float* ray_end = ray_start + nrays;
     void* fold_mem = reinterpret_cast<char*>(workspace) + ((render_state_bytes(nrays) + 2 * (size_t)nrays * sizeof(float) + 63) & ~(size_t)63);
 
+    int R = 0;                                        // square image -> XCD strip order of the rays; otherwise linear order
+    for (int r = 1; r * r <= M; ++r) if (r * r == M) R = r;
+    if (cam && R == 0) { set_error("render_forward: camera mode needs M = R * R rays (got %d)", M); return R3D_ERR_INVALID_ARG; }
     RenderArgs a;
     {
         ProfScope ps(R3D_PROF_MISC, st);
@@ -1314,19 +1344,19 @@ extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
             plane_absmax = part; n_plane_absmax = kAbsmaxBlocks;
         }
         hipLaunchKernelGGL(ray_limits_kernel, dim3((nrays + kLimitsBlock - 1) / kLimitsBlock + 1), dim3(kLimitsBlock), 0, st, origins, dirs, nrays,
-                           box_warp * 0.5f, ray_start, ray_end, valid, gstate, plane_absmax, n_plane_absmax, w1, b1, w2, fold);
+                           box_warp * 0.5f, ray_start, ray_end, valid, gstate, plane_absmax, n_plane_absmax, w1, b1, w2, fold,
+                           cam ? cam2world : nullptr, cam ? intrinsics : nullptr, R);
         a.fold = fold;
     }
     a.planes4 = reinterpret_cast<const float4*>(planes_nhwc); a.N = N; a.H = H; a.W = W; a.M = M; a.D = triplane_depth;
     a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
+    a.cam_c2w = cam ? cam2world : nullptr; a.cam_K = cam ? intrinsics : nullptr; a.cam_R = R;
     a.origins = origins; a.dirs = dirs; a.ray_start = ray_start; a.ray_end = ray_end; a.valid = valid;
     a.gstate = gstate; a.nlimit_blocks = (nrays + kLimitsBlock - 1) / kLimitsBlock; a.Nc = Nc; a.Nf = Nf; a.scale = 2.0f / box_warp; a.white_back = white_back;
     a.noise_c = noise_c; a.u_f = u_f; a.seed = seed;
     a.rgb = rgb; a.depth = depth; a.wsum = wsum; a.rgb_cm = rgb_channel_major ? 1 : 0;
 
-    // square image -> XCD strip order; otherwise linear order
-    int R = 0;
-    for (int r = 1; r * r <= M; ++r) if (r * r == M) R = r;
+    // (R computed above: square image -> XCD strip order; otherwise linear order)
     const int waves_needed = nrays;
     int grid = 512;                                   // 2 blocks per CU on 256 CUs, multiple of 8 (XCD strips)
     const int max_blocks = ((waves_needed + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8;

@@ -160,11 +160,11 @@ class ClipRenderer:
         G = self.G
         G.renderer.seed = frame_seed(self.base_seed, t)
         cam = self.cameras[t: t + 1]
-        o, d = G.ray_sampler(cam[:, :16].view(-1, 4, 4), cam[:, 16:25].view(-1, 3, 3), G.neural_rendering_resolution)
         ren = G.renderer
         keep, ren.need_depth = ren.need_depth, False          # only the frames leave this driver: no depth image, no clamp launch
         try:
-            feat, depth, wsum, valid = ren(self.planes_for(t), G.decoder, o, d, G.rendering_kwargs)
+            feat, depth, wsum, valid = ren.forward_camera(self.planes_for(t), G.decoder, cam[:, :16].view(-1, 4, 4), cam[:, 16:25].view(-1, 3, 3),
+                                                          G.neural_rendering_resolution, G.rendering_kwargs)
         finally:
             ren.need_depth = keep                             # (G.synthesis() on the same generator still gets its depth)
         R = G.neural_rendering_resolution

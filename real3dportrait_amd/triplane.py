@@ -86,8 +86,13 @@ class TriPlaneGenerator(nn.Module):
     def _ray_images(self, planes, camera):
         """Rays -> fused HIP renderer -> the 'raw' neural-rendered images [N,C,R,R] (triplane.py:96-127 / secc_img2plane.py:99-130)."""
         R = self.neural_rendering_resolution
-        origins, directions = self.ray_sampler(camera[:, :16].view(-1, 4, 4), camera[:, 16:25].view(-1, 3, 3), R)
-        feat, depth, wsum, valid = self.renderer(planes, self.decoder, origins, directions, self.rendering_kwargs)   # [N, R*R, C]
+        c2w, K = camera[:, :16].view(-1, 4, 4), camera[:, 16:25].view(-1, 3, 3)
+        if type(self.ray_sampler) is RaySampler and type(self.renderer) is ImportanceRenderer:
+            # both operators are the HIP ones: the rays are generated inside the render launches (same pixels, triplane.py:96-99 + :113)
+            feat, depth, wsum, valid = self.renderer.forward_camera(planes, self.decoder, c2w, K, R, self.rendering_kwargs)
+        else:
+            origins, directions = self.ray_sampler(c2w, K, R)
+            feat, depth, wsum, valid = self.renderer(planes, self.decoder, origins, directions, self.rendering_kwargs)   # [N, R*R, C]
         N = feat.shape[0]
         to_img = lambda t: t.transpose(1, 2).reshape(N, t.shape[-1], R, R)
         images = {"feature": to_img(feat).contiguous(), "depth": to_img(depth), "weights": to_img(wsum).contiguous()}

@@ -179,19 +179,31 @@ class ImportanceRenderer(nn.Module):
             raise NotImplementedError("density_noise is a training-only branch")
 
     # -- forward ----------------------------------------------------------------------------------------
-    def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options):
+    def forward_camera(self, planes, decoder, cam2world_matrix, intrinsics, resolution, rendering_options):
+        """RaySampler.forward + forward in one call: the rays are generated inside the kernels (r3d_render_forward's camera mode) with the
+        instruction sequence of r3d_raygen -- identical pixels, one launch and two [N,M,3] arrays less.  Same return value as forward."""
+        return self.forward(planes, decoder, None, None, rendering_options, _camera=(_f32c(cam2world_matrix), _f32c(intrinsics), int(resolution)))
+
+    def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options, _camera=None):
         lib = _lib.load()
         self._check_options(rendering_options)
         planes_nhwc = self._planes_nhwc(planes)
         N, H, W = planes_nhwc.shape[0], planes_nhwc.shape[-3], planes_nhwc.shape[-2]
         D = self.triplane_depth
         assert planes_nhwc.dim() == (5 if D == 1 else 6) and (D == 1 or planes_nhwc.shape[2] == D), planes_nhwc.shape
-        o, d = _f32c(ray_origins), _f32c(ray_directions)
-        M = o.shape[1]
+        if _camera is not None:
+            c2w, K, R = _camera
+            assert c2w.shape[0] == N and tuple(c2w.shape[1:]) == (4, 4) and tuple(K.shape) == (N, 3, 3), (c2w.shape, K.shape)
+            o = d = None
+            M = R * R
+        else:
+            c2w = K = None
+            o, d = _f32c(ray_origins), _f32c(ray_directions)
+            M = o.shape[1]
         Nc = int(rendering_options["depth_resolution"])
         Nf = int(rendering_options["depth_resolution_importance"])
         w1, b1, w2, b2 = decoder_params(decoder)
-        dev = o.device
+        dev = planes_nhwc.device
 
         noise_c = u_f = None
         if self.noise_override is not None:
@@ -224,7 +236,7 @@ class ImportanceRenderer(nn.Module):
             int(bool(rendering_options.get("white_back", False))),
             _lib.ptr(noise_c), _lib.ptr(u_f), int(self.seed) & 0xFFFFFFFFFFFFFFFF,
             _lib.ptr(rgb_cm), int(self.rgb_channel_major), _lib.ptr(depth), _lib.ptr(wsum), _lib.ptr(valid),
-            None if part is None else part.data_ptr(), npart,
+            None if part is None else part.data_ptr(), npart, _lib.ptr(c2w), _lib.ptr(K),
             _lib.ptr(self._workspace), need, _lib.stream_ptr()), "render_forward")
         return rgb, depth, wsum, valid
 

@@ -618,3 +618,30 @@ def test_sr_resize_golden(torch_cuda, tag):
     e = max(np.abs(out[:, :, ::4, ::4] - g["strided_" + tag]).max(), np.abs(out[:, :, :64, :64] - g["corner_" + tag]).max())
     print("sr_resize %s (%d^2 -> 128^2): max err %.2e (tol %.1e)" % (tag, r, e, tol))
     assert e <= tol
+
+
+def test_camera_mode_equals_explicit_rays(torch_cuda):
+    """r3d_render_forward's camera mode (rays generated inside the limits pass and the render kernel) must render the pixels of
+    RaySampler + explicit ray arrays bit for bit -- N = 2 cameras, invalid rays included (camera pushed sideways), depth and validity too."""
+    torch = torch_cuda
+    from real3dportrait_amd import ImportanceRenderer, RaySampler, synth
+    planes = T(torch, synth.synth_planes(5, N=2, H=64, W=64))
+    dec = make_decoder(torch, synth.synth_decoder(6, sigma_bias=3.0))
+    cams = synth.camera_sweep(2, -0.3, 0.3).copy()
+    cams[1, 3] += 0.45
+    cams = T(torch, cams)
+    c2w, K = cams[:, :16].view(-1, 4, 4), cams[:, 16:].view(-1, 3, 3)
+    R, Nc, Nf = 40, 24, 24
+    outs = []
+    for mode in ("rays", "camera"):
+        ren = ImportanceRenderer(hp={})
+        ren.noise_mode, ren.seed = "hash", 123
+        if mode == "rays":
+            o, d = RaySampler()(c2w, K, R)
+            outs.append(ren(planes, dec, o, d, opts(Nc, Nf)))
+        else:
+            outs.append(ren.forward_camera(planes, dec, c2w, K, R, opts(Nc, Nf)))
+    torch.cuda.synchronize()
+    assert not bool(outs[0][3].all()) and bool(outs[0][3].any())          # the case has valid and invalid rays
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
