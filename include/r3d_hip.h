@@ -103,10 +103,14 @@ int r3d_render_forward(const float* planes_nhwc, int N, int H, int W, int tripla
                        float* rgb, int rgb_channel_major, float* depth, float* wsum, uint8_t* valid,
                        const float* plane_absmax, int n_plane_absmax,
                        const float* cam2world, const float* intrinsics,
+                       void* split_out, const float* split_scale, size_t split_scale_stride,
                        void* workspace, size_t workspace_bytes, r3d_stream_t stream);
 /* Camera mode (origins = dirs = NULL, cam2world [N,4,4] + intrinsics [N,3,3] given, M = R * R): RaySampler.forward is evaluated inside
  * the limits pass and the render kernel with r3d_raygen's instruction sequence -- the same pixels as r3d_raygen + the ray arrays, without
- * the launch and the two [N,M,3] round trips.  cam2world / intrinsics are ignored when origins / dirs are given (pass NULL). */
+ * the launch and the two [N,M,3] round trips.  cam2world / intrinsics are ignored when origins / dirs are given (pass NULL).
+ * split_out (may be NULL): a second copy of the colours in R3D_FMT_SPLIT ([N][hi|lo][4][M][8] fp16), multiplied by split_scale[n][c]
+ * (stride split_scale_stride floats; = the start of the consuming SR block's styles buffer AFTER r3d_chain_fold): the input of
+ * r3d_sr_block_forward(x_format = R3D_FMT_SPLIT) without a conversion launch. */
 
 /* Replaces ImportanceRenderer.run_model(planes, decoder, sample_coordinates, sample_directions, options)
  * (renderer.py:169-188; inference branches) -- the point-query used by .sample() (triplane.py:140-148).

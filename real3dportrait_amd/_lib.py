@@ -27,7 +27,7 @@ SIGNATURES = {
     "r3d_raygen": (c_int, [P, P, c_int, c_int, P, P, P]),
     "r3d_render_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "r3d_render_forward": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, P, P, c_int, c_int, c_int, c_float, c_int,
-                                   P, P, c_uint64, P, c_int, P, P, P, P, c_int, P, P, P, c_size_t, P]),
+                                   P, P, c_uint64, P, c_int, P, P, P, P, c_int, P, P, P, P, c_size_t, P, c_size_t, P]),
     "r3d_run_model": (c_int, [P, c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, c_float, P, P, P, c_int, P, c_size_t, P]),
     "r3d_run_model_workspace_bytes": (c_size_t, []),
     "r3d_sr_block_prepacked_bytes": (c_size_t, [c_int, c_int]),

@@ -47,6 +47,20 @@ __device__ __forceinline__ uint8_t frame_u8(float v) {
     return (uint8_t)(int)((v + 1.0f) * 127.5f);
 }
 
+// ---- fp32 -> SPLIT (fp16 hi + fp16 lo) of x * s, the conversion every producer of an SR block's first operand performs (to_split_kernel in
+// r3d_sr_f16x3.hip, the ray kernel's split_out in r3d_render.hip).  The residual comes from the exact product (one fma).  The fma is
+// opaque to the compiler on purpose: left to itself it folds fptrunc(fma) into v_fma_mixlo_f16 at some sites and not at others
+// (single vs double rounding: a 1-ulp difference of lo on fp16 ties, seen as a 3e-5 difference of the SR image between two
+// producers), and the producers must agree bit for bit.
+__device__ __forceinline__ void split_scaled(float x, float s, _Float16& hi, _Float16& lo) {
+    const float p = x * s;
+    hi = (_Float16)fminf(fmaxf(p, -65504.f), 65504.f);
+    const float h32 = (float)hi;
+    float r;
+    asm("v_fma_f32 %0, %1, %2, -%3" : "=v"(r) : "v"(x), "v"(s), "v"(h32));
+    lo = (_Float16)r;
+}
+
 // ---- counter-based uniform [0,1) (used when the caller passes no noise tensors) ---------------------
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;

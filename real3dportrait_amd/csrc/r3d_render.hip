@@ -772,6 +772,7 @@ struct RenderArgs {
     const float* w1; const float* b1; const float* w2; const float* b2;
     const float* origins; const float* dirs;        // NULL in camera mode: rays from (cam_c2w, cam_K, cam_R), image n = ray / M
     const float* cam_c2w; const float* cam_K; int cam_R;
+    uint2* split_out; const float* split_scale; size_t split_scale_stride;     // optional second copy of the colours: the SPLIT operand of the SR's first conv
     const float* ray_start; const float* ray_end; const uint8_t* valid;
     int* gstate; int nlimit_blocks;
     int Nc, Nf; float scale; int white_back;
@@ -1113,6 +1114,29 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
                 if (a.white_back) v = v + 1.0f - wsum;
                 acc[ot][r] = v * 2.0f - 1.0f;            // ray_marcher.py:52-55
             }
+        if (s == 0 && a.split_out) {
+            // the feature image a second time, as the SR's first operand wants it: times block0.conv0's folded style vector, split into
+            // fp16 hi + lo, [n][hi|lo][c/8][pixel][8] -- what to_split_kernel would produce from the fp32 copy (its launch and the 2 MB
+            // round trip are gone).  Lane q: channels 4q..4q+3 = half (q & 1) of chunk q >> 1, channels 16+4q.. = chunk 2 + (q >> 1).
+            const float* sc = a.split_scale + (size_t)n * a.split_scale_stride;
+            const size_t pix = (size_t)(ray - n * a.M), plane = (size_t)(kC / 8) * a.M;
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+                const float4 s4 = *reinterpret_cast<const float4*>(sc + 16 * ot + 4 * q);
+                const float sv[4] = {s4.x, s4.y, s4.z, s4.w};
+                typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+                h4v hi, lo;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    _Float16 hh, ll;
+                    split_scaled(acc[ot][r], sv[r], hh, ll);              // r3d_common.h: bit for bit what to_split_kernel stores
+                    hi[r] = hh; lo[r] = ll;
+                }
+                uint2* dst = a.split_out + (((size_t)n * 2 * plane + (size_t)(2 * ot + (q >> 1)) * a.M + pix) * 2 + (q & 1));
+                dst[0] = *reinterpret_cast<uint2*>(&hi);
+                dst[2 * plane] = *reinterpret_cast<uint2*>(&lo);
+            }
+        }
         if (s == 0) {
             if (a.rgb_cm) {                                 // lane q holds channels 4q..4q+3 and 16+4q..16+4q+3 of the ray
                 float* o = a.rgb + ((size_t)n * kC + 4 * q) * a.M + (ray - n * a.M);
@@ -1309,8 +1333,12 @@ extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
                                   float* rgb, int rgb_channel_major, float* depth, float* wsum, uint8_t* valid,
                                   const float* plane_absmax, int n_plane_absmax,
                                   const float* cam2world, const float* intrinsics,
+                                  void* split_out, const float* split_scale, size_t split_scale_stride,
                                   void* workspace, size_t workspace_bytes, r3d_stream_t stream)
 {
+    if (split_out && (!split_scale || ((uintptr_t)split_out & 15) || ((uintptr_t)split_scale & 15) || (split_scale_stride & 3))) {
+        set_error("render_forward: split_out needs a 16-byte aligned split_scale [N][32] (stride a multiple of 4 floats)"); return R3D_ERR_INVALID_ARG;
+    }
     const bool cam = origins == nullptr && dirs == nullptr && cam2world != nullptr && intrinsics != nullptr;
     if (!planes_nhwc || !w1 || !b1 || !w2 || !b2 || (!cam && (!origins || !dirs)) || !rgb || !wsum || !valid) {
         set_error("render_forward: NULL pointer (rays: origins + dirs, or cam2world + intrinsics with origins = dirs = NULL)"); return R3D_ERR_INVALID_ARG;
@@ -1350,6 +1378,7 @@ extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
     }
     a.planes4 = reinterpret_cast<const float4*>(planes_nhwc); a.N = N; a.H = H; a.W = W; a.M = M; a.D = triplane_depth;
     a.w1 = w1; a.b1 = b1; a.w2 = w2; a.b2 = b2;
+    a.split_out = reinterpret_cast<uint2*>(split_out); a.split_scale = split_scale; a.split_scale_stride = split_scale_stride;
     a.cam_c2w = cam ? cam2world : nullptr; a.cam_K = cam ? intrinsics : nullptr; a.cam_R = R;
     a.origins = origins; a.dirs = dirs; a.ray_start = ray_start; a.ray_end = ray_end; a.valid = valid;
     a.gstate = gstate; a.nlimit_blocks = (nrays + kLimitsBlock - 1) / kLimitsBlock; a.Nc = Nc; a.Nf = Nf; a.scale = 2.0f / box_warp; a.white_back = white_back;

@@ -172,7 +172,7 @@ __global__ void to_split_kernel(const float* __restrict__ src, int cb8, const fl
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const float sc = (scale && cb * 8 + c < Creal) ? scale[n * scale_stride_n + cb * 8 + c] : 1.f;
-        _Float16 a, b; split1(v[c] * sc, a, b); hi[c] = a; lo[c] = b;
+        _Float16 a, b; split_scaled(v[c], sc, a, b); hi[c] = a; lo[c] = b;
     }
     const size_t plane = (size_t)(C / 8) * HW;
     uint4* d = dst + (size_t)n * 2 * plane + (size_t)cb * HW + p;

@@ -161,20 +161,25 @@ class ClipRenderer:
         G.renderer.seed = frame_seed(self.base_seed, t)
         cam = self.cameras[t: t + 1]
         ren = G.renderer
+        R = G.neural_rendering_resolution
+        sr = G.superresolution
+        # the ray kernel writes the SR's first operand itself (SPLIT copy of the feature image) when the SR takes 128^2 inputs as they come
+        spec = sr.split_input_spec(self.ws, 1, cam.device) if (hasattr(sr, "split_input_spec") and R == getattr(sr, "input_resolution", -1)) else None
         keep, ren.need_depth = ren.need_depth, False          # only the frames leave this driver: no depth image, no clamp launch
         try:
             feat, depth, wsum, valid = ren.forward_camera(self.planes_for(t), G.decoder, cam[:, :16].view(-1, 4, 4), cam[:, 16:25].view(-1, 3, 3),
-                                                          G.neural_rendering_resolution, G.rendering_kwargs)
+                                                          R, G.rendering_kwargs, _split_for=spec)
         finally:
             ren.need_depth = keep                             # (G.synthesis() on the same generator still gets its depth)
-        R = G.neural_rendering_resolution
         fimg = feat.permute(0, 2, 1).reshape(1, 32, R, R).contiguous()
         fimg._r3d_bound = const_bound(1.01, 1, fimg.device)
+        fimg._r3d_split = getattr(feat, "_r3d_split", None)
         return fimg
 
     def render_image(self, t):
         fimg = self._features(t)
-        return self.G.superresolution(fimg[:, :3], fimg, self.ws, noise_mode="none")
+        x = fimg._r3d_split if fimg._r3d_split is not None else fimg
+        return self.G.superresolution(fimg[:, :3], x, self.ws, noise_mode="none")
 
     def render_u8(self, t, out=None):
         """Frame t as uint8 [H,W,3] (into `out` [1,H,W,3] if given).  With the f16x3 SR the clamp -> uint8 conversion of
@@ -184,10 +189,11 @@ class ClipRenderer:
         sr = self.G.superresolution
         if out is None:
             out = torch.empty(1, 512, 512, 3, dtype=torch.uint8, device=fimg.device)
+        x = fimg._r3d_split if fimg._r3d_split is not None else fimg
         if sr.block0.precision == "f16x3":
-            sr(fimg[:, :3], fimg, self.ws, noise_mode="none", _u8_out=out, _need_img=False)
+            sr(fimg[:, :3], x, self.ws, noise_mode="none", _u8_out=out, _need_img=False)
         else:
-            img = sr(fimg[:, :3], fimg, self.ws, noise_mode="none").contiguous()
+            img = sr(fimg[:, :3], x, self.ws, noise_mode="none").contiguous()
             N, _, H, W = img.shape
             self._lib.check(lib.r3d_frames_to_u8(self._lib.ptr(img), N, H, W, self._lib.ptr(out), self._lib.stream_ptr()),
                             "frames_to_u8")

@@ -685,38 +685,68 @@ class SuperresolutionHybrid8XDC(nn.Module):
         self._ws3 = (ws, ws._version, ws3)
         return ws3
 
-    def forward(self, rgb, x, ws, _u8_out=None, _need_img=True, **block_kwargs):
-        """_u8_out: optional uint8 [N,512,512,3] tensor that receives clamp(-1,1) -> ((x+1)/2*255).int() of the result, fused
-        into the last block's toRGB kernel (the conversion real3d_infer.py:472,518-522 does per frame); with
-        _need_img=False the fp32 image is not materialised and None is returned."""
+    FEATURE_BOUND = 1.01      # |renderer feature image| <= 1.002 by construction (sigmoid * 1.002 - 0.001 composited with weights summing to <= 1)
+
+    def _prepare_and_fold(self, ws, N, dev, bx, dx):
+        """Style vectors of both blocks (cached per ws) + the range fold for an input bounded by bx (skipped while nothing it depends on
+        changed).  Returns (ws3, prep0, prep1, x_absmax slot or None)."""
         ws3 = self._ws_last3(ws)
-        if x.shape[-1] != self.input_resolution:      # :351-355: any other neural-rendering resolution is resampled to 128^2 first
-            sz = (self.input_resolution, self.input_resolution)
-            x, rgb = resize_bilinear(x, sz, self.sr_antialias), resize_bilinear(rgb, sz, self.sr_antialias)
         b0, b1 = self.block0, self.block1
         b1.precision = b0.precision
-        prep0 = b0.prepare(ws3, x.device, ws_key=ws)
-        prep1 = b1.prepare(ws3, x.device, ws_key=ws)
+        prep0 = b0.prepare(ws3, dev, ws_key=ws)
+        prep1 = b1.prepare(ws3, dev, ws_key=ws)
         mx = b0.precision == "f16mx"
         x_absmax = None
         if b0.precision in ("f16x3", "f16mx"):
             # one fold launch for both blocks; block0's conv1 epilogue then emits its output already multiplied by block1.conv0's
             # folded styles and split into fp16 hi/lo planes, so block1 stages its input with plain copies
-            x = _keep_tags(x)
-            bx, dx = bound_of(x, self._meter, layers=4 if not mx else MAX_DEPTH + 1)
             b0._depth_in, b1._depth_in = dx, dx + 2
             if mx:      # block1's conv1 operand must sit within one layer of a measurement: block0 measures max|x0| in its epilogue
-                if self._mx_slot is None or self._mx_slot.shape[0] != x.shape[0] or self._mx_slot.device != x.device:
-                    self._mx_slot = torch.zeros(x.shape[0], device=x.device, dtype=torch.float32)
+                if self._mx_slot is None or self._mx_slot.shape[0] != N or self._mx_slot.device != dev:
+                    self._mx_slot = torch.zeros(N, device=dev, dtype=torch.float32)
                 x_absmax = self._mx_slot
             # The fold is a function of (bx, both blocks' style vectors).  With a constant bound (the renderer's feature image,
             # const_bound) and the per-clip style cache unchanged, the folded vectors of the previous frame are still in place:
             # skip the launch (13 us per frame).  f16mx re-folds block1 from a measured max every frame: never skipped.
             sig = (id(bx), dx, b0._styles_key, b1._styles_key, b0._fold_epoch, b1._fold_epoch, b0.precision)
             if mx or not getattr(bx, "_r3d_const", False) or self._fold_sig != sig:
-                chain_fold([b0.chain_op(-1), b1.chain_op(0)], x.shape[0], [bx], zero=[x_absmax] if mx else ())
+                chain_fold([b0.chain_op(-1), b1.chain_op(0)], N, [bx], zero=[x_absmax] if mx else ())
                 self._fold_sig = (id(bx), dx, b0._styles_key, b1._styles_key, b0._fold_epoch, b1._fold_epoch, b0.precision)
                 self._fold_bx = bx           # keeps id(bx) from being recycled
+        return ws3, prep0, prep1, x_absmax
+
+    def split_input_spec(self, ws, N, dev):
+        """For a producer that writes this network's input directly in the SPLIT format (the ray kernel, r3d_render_forward `split_out`):
+        makes sure the styles and the fold for the renderer's feature image (|x| <= FEATURE_BOUND) are in place and returns
+        (folded input multiplier as a float tensor, per-sample stride in floats, consuming block); None for the exact-f32 precision."""
+        if self.block0.precision not in ("f16x3", "f16mx"):
+            return None
+        self._prepare_and_fold(ws, N, dev, const_bound(self.FEATURE_BOUND, N, dev), 0)
+        scale, stride = self.block0.in_scale()
+        return scale, stride, self.block0
+
+    def forward(self, rgb, x, ws, _u8_out=None, _need_img=True, **block_kwargs):
+        """_u8_out: optional uint8 [N,512,512,3] tensor that receives clamp(-1,1) -> ((x+1)/2*255).int() of the result, fused
+        into the last block's toRGB kernel (the conversion real3d_infer.py:472,518-522 does per frame); with
+        _need_img=False the fp32 image is not materialised and None is returned.
+        x may be the renderer's SPLIT copy of the feature image (produced for `split_input_spec`): no conversion launch then."""
+        b0, b1 = self.block0, self.block1
+        x_is_split = getattr(x, "_r3d_fmt", None) == "split"
+        if x_is_split:
+            N, dev = x.shape[0], x.device
+            bx, dx = const_bound(self.FEATURE_BOUND, N, dev), 0          # the bound split_input_spec folded for
+        else:
+            if x.shape[-1] != self.input_resolution:      # :351-355: any other neural-rendering resolution is resampled to 128^2 first
+                sz = (self.input_resolution, self.input_resolution)
+                x, rgb = resize_bilinear(x, sz, self.sr_antialias), resize_bilinear(rgb, sz, self.sr_antialias)
+            N, dev = x.shape[0], x.device
+            bx, dx = None, 0
+            if b0.precision in ("f16x3", "f16mx"):
+                x = _keep_tags(x)
+                bx, dx = bound_of(x, self._meter, layers=4 if b0.precision != "f16mx" else MAX_DEPTH + 1)
+        ws3, prep0, prep1, x_absmax = self._prepare_and_fold(ws, N, dev, bx, dx)
+        mx = b0.precision == "f16mx"
+        if b0.precision in ("f16x3", "f16mx"):
             b0.out_format, nxt = "split", b1
         else:
             b0.out_format, nxt = "cb8", None

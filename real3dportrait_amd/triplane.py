@@ -83,19 +83,28 @@ class TriPlaneGenerator(nn.Module):
             self._last_planes = planes
         return planes.view(len(planes), 3, -1, planes.shape[-2], planes.shape[-1])
 
-    def _ray_images(self, planes, camera):
-        """Rays -> fused HIP renderer -> the 'raw' neural-rendered images [N,C,R,R] (triplane.py:96-127 / secc_img2plane.py:99-130)."""
+    def _ray_images(self, planes, camera, sr_ws=None):
+        """Rays -> fused HIP renderer -> the 'raw' neural-rendered images [N,C,R,R] (triplane.py:96-127 / secc_img2plane.py:99-130).
+        sr_ws: the ws the SR will be called with next; when the SR is the HIP one and takes R^2 inputs as they come, the ray kernel
+        also writes its first operand (images["feature_split"], ImportanceRenderer.forward `_split_for`)."""
         R = self.neural_rendering_resolution
         c2w, K = camera[:, :16].view(-1, 4, 4), camera[:, 16:25].view(-1, 3, 3)
+        split = None
         if type(self.ray_sampler) is RaySampler and type(self.renderer) is ImportanceRenderer:
             # both operators are the HIP ones: the rays are generated inside the render launches (same pixels, triplane.py:96-99 + :113)
-            feat, depth, wsum, valid = self.renderer.forward_camera(planes, self.decoder, c2w, K, R, self.rendering_kwargs)
+            sr = self.superresolution
+            spec = None
+            if (sr_ws is not None and hasattr(sr, "split_input_spec") and R == getattr(sr, "input_resolution", -1)
+                    and not self.hparams.get("mask_invalid_rays", False)):          # (the mask edits the fp32 image afterwards)
+                spec = sr.split_input_spec(sr_ws, c2w.shape[0], c2w.device)
+            feat, depth, wsum, valid = self.renderer.forward_camera(planes, self.decoder, c2w, K, R, self.rendering_kwargs, _split_for=spec)
+            split = getattr(feat, "_r3d_split", None)
         else:
             origins, directions = self.ray_sampler(c2w, K, R)
             feat, depth, wsum, valid = self.renderer(planes, self.decoder, origins, directions, self.rendering_kwargs)   # [N, R*R, C]
         N = feat.shape[0]
         to_img = lambda t: t.transpose(1, 2).reshape(N, t.shape[-1], R, R)
-        images = {"feature": to_img(feat).contiguous(), "depth": to_img(depth), "weights": to_img(wsum).contiguous()}
+        images = {"feature": to_img(feat).contiguous(), "depth": to_img(depth), "weights": to_img(wsum).contiguous(), "feature_split": split}
         if self.hparams.get("mask_invalid_rays", False):
             # feature <- -1 and depth <- min valid depth on rays that miss the box (triplane.py:123-126), without the
             # reference's host sync (.item()) and boolean indexing
@@ -119,13 +128,15 @@ class TriPlaneGenerator(nn.Module):
         """triplane.py:90-138.  Returns the reference's keys plus 'weights_img' (the name the Real3D shells use,
         secc_img2plane.py:132)."""
         planes = self._planes(ws, update_emas, cache_backbone, use_cached_backbone, synthesis_kwargs)
-        im = self._ray_images(planes, camera)
+        sr_ws = self._ws_for_sr(ws)
+        im = self._ray_images(planes, camera, sr_ws=None if synthesis_kwargs else sr_ws)
         feature = im["feature"]
         # |feature| <= 1.002 by construction (sigmoid * 1.002 - 0.001 composited with weights summing to <= 1, then * 2 - 1):
         # the SR's fp16 range fold uses this bound instead of measuring it
         feature._r3d_bound, feature._r3d_depth = const_bound(1.01, feature.shape[0], feature.device), 0
         sr_kwargs = {k: v for k, v in synthesis_kwargs.items() if k != "noise_mode"}
-        sr_image = self.superresolution(feature[:, :3], feature, self._ws_for_sr(ws),
+        x = im["feature_split"] if im.get("feature_split") is not None else feature
+        sr_image = self.superresolution(feature[:, :3], x, sr_ws,
                                         noise_mode=self.rendering_kwargs["superresolution_noise_mode"], **sr_kwargs)
         return {"image": sr_image.clamp(-1, 1), "image_raw": feature[:, :3].clamp(-1, 1), "image_depth": im["depth"],
                 "image_feature": feature[:, 3:], "plane": planes, "weights_img": im["weights"]}

@@ -179,12 +179,15 @@ class ImportanceRenderer(nn.Module):
             raise NotImplementedError("density_noise is a training-only branch")
 
     # -- forward ----------------------------------------------------------------------------------------
-    def forward_camera(self, planes, decoder, cam2world_matrix, intrinsics, resolution, rendering_options):
+    def forward_camera(self, planes, decoder, cam2world_matrix, intrinsics, resolution, rendering_options, _split_for=None):
         """RaySampler.forward + forward in one call: the rays are generated inside the kernels (r3d_render_forward's camera mode) with the
-        instruction sequence of r3d_raygen -- identical pixels, one launch and two [N,M,3] arrays less.  Same return value as forward."""
-        return self.forward(planes, decoder, None, None, rendering_options, _camera=(_f32c(cam2world_matrix), _f32c(intrinsics), int(resolution)))
+        instruction sequence of r3d_raygen -- identical pixels, one launch and two [N,M,3] arrays less.  Same return value as forward.
+        _split_for = (scale float tensor, per-sample stride in floats, consumer module): the colours are ALSO written as the consumer's
+        SPLIT operand (fp16 hi / lo, times its folded input multiplier); the tensor comes back as `rgb._r3d_split`."""
+        return self.forward(planes, decoder, None, None, rendering_options, _camera=(_f32c(cam2world_matrix), _f32c(intrinsics), int(resolution)),
+                            _split_for=_split_for)
 
-    def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options, _camera=None):
+    def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options, _camera=None, _split_for=None):
         lib = _lib.load()
         self._check_options(rendering_options)
         planes_nhwc = self._planes_nhwc(planes)
@@ -230,6 +233,12 @@ class ImportanceRenderer(nn.Module):
         if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
             self._workspace = torch.empty(need, device=dev, dtype=torch.uint8)
         part, npart = getattr(planes_nhwc, "_r3d_absmax", (None, 0))        # absent (caller's own layout): measured inside the call
+        x_split, sp_scale, sp_stride = None, None, 0
+        if _split_for is not None:
+            sp_scale, sp_stride, consumer = _split_for
+            R = int(round(M ** 0.5))
+            assert R * R == M, "the SPLIT copy is an image: M must be a square"
+            x_split = torch.empty(N, 2, 4, R, R, 8, device=dev, dtype=torch.float16)
         _lib.check(lib.r3d_render_forward(
             _lib.ptr(planes_nhwc), N, H, W, D, _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2), _lib.ptr(b2),
             _lib.ptr(o), _lib.ptr(d), M, Nc, Nf, float(rendering_options["box_warp"]),
@@ -237,7 +246,11 @@ class ImportanceRenderer(nn.Module):
             _lib.ptr(noise_c), _lib.ptr(u_f), int(self.seed) & 0xFFFFFFFFFFFFFFFF,
             _lib.ptr(rgb_cm), int(self.rgb_channel_major), _lib.ptr(depth), _lib.ptr(wsum), _lib.ptr(valid),
             None if part is None else part.data_ptr(), npart, _lib.ptr(c2w), _lib.ptr(K),
+            _lib.ptr(x_split), None if sp_scale is None else sp_scale.data_ptr(), int(sp_stride),
             _lib.ptr(self._workspace), need, _lib.stream_ptr()), "render_forward")
+        if x_split is not None:
+            x_split._r3d_fmt, x_split._r3d_for = "split", consumer
+            rgb._r3d_split = x_split
         return rgb, depth, wsum, valid
 
     def run_model(self, planes, decoder, sample_coordinates, sample_directions, options):

@@ -44,17 +44,20 @@ def test_argument_errors_are_reported_not_thrown():
     assert rc == -1 and b"raygen" in lib.r3d_last_error()
     one = ctypes.c_void_p(64)      # never dereferenced: validation fails first
     rc = lib.r3d_render_forward(one, 1, 32, 32, 1, one, one, one, one, one, one, 256, 200, 0, 1.0, 0, None, None, 0,
-                                one, 0, one, one, one, None, 0, None, None, one, 1 << 20, None)
+                                one, 0, one, one, one, None, 0, None, None, None, None, 0, one, 1 << 20, None)
     assert rc == -1 and b"depth_resolution" in lib.r3d_last_error()
     rc = lib.r3d_render_forward(one, 1, 32, 32, 1, one, one, one, one, one, one, 256, 48, 48, 1.0, 0, None, None, 0,
-                                one, 1, None, one, one, None, 0, None, None, one, 8, None)
+                                one, 1, None, one, one, None, 0, None, None, None, None, 0, one, 8, None)
     assert rc == -2 and b"workspace" in lib.r3d_last_error()
     rc = lib.r3d_render_forward(one, 1, 32, 32, 1, one, one, one, one, None, None, 250, 48, 48, 1.0, 0, None, None, 0,
-                                one, 1, None, one, one, None, 0, one, one, one, 1 << 20, None)
+                                one, 1, None, one, one, None, 0, one, one, None, None, 0, one, 1 << 20, None)
     assert rc == -1 and b"camera mode" in lib.r3d_last_error()       # camera mode needs a square ray count
     rc = lib.r3d_render_forward(one, 1, 32, 32, 1, one, one, one, one, None, None, 256, 48, 48, 1.0, 0, None, None, 0,
-                                one, 1, None, one, one, None, 0, None, None, one, 1 << 20, None)
+                                one, 1, None, one, one, None, 0, None, None, None, None, 0, one, 1 << 20, None)
     assert rc == -1 and b"NULL pointer" in lib.r3d_last_error()      # neither rays nor a camera
+    rc = lib.r3d_render_forward(one, 1, 32, 32, 1, one, one, one, one, one, one, 256, 48, 48, 1.0, 0, None, None, 0,
+                                one, 1, None, one, one, None, 0, None, None, one, None, 0, one, 1 << 20, None)
+    assert rc == -1 and b"split_scale" in lib.r3d_last_error()
     rc = lib.r3d_run_model(one, 1, 32, 32, 1, one, one, one, one, one, 16, 1.0, one, one, None, 0, one, 8, None)
     assert rc == -2 and b"workspace" in lib.r3d_last_error()
     n = ctypes.c_int(0)

@@ -645,3 +645,31 @@ def test_camera_mode_equals_explicit_rays(torch_cuda):
     assert not bool(outs[0][3].all()) and bool(outs[0][3].any())          # the case has valid and invalid rays
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+
+
+def test_ray_kernel_split_output_equals_conversion_launch(torch_cuda):
+    """The SPLIT copy of the feature image written by the ray kernel (times block0.conv0's folded styles) must give the frame the
+    fp32 copy + to_split_kernel gives, bit for bit (uint8 ring frame and fp32 image), for a non-trivial ws."""
+    torch = torch_cuda
+    from real3dportrait_amd import TriPlaneGenerator, synth
+    from real3dportrait_amd.frames import ClipRenderer
+    G = TriPlaneGenerator().cuda().eval()
+    dec = synth.synth_decoder(3, sigma_bias=4.0)
+    with torch.no_grad():
+        G.decoder.net[0].weight.copy_(T(torch, dec[0])); G.decoder.net[0].bias.copy_(T(torch, dec[1]))
+        G.decoder.net[2].weight.copy_(T(torch, dec[2])); G.decoder.net[2].bias.copy_(T(torch, dec[3]))
+    params = synth.synth_sr_params(3)
+    load_block(torch, G.superresolution.block0, params[0]); load_block(torch, G.superresolution.block1, params[1])
+    cano = T(torch, synth.synth_planes(3, N=1)); res = [T(torch, synth.synth_planes(4, N=1, scale=0.1))]
+    cams = T(torch, synth.camera_sweep(3, -0.3, 0.3))
+    ws = torch.ones(1, 14, 512, device="cuda") + 0.1 * T(torch, synth.hash_unitvar(9, (1, 14, 512), stream=2))
+    clip = ClipRenderer(G, cano, res, cams, ws, base_seed=5)
+    for t in range(3):
+        fimg = clip._features(t)
+        assert fimg._r3d_split is not None and tuple(fimg._r3d_split.shape) == (1, 2, 4, 128, 128, 8)
+        fused_u8 = clip.render_u8(t).clone()
+        fused = G.superresolution(fimg[:, :3], fimg._r3d_split, ws, noise_mode="none").clone()
+        plain = G.superresolution(fimg[:, :3], fimg, ws, noise_mode="none")
+        assert torch.equal(fused, plain)
+        u8 = ((plain[0].clamp(-1, 1).permute(1, 2, 0) + 1) / 2 * 255).int().to(torch.uint8)
+        assert torch.equal(fused_u8, u8)
