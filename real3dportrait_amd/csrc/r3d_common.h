@@ -47,6 +47,14 @@ __device__ __forceinline__ uint8_t frame_u8(float v) {
     return (uint8_t)(int)((v + 1.0f) * 127.5f);
 }
 
+// ---- "this fp32 value, as rounded, and nothing else".  Every fp32 -> fp16 hi/lo split starts with it.  Without it hipcc (contract = fast)
+// may re-derive the value from its factors at one use and not at another: for  v = a * b; hi = fp16(v); lo = fp16(v - float(hi))  it
+// emitted hi (stored) = v_cvt_pk_f16_f32(fl32(a * b)) but lo = v_fma_mixlo_f16(a, b, -h') with h' = v_fma_mixlo_f16(a, b, 0), the SINGLY
+// rounded product: where the double rounding of `hi` and the single rounding of h' disagree, hi + lo is off by a whole fp16 ulp of hi
+// (2^-11 relative, rare) -- a 16x loss of accuracy of SynthesisBlockNoUp found by the range sweeps.  tests/test_abi.py lints the
+// device assembly for the fused-rounding form.
+__device__ __forceinline__ float as_rounded(float v) { asm("" : "+v"(v)); return v; }
+
 // ---- fp32 -> SPLIT (fp16 hi + fp16 lo) of x * s, the conversion every producer of an SR block's first operand performs (to_split_kernel in
 // r3d_sr_f16x3.hip, the ray kernel's split_out in r3d_render.hip).  The residual comes from the exact product (one fma).  The fma is
 // opaque to the compiler on purpose: left to itself it folds fptrunc(fma) into v_fma_mixlo_f16 at some sites and not at others

@@ -354,8 +354,9 @@ __device__ __forceinline__ void split8(const float (&x)[8], h8& hi, h8& lo)
 {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const _Float16 a = (_Float16)fminf(fmaxf(x[j], -65504.f), 65504.f);
-        hi[j] = a; lo[j] = (_Float16)(x[j] - (float)a);
+        const float v = as_rounded(x[j]);
+        const _Float16 a = (_Float16)fminf(fmaxf(v, -65504.f), 65504.f);
+        hi[j] = a; lo[j] = (_Float16)(v - (float)a);
     }
 }
 // the per-sample operands (gathered features, hidden values): |x| < 2^15 is GUARANTEED by the range fold (decoder_fold_block limits 2^b and

@@ -35,6 +35,7 @@ static constexpr int F_PATCH_H = F_TILE_H + 2, F_PATCH_W = F_TILE_W + 2, F_PATCH
 
 __device__ __forceinline__ void split1(float v, _Float16& hi, _Float16& lo)
 {
+    v = as_rounded(v);
     const float c = fminf(fmaxf(v, -65504.f), 65504.f);
     hi = (_Float16)c;
     lo = (_Float16)(v - (float)hi);
@@ -43,6 +44,7 @@ __device__ __forceinline__ void split1(float v, _Float16& hi, _Float16& lo)
 // hot epilogues: the range fold (r3d_chain_fold) guarantees |v| < 2^15, so the saturation of split1 is dead weight there
 __device__ __forceinline__ void split1_folded(float v, _Float16& hi, _Float16& lo)
 {
+    v = as_rounded(v);
     hi = (_Float16)v;
     lo = (_Float16)(v - (float)hi);
 }
@@ -241,6 +243,9 @@ template <bool FULL_EPI, int WN, int NT>
 __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhase& ph, int n, f32x16 (&acc)[2][NT],
                                               int i0, int j0, int m0, float* ev)
 {
+    // The instantiations of this epilogue (tile shapes, MX) must agree bit for bit -- a layer may run on 16x16 or 8x16 tiles depending on
+    // the batch size -- so nothing here is left to the compiler's contraction choices: every fma is spelled out.
+#pragma clang fp contract(off)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave / WN, wn = wave - wm * WN;
     const int li = lane & 31, h = lane >> 5;
@@ -305,18 +310,19 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
                 float v[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float t = acc[mt][nt][4 * g + r] * dv[r];
+                    float t;
                     if (FULL_EPI) {
-                        t += bv[r];
+                        t = __builtin_fmaf(acc[mt][nt][4 * g + r], dv[r], bv[r]);
                         if (a.act) t = (t < 0.f ? t * a.act_slope : t) * a.act_gain;
                         if (a.clamp >= 0.f) t = fminf(fmaxf(t, -a.clamp), a.clamp);
                     }
+                    else t = acc[mt][nt][4 * g + r] * dv[r];
                     v[r] = t;
                 }
                 if (do_rgb) {
-                    rgbp[nt][0] += v[0] * w0.x + v[1] * w0.y + v[2] * w0.z + v[3] * w0.w;
-                    rgbp[nt][1] += v[0] * w1.x + v[1] * w1.y + v[2] * w1.z + v[3] * w1.w;
-                    rgbp[nt][2] += v[0] * w2.x + v[1] * w2.y + v[2] * w2.z + v[3] * w2.w;
+                    rgbp[nt][0] = __builtin_fmaf(v[3], w0.w, __builtin_fmaf(v[2], w0.z, __builtin_fmaf(v[1], w0.y, __builtin_fmaf(v[0], w0.x, rgbp[nt][0]))));
+                    rgbp[nt][1] = __builtin_fmaf(v[3], w1.w, __builtin_fmaf(v[2], w1.z, __builtin_fmaf(v[1], w1.y, __builtin_fmaf(v[0], w1.x, rgbp[nt][1]))));
+                    rgbp[nt][2] = __builtin_fmaf(v[3], w2.w, __builtin_fmaf(v[2], w2.z, __builtin_fmaf(v[1], w2.y, __builtin_fmaf(v[0], w2.x, rgbp[nt][2]))));
                 }
                 if (!inside) continue;
                 if (want_max) vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
@@ -557,12 +563,21 @@ static constexpr int F3_LDS_UINT4 = 2 * P_BUF + 2 * W2_BUF;           // 4736 ui
 
 typedef int i8v __attribute__((ext_vector_type(8)));
 
-template <bool FULL_EPI, bool MX = false>
+// TH = pixel rows per tile: 16 (the shape above), or 8 for layers whose 16x16 tiling leaves most of the chip idle (the 128^2 layers of
+// to_plane_cnn: 128 blocks for 512 block slots): 128 couts x 8x16 px per block, 8 waves x (64 couts x 32 px), twice the blocks, same
+// K order per output (bit-identical results).  LDS 2 x 12.3 KB patch + 2 x 16 KB weights = 57 KB.
+template <bool FULL_EPI, bool MX = false, int TH = F_TILE_H>
 __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const ConvPhase& ph, int n, uint4* lds)
 {
-    constexpr int WN = 4, NT = 2;
-    uint4* pbuf = lds;                                                // [2][P_BUF]
-    uint4* wbuf = lds + 2 * P_BUF;                                    // [2][W2_BUF]
+    static_assert(TH == 16 || (TH == 8 && !MX), "tile rows");
+    constexpr int WN = 4, NT = TH / 8;
+    constexpr int PATCH_PIX = (TH + 2) * F_PATCH_W;                  // 324 | 180
+    constexpr int PSEGS = (4 * PATCH_PIX + 63) / 64;                 // 21 | 12 DMA segments of 64 slots
+    constexpr int PBUF = PSEGS * 64;
+    constexpr int KMAX = (PSEGS + 7) / 8;                             // patch DMAs per wave and stage: 3 | 2 (waves >= PSEGS - 8 (KMAX - 1): one less)
+    static_assert(PBUF == (TH == 16 ? P_BUF : 768), "patch buffer");
+    uint4* pbuf = lds;                                                // [2][PBUF]
+    uint4* wbuf = lds + 2 * PBUF;                                     // [2][W2_BUF]
     const int tiles_x = (ph.outW + F_TILE_W - 1) / F_TILE_W;
     int tile = blockIdx.x, cgi = blockIdx.y;
     if (a.order) {
@@ -580,7 +595,7 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
         tile = a.order == 1 ? t * 8 + xcd : xcd * (gridDim.x >> 3) + t;
     }
     const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const int i0 = ty * F_TILE_H, j0 = tx * F_TILE_W;
+    const int i0 = ty * TH, j0 = tx * F_TILE_W;
     const int m0 = cgi * BLOCK_M;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
@@ -604,19 +619,19 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
     const int row0 = wn * 2 * NT;
     int boff[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) boff[nt] = (row0 + nt * 2 + prow + 1) * F_PATCH_W + (pcol + 1) + h * F_PATCH_PIX;
+    for (int nt = 0; nt < NT; ++nt) boff[nt] = (row0 + nt * 2 + prow + 1) * F_PATCH_W + (pcol + 1) + h * PATCH_PIX;
     const int aoff = h * 256 + 64 * wm + li;                          // [ts][chunk = h][hi|lo][128]: + ts*512 + mt*32 (+128 for lo)
 
-    // patch DMA: wave w fills segments w, w+8, w+16 (< 21); slot e = 64*seg + lane -> (plane, chunk, 18x18 pixel)
+    // patch DMA: wave w fills segments w, w+8, w+16 (< PSEGS); slot e = 64*seg + lane -> (plane, chunk, (TH+2)x18 pixel)
     unsigned pf_off[3];
     unsigned pf_valid = 0;
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < KMAX; ++k) {
         const int e = (8 * k + wave_u) * 64 + lane;
         unsigned off = 0;
-        if (e < 4 * F_PATCH_PIX) {
-            const int pl = e / (2 * F_PATCH_PIX), rem = e - pl * (2 * F_PATCH_PIX);
-            const int c = rem / F_PATCH_PIX, pp = rem - c * F_PATCH_PIX;
+        if (e < 4 * PATCH_PIX) {
+            const int pl = e / (2 * PATCH_PIX), rem = e - pl * (2 * PATCH_PIX);
+            const int c = rem / PATCH_PIX, pp = rem - c * PATCH_PIX;
             const int py = pp / F_PATCH_W, px = pp - py * F_PATCH_W;
             const int iy = i0 + py - 1, ix = j0 + px - 1;
             if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
@@ -626,7 +641,7 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
         }
         pf_off[k] = off;
     }
-    const bool three = wave_u < P_SEGS - 16;                          // waves 0..4 issue three patch DMAs, the others two
+    const bool three = wave_u < PSEGS - 8 * (KMAX - 1);               // these waves issue KMAX patch DMAs per stage, the others KMAX - 1
     // MX (register budget: 16 more operand VGPRs than f16x3): saddr-form DMAs -- no per-source 64-bit address pairs -- with the
     // out-of-image slots zero-filled ONCE here (both buffers) and skipped by every stage's DMA (exec mask) instead of reading a zero block
     unsigned long long pmask[3] = {0, 0, 0};
@@ -634,12 +649,12 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
     const unsigned lane16 = (unsigned)lane * 16u;
     if constexpr (MX) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < KMAX; ++k) {
             pmask[k] = __ballot((pf_valid >> k) & 1u);
             pf_boff[k] = pf_off[k] * 16u;
-            if ((k < 2 || three) && !((pf_valid >> k) & 1u)) {
+            if ((k < KMAX - 1 || three) && !((pf_valid >> k) & 1u)) {
                 pbuf[64 * (8 * k + wave_u) + lane] = make_uint4(0, 0, 0, 0);
-                pbuf[P_BUF + 64 * (8 * k + wave_u) + lane] = make_uint4(0, 0, 0, 0);
+                pbuf[PBUF + 64 * (8 * k + wave_u) + lane] = make_uint4(0, 0, 0, 0);
             }
         }
         __syncthreads();                                              // zero fill done before any DMA is in flight
@@ -647,8 +662,8 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
     auto dma_patch = [&](int st, uint4* dst) {
         const uint4* Xs = X + (size_t)(2 * st) * chunk_stride;
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
-            if (k < 2 || three) {
+        for (int k = 0; k < KMAX; ++k)
+            if (k < KMAX - 1 || three) {
                 if constexpr (MX) {
                     // (a fully out-of-image segment still issues one DMA -- of the zero block -- so that the counted vmcnt waits hold)
                     if (pmask[k]) dma64s_masked(Xs, pf_boff[k], pmask[k], dst + 64 * (8 * k + wave_u));
@@ -691,21 +706,22 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
             // would no longer name the right instruction, so that instantiation always drains -- the patch DMA has had a full sub-stage)
             const bool patch_behind = !MX && ((uu == 1 && sp + 1 < nst) || (uu == 6 && sp + 2 < nst));
             if (patch_behind) {
-                if (three) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                if constexpr (KMAX == 3) { if (three) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+                else { if (three) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
             } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             const int par = (uu + (sp >> 1)) & 1;                     // 9 sub-stages per stage pair: the buffer parity alternates between pairs
             const uint4* curW = wbuf + par * W2_BUF;
             dma_weights2(T0 + 2, wbuf + (par ^ 1) * W2_BUF);
-            if (uu == 0 && sp + 1 < nst) dma_patch(sp + 1, pbuf + P_BUF);
+            if (uu == 0 && sp + 1 < nst) dma_patch(sp + 1, pbuf + PBUF);
             if (uu == 5 && sp + 2 < nst) dma_patch(sp + 2, pbuf);
 #pragma unroll
             for (int ts = 0; ts < 2; ++ts) {
                 const int Tl = 2 * uu + ts;                           // 0..17 within the stage pair (compile time)
                 const int sl = Tl / 9, t = Tl - 9 * sl;
                 if (sp + sl < nst) {
-                    const uint4* curP = pbuf + sl * P_BUF;
+                    const uint4* curP = pbuf + sl * PBUF;
                     h8 ah[2], al[2];
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
@@ -726,7 +742,7 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
 #if defined(R3D_ABLATE) && (R3D_ABLATE & 2048)
                         if (!MX) bl = bh;
 #else
-                        if (!MX) { uint4 r1 = curP[boff[nt] + toff + 2 * F_PATCH_PIX]; bl = *reinterpret_cast<h8*>(&r1); }
+                        if (!MX) { uint4 r1 = curP[boff[nt] + toff + 2 * PATCH_PIX]; bl = *reinterpret_cast<h8*>(&r1); }
 #endif
 #pragma unroll
                         for (int mt = 0; mt < 2; ++mt) {
@@ -755,7 +771,7 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
                 int hh = h;
                 asm volatile("" : "+v"(hh));                        // keep the per-sub-stage address arithmetic inside the loop (9 hoisted VGPRs spill)
                 // this lane half's tap: its stage's "lo" plane, pixel slot without the f16 chunk offset h * F_PATCH_PIX
-                const int p8 = 2 * F_PATCH_PIX + sl0 * P_BUF + toffa + hh * ((sl1 - sl0) * P_BUF + toffb - toffa - F_PATCH_PIX);
+                const int p8 = 2 * PATCH_PIX + sl0 * PBUF + toffa + hh * ((sl1 - sl0) * PBUF + toffb - toffa - PATCH_PIX);
                 const uint4* P8 = pbuf + p8;
                 const uint4* W8 = curW + 128 + aoff + hh * 256;                                           // [ts = h][chunk][lo row][cout]: aoff has h * 256
                 i8v a8[2];
@@ -766,7 +782,7 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const uint4 r0 = P8[boff[nt]], r1 = P8[boff[nt] + F_PATCH_PIX];
+                    const uint4 r0 = P8[boff[nt]], r1 = P8[boff[nt] + PATCH_PIX];
                     const i8v b8 = (i8v){(int)r0.x, (int)r0.y, (int)r0.z, (int)r0.w, (int)r1.x, (int)r1.y, (int)r1.z, (int)r1.w};
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
@@ -802,6 +818,14 @@ __global__ __launch_bounds__(128 * WN, OCC) void conv_mfma_f16x3_kernel(Conv2Arg
         __shared__ uint4 lds[F_LDS_UINT4];
         conv2_block<9, true, WN, NT>(a, a.ph[0], blockIdx.z, lds);
     }
+}
+
+// the same conv on 8x16-pixel tiles (conv3x3_dma_block TH = 8), for launches that would fill less than half of the chip's block slots
+static constexpr int F3S_LDS_UINT4 = 2 * 768 + 2 * W2_BUF;           // 57.3 KB
+__global__ __launch_bounds__(512, 4) void conv_mfma_f16x3_rows8_kernel(Conv2Args a)
+{
+    __shared__ uint4 lds[F3S_LDS_UINT4];
+    conv3x3_dma_block<true, false, 8>(a, a.ph[0], blockIdx.z, lds);
 }
 
 // 1x1 conv with the full epilogue (nn.Conv2d(k=1) layers of the torso/background fusion stack)
@@ -1107,6 +1131,7 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
                     }
                     va = va * ma;                                   // |.| < 2^15 by the range fold (r3d_chain_fold): no saturation guard needed
                     vb = vb * mb;
+                    asm("" : "+v"(va), "+v"(vb));                   // as_rounded(): hi and lo below come from these fp32 values, not from their factors
                     const hh2 hia = __builtin_convertvector(va, hh2), hib = __builtin_convertvector(vb, hh2);
                     const hh2 loa = __builtin_convertvector(va - __builtin_convertvector(hia, f2), hh2);
                     const hh2 lob = __builtin_convertvector(vb - __builtin_convertvector(hib, f2), hh2);
@@ -1434,6 +1459,14 @@ static void launch_conv2(Conv2Args& a, int tiles, int N, hipStream_t st, bool mx
 {
 
     dim3 grid(tiles, a.Cout / BLOCK_M, N * a.nphase);
+    static const int rows8 = getenv("R3D_CONV_ROWS8") ? atoi(getenv("R3D_CONV_ROWS8")) : 1;   // A/B switch: 0 = always 16x16 tiles
+    if (rows8 && (rows8 == 1 || (rows8 == 2 && !a.rgb_partial) || (rows8 == 3 && a.rgb_partial)) && !mx && a.nphase == 1 && a.ph[0].ntaps == 9 && (size_t)tiles * grid.y * grid.z <= 256) {
+        // under-filled launch (<= half of the 512 block slots): 8x16-pixel tiles, twice the blocks (bit-identical results)
+        const int t8 = ((a.ph[0].outW + F_TILE_W - 1) / F_TILE_W) * ((a.ph[0].outH + 7) / 8);
+        a.order = (t8 & 7) == 0 ? 2 : 0;
+        hipLaunchKernelGGL(conv_mfma_f16x3_rows8_kernel, dim3(t8, grid.y, grid.z), dim3(512), 0, st, a);
+        return;
+    }
     static const int shape = getenv("R3D_CONV_SHAPE") ? atoi(getenv("R3D_CONV_SHAPE")) : 0;   // tuning switch, default 0
     static const int order = getenv("R3D_CONV_ORDER") ? atoi(getenv("R3D_CONV_ORDER")) : 2;   // tuning switch (0: plain (x, y) order)
     a.order = (tiles & 7) == 0 ? order : 0;

@@ -67,6 +67,7 @@ class WarpSRState:
     def __init__(self, hparams):
         self.hparams = dict(hparams)
         self.slots = None
+        self.split_fold_pending = False     # split_input_spec() folded block0 for a SPLIT input that forward() has not consumed yet
         self.meter_x, self.meter_hid = _BoundMeter(), _BoundMeter()
         self.c_torso256, self.c_bg256, self.c_xbg, self.c_ws3 = _Cached(), _Cached(), _Cached(), _Cached()
 
@@ -74,6 +75,24 @@ class WarpSRState:
         if self.slots is None or self.slots.shape[1] != N or self.slots.device != dev:
             self.slots = torch.zeros(4, N, device=dev, dtype=torch.float32)
         return self.slots[k]
+
+
+def warp_split_input_spec(self, ws, N, dev):
+    """As SuperresolutionHybrid8XDC.split_input_spec, for the fused Warp forward: block0's styles and range fold for the renderer's
+    feature image (|x| <= 1.01) are put in place NOW (the fold also clears the max|x0| slot block0's epilogue measures into), and
+    (folded input multiplier, per-sample stride in floats, consuming block) is returned for r3d_render_forward's split_out.  The
+    caller hands the SPLIT tensor to the next forward() as `x`; None when the precision has no SPLIT operand."""
+    from .superresolution import const_bound
+    S = self._r3d_state
+    b0 = self.block0
+    if b0.precision != "f16x3" or self.input_resolution != 128:
+        return None
+    ws3 = S.c_ws3.get(ws, lambda w: w[:, -1:, :].expand(N, 3, -1).contiguous())
+    b0.prepare(ws3, dev, ws_key=ws)
+    chain_fold([b0.chain_op(-1)], N, [const_bound(1.01, N, dev)], zero=[S.slot(0, N, dev)])
+    S.split_fold_pending = True
+    scale, stride = b0.in_scale()
+    return scale, stride, b0
 
 
 def forward_v2(self, rgb, x, ws, ref_torso_rgb, ref_bg_rgb, weights_img, segmap, kp_s, kp_d, target_torso_mask=None, **block_kwargs):
@@ -107,7 +126,7 @@ def _forward_v2(self, S, rgb, x, ws, ref_torso_rgb, ref_bg_rgb, weights_img, seg
     weights_img = weights_img.detach()
     N, dev = rgb.shape[0], rgb.device
     ws3 = S.c_ws3.get(ws, lambda w: w[:, -1:, :].expand(N, 3, -1).contiguous())                      # :69
-    if x.shape[-1] != self.input_resolution:                                                           # :71-75, cold
+    if getattr(x, "_r3d_fmt", None) != "split" and x.shape[-1] != self.input_resolution:               # :71-75, cold
         sz = (self.input_resolution, self.input_resolution)
         x, rgb = resize_bilinear(x, sz, aa), resize_bilinear(rgb, sz, aa)
     rgb_256 = resize_bilinear(rgb, (256, 256), aa)                                                      # :77
@@ -123,9 +142,15 @@ def _forward_v2(self, S, rgb, x, ws, ref_torso_rgb, ref_bg_rgb, weights_img, seg
 
     # ---- block0: 128^2 head features -> 256^2 (:83); its conv1 epilogue measures max|x0| ------------------------------------------
     prep0 = b0.prepare(ws3, dev, ws_key=ws)
-    x = _keep_tags(x)
-    bx, _ = bound_of(x, S.meter_x, layers=2)
-    chain_fold([b0.chain_op(-1)], N, [bx], zero=[m_x0])
+    if getattr(x, "_r3d_fmt", None) == "split":
+        # the ray kernel wrote block0's first operand itself (split_input_spec below folded for it before the render launch)
+        if getattr(x, "_r3d_for", None) is not b0 or not S.split_fold_pending:
+            raise RuntimeError("SPLIT feature image without a pending split_input_spec() fold of this module")
+        S.split_fold_pending = False
+    else:
+        x = _keep_tags(x)
+        bx, _ = bound_of(x, S.meter_x, layers=2)
+        chain_fold([b0.chain_op(-1)], N, [bx], zero=[m_x0])
     b0.out_format, b0.return_x = "cb8", True
     x0, rgb0 = b0(x, rgb, ws3, _prepared=prep0, _folded=True, _x_absmax=m_x0, **kw)
 
@@ -200,3 +225,6 @@ class SuperresolutionHybrid8XDC_Warp(torch.nn.Module):
         self._r3d_state = WarpSRState(hp)
 
     forward = forward_v2
+
+    def split_input_spec(self, ws, N, dev):
+        return warp_split_input_spec(self, ws, N, dev)

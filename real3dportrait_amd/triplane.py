@@ -233,6 +233,7 @@ def patch_model(model, fuse_warp_sr=True):
                 {k: hp[k] for k in ("weight_fuse", "htbsr_head_weight_fuse_mode", "htbsr_head_threshold", "torso_model_version") if k in hp})
             sr._r3d_reference_forward = sr.forward           # the exact-f32 precision runs the reference forward over the patched sub-modules
             sr.forward = types.MethodType(sr_with_ref.forward_v2, sr)
+            sr.split_input_spec = types.MethodType(sr_with_ref.warp_split_input_spec, sr)
     for owner in (getattr(model, "secc_img2plane_backbone", None), getattr(model, "img2plane_backbone", None)):
         _patch_sequential(owner, "to_plane_cnn", dev)       # per-frame plane producer tail (segformer.py:691-700)
     return model

@@ -1,16 +1,15 @@
-# per-launch durations of the torso frame's kernels (rocprofv3 --kernel-trace of scripts/prof_torso.py), in launch order of one frame
-export R=$PWD; mkdir -p gpurun_out; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/torso_trace -o t -- python $R/scripts/prof_torso.py 6 > $R/gpurun_out/torso_trace.log 2>&1
-tail -1 $R/gpurun_out/torso_trace.log
+#!/bin/bash
+# Kernel trace of the torso frame (BASELINE config 4 surrogate, bench.py build_torso_frame): per-kernel time and launch count per frame.
+cd $GRAFT_REPO_ROOT; export R=$PWD; O=$R/gpurun_out/torso_trace; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- python $R/scripts/torso_frames.py 20 > $O/run.log 2>&1
 python - <<'PY'
 import csv, glob, os
-R = os.environ["R"]
-rows = list(csv.DictReader(open(glob.glob(R + "/gpurun_out/torso_trace/**/t_kernel_trace.csv", recursive=True)[0])))
-idx = [i for i, r in enumerate(rows) if "render_kernel" in r["Kernel_Name"]]
-a, b = idx[-3], idx[-2]
-tot = 0.0
-for r in rows[a:b]:
-    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3; tot += d
-    print("%8.1f us  %-64s grid=%s wg=%s" % (d, r["Kernel_Name"].replace("void r3d::", "").split("(")[0][:64], r["Grid_Size_X"] + "x" + r["Grid_Size_Y"], r["Workgroup_Size_X"]))
-print("sum %.1f us over %d launches" % (tot, b - a))
+O = os.environ["R"] + "/gpurun_out/torso_trace"
+st = glob.glob(O + "/stats/**/p_kernel_stats.csv", recursive=True)
+rows = list(csv.DictReader(open(st[0])))
+out = ["%-90s %6s %10s %10s" % ("kernel", "calls", "total_us", "avg_us")]
+for r in rows:
+    out.append("%-90s %6s %10.1f %10.2f" % (r["Name"][:90], r["Calls"], float(r["TotalDurationNs"]) / 1e3, float(r["AverageNs"]) / 1e3))
+open(O + "/torso_kernel_stats.txt", "w").write("\n".join(out) + "\n")
 PY
+tail -2 $O/run.log; head -45 $O/torso_kernel_stats.txt

@@ -123,10 +123,15 @@ def test_no_hazardous_packed_f32_forms(tmp_path):
     subprocess.check_call([llvm + "/llvm-objdump", "--offloading", so], stdout=subprocess.DEVNULL)      # writes lib.so.<k>.hipv4-...-gfx950
     objs = [str(tmp_path / f) for f in sorted(os.listdir(tmp_path)) if "amdgcn" in f]
     assert len(objs) >= 4, objs
-    n_pk = n_bad = 0
+    n_pk = n_bad = n_mix = 0
     for o in objs:
         dis = subprocess.run([llvm + "/llvm-objdump", "-d", "--no-show-raw-insn", o], capture_output=True, text=True, check=True).stdout
         for line in dis.splitlines():
+            # fp16(a * b) fused into one rounding (v_fma_mixlo/hi_f16 a, b, 0): hipcc derives `hi` of an fp16 hi/lo split this way at one
+            # use and by fl32 + v_cvt at another, so hi + lo misses the value by an ulp of hi where the roundings differ
+            # (csrc/r3d_common.h as_rounded()); no split in this library may compile to it
+            if re.search(r"v_fma_mix(lo|hi)_f16 v\d+, [^,]+, [^,]+, 0\b", line):
+                n_mix += 1
             if "v_pk_" not in line:
                 continue
             p = pk_opsel_fix.parse(re.sub(r"\s*//.*", "", line))
@@ -135,6 +140,7 @@ def test_no_hazardous_packed_f32_forms(tmp_path):
                 n_bad += int(pk_opsel_fix.hazardous(p))
     assert n_pk > 1000, "disassembly found only %d packed-f32 instructions: is the extraction broken?" % n_pk
     assert n_bad == 0, "%d packed-f32 instructions with a crossed src1 / src2 op_sel in libr3d_hip.so" % n_bad
+    assert n_mix == 0, "%d fp16 roundings fused into their product (v_fma_mix*_f16 a, b, 0): a hi/lo split is missing as_rounded()" % n_mix
 
 
 def test_pk_opsel_rewriter_rules():

@@ -83,6 +83,26 @@ def test_torso_frames_on_three_streams_are_bit_identical():
     assert float(ref[0].std()) > 1e-3
 
 
+def test_torso_frame_fused_input_equals_unfused_sequence():
+    """Camera-mode rays + the ray kernel's SPLIT copy as block0's operand (warp_split_input_spec) vs ray arrays + fp32 feature image +
+    conversion launch: the same uint8-able frame, bit for bit."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    dev = torch.device("cuda", 0)
+    G, clip, dec, scene = bench.build_scene(torch, dev, n_frames=8)
+    fused = bench.build_torso_frame(torch, dev, G)[0]
+    plain = bench.build_torso_frame(torch, dev, G, fused_input=False)[0]
+    for t in range(4):
+        a = fused(t).clone()
+        b = plain(t)
+        assert torch.equal(a, b), (t, float((a - b).abs().max()))
+        a2 = fused(t)
+        assert torch.equal(a2, b)
+
+
 def test_warp_sr_forward_v2_batch_of_two_equals_two_singles():
     """N = 2 through the fused forward (the per-sample bounds of a tagged activation sit one scales record apart: consumers need them
     dense): a batch whose two samples differ in magnitude by 2^6 must equal the two samples run one by one."""
