@@ -272,7 +272,7 @@ def test_sr_block_range_sweep(torch_cuda, what, k, up):
     ex = (xo.cpu().double() - rx).abs().max().item() / max(rx.abs().max().item(), 1e-300)
     ei = (io.cpu().double() - ri).abs().max().item() / max(ri.abs().max().item(), 1e-300)
     assert torch.isfinite(xo).all() and torch.isfinite(io).all()
-    assert ex <= 2e-5 and ei <= 2e-5, (what, k, up, ex, ei)
+    assert ex <= 4e-6 and ei <= 4e-6, (what, k, up, ex, ei)      # measured worst of the whole sweep: 1.3e-6 (profiles/r03/sr_sweep_errors.txt)
 
 
 def test_bounds_are_upper_bounds_and_stored_operands_fit_fp16(torch_cuda):
