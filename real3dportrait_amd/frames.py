@@ -164,7 +164,8 @@ class ClipRenderer:
         R = G.neural_rendering_resolution
         sr = G.superresolution
         # the ray kernel writes the SR's first operand itself (SPLIT copy of the feature image) when the SR takes 128^2 inputs as they come
-        spec = sr.split_input_spec(self.ws, 1, cam.device) if (hasattr(sr, "split_input_spec") and R == getattr(sr, "input_resolution", -1)) else None
+        from .superresolution import SuperresolutionHybrid8XDC
+        spec = sr.split_input_spec(self.ws, 1, cam.device) if (isinstance(sr, SuperresolutionHybrid8XDC) and R == sr.input_resolution) else None
         keep, ren.need_depth = ren.need_depth, False          # only the frames leave this driver: no depth image, no clamp launch
         try:
             feat, depth, wsum, valid = ren.forward_camera(self.planes_for(t), G.decoder, cam[:, :16].view(-1, 4, 4), cam[:, 16:25].view(-1, 3, 3),

@@ -148,6 +148,7 @@ def _forward_v2(self, S, rgb, x, ws, ref_torso_rgb, ref_bg_rgb, weights_img, seg
             raise RuntimeError("SPLIT feature image without a pending split_input_spec() fold of this module")
         S.split_fold_pending = False
     else:
+        S.split_fold_pending = False
         x = _keep_tags(x)
         bx, _ = bound_of(x, S.meter_x, layers=2)
         chain_fold([b0.chain_op(-1)], N, [bx], zero=[m_x0])

@@ -94,7 +94,7 @@ class TriPlaneGenerator(nn.Module):
             # both operators are the HIP ones: the rays are generated inside the render launches (same pixels, triplane.py:96-99 + :113)
             sr = self.superresolution
             spec = None
-            if (sr_ws is not None and hasattr(sr, "split_input_spec") and R == getattr(sr, "input_resolution", -1)
+            if (sr_ws is not None and isinstance(sr, SuperresolutionHybrid8XDC) and R == sr.input_resolution
                     and not self.hparams.get("mask_invalid_rays", False)):          # (the mask edits the fp32 image afterwards)
                 spec = sr.split_input_spec(sr_ws, c2w.shape[0], c2w.device)
             feat, depth, wsum, valid = self.renderer.forward_camera(planes, self.decoder, c2w, K, R, self.rendering_kwargs, _split_for=spec)
@@ -129,12 +129,12 @@ class TriPlaneGenerator(nn.Module):
         secc_img2plane.py:132)."""
         planes = self._planes(ws, update_emas, cache_backbone, use_cached_backbone, synthesis_kwargs)
         sr_ws = self._ws_for_sr(ws)
-        im = self._ray_images(planes, camera, sr_ws=None if synthesis_kwargs else sr_ws)
+        sr_kwargs = {k: v for k, v in synthesis_kwargs.items() if k != "noise_mode"}
+        im = self._ray_images(planes, camera, sr_ws=None if sr_kwargs else sr_ws)
         feature = im["feature"]
         # |feature| <= 1.002 by construction (sigmoid * 1.002 - 0.001 composited with weights summing to <= 1, then * 2 - 1):
         # the SR's fp16 range fold uses this bound instead of measuring it
         feature._r3d_bound, feature._r3d_depth = const_bound(1.01, feature.shape[0], feature.device), 0
-        sr_kwargs = {k: v for k, v in synthesis_kwargs.items() if k != "noise_mode"}
         x = im["feature_split"] if im.get("feature_split") is not None else feature
         sr_image = self.superresolution(feature[:, :3], x, sr_ws,
                                         noise_mode=self.rendering_kwargs["superresolution_noise_mode"], **sr_kwargs)

@@ -673,3 +673,34 @@ def test_ray_kernel_split_output_equals_conversion_launch(torch_cuda):
         assert torch.equal(fused, plain)
         u8 = ((plain[0].clamp(-1, 1).permute(1, 2, 0) + 1) / 2 * 255).int().to(torch.uint8)
         assert torch.equal(fused_u8, u8)
+
+
+def test_synthesis_batch_of_two_equals_two_singles(torch_cuda):
+    """TriPlaneGenerator.synthesis with N = 2 (own planes, camera and ws per sample; the ray kernel writes the SR's SPLIT operand with
+    per-sample folded styles) equals the two samples rendered one by one, bit for bit."""
+    torch = torch_cuda
+    from real3dportrait_amd import TriPlaneGenerator, synth
+    G = TriPlaneGenerator().cuda().eval()
+    G.hparams["ones_ws_for_sr"] = False
+    dec = synth.synth_decoder(5, sigma_bias=4.0)
+    with torch.no_grad():
+        G.decoder.net[0].weight.copy_(T(torch, dec[0])); G.decoder.net[0].bias.copy_(T(torch, dec[1]))
+        G.decoder.net[2].weight.copy_(T(torch, dec[2])); G.decoder.net[2].bias.copy_(T(torch, dec[3]))
+    params = synth.synth_sr_params(5)
+    load_block(torch, G.superresolution.block0, params[0]); load_block(torch, G.superresolution.block1, params[1])
+    planes = T(torch, synth.synth_planes(6, N=2)).view(2, 96, 256, 256)
+    cams = T(torch, synth.camera_sweep(2, -0.25, 0.3))
+    ws = torch.ones(2, 14, 512, device="cuda") + 0.15 * T(torch, synth.hash_unitvar(10, (2, 14, 512), stream=4))
+    M, Nc, Nf = 128 * 128, 48, 48
+    noise_c = T(torch, synth.synth_noise(8, (2, M, Nc, 1), stream=7)); u_f = T(torch, synth.synth_noise(8, (2 * M, Nf), stream=8))
+    G.renderer.noise_override = (noise_c, u_f)
+    G._last_planes = planes
+    both = G.synthesis(ws, cams, use_cached_backbone=True, noise_mode="none")
+    img2, raw2, dep2 = both["image"].clone(), both["image_raw"].clone(), both["image_depth"].clone()
+    for n in range(2):
+        G._last_planes = planes[n:n + 1].contiguous()
+        G.renderer.noise_override = (noise_c[n:n + 1].contiguous(), u_f[n * M:(n + 1) * M].contiguous())
+        one = G.synthesis(ws[n:n + 1].contiguous(), cams[n:n + 1].contiguous(), use_cached_backbone=True, noise_mode="none")
+        assert torch.equal(one["image_raw"], raw2[n:n + 1]), n
+        assert torch.equal(one["image"], img2[n:n + 1]), (n, float((one["image"] - img2[n:n + 1]).abs().max()))
+    assert float(img2[1].std()) > 1e-3 and torch.isfinite(img2).all() and not torch.equal(img2[0], img2[1])
