@@ -200,7 +200,9 @@ int r3d_sr_block_forward(const void* prepacked, const void* styles, int N, int C
  * after at most 3 chained layers.  r3d_*_bound_offset: float offset, within one sample's buffer, of the op's output bound.
  * Measuring without an extra pass: r3d_sr_block_forward / r3d_conv_forward take `y_absmax` (device float[N] or NULL): the conv
  * epilogue then atomically maxes |y| into it; the slot must be zero beforehand -- pass it in `zero_slots` of the r3d_chain_fold
- * launch that precedes the producer (up to R3D_CHAIN_MAX_ZERO slots of N floats each are cleared by the fold kernel). */
+ * launch that precedes the producer (up to R3D_CHAIN_MAX_ZERO slots of N floats each are cleared by the fold kernel).  The kernel
+ * reads its external bounds BEFORE it clears: a slot may be an ext bound and a zero slot of the same fold (consume the measured
+ * maximum of this frame, re-arm the slot for the next frame). */
 #define R3D_CHAIN_MAX_ZERO 4
 #define R3D_CHAIN_MAX_OPS 12
 #define R3D_CHAIN_MAX_EXT 4

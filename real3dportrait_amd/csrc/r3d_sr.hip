@@ -153,7 +153,7 @@ struct ChainArgs {
     r3d_chain_op ops[R3D_CHAIN_MAX_OPS];
     const float* ext[R3D_CHAIN_MAX_EXT];
     float* zero[R3D_CHAIN_MAX_ZERO];
-    int nops, N, nzero;
+    int nops, N, nzero, next;
 };
 
 __device__ __forceinline__ float block_max(float v, float* red)
@@ -170,7 +170,12 @@ __global__ __launch_bounds__(256) void chain_fold_kernel(ChainArgs a)
 {
     __shared__ float red[4];
     __shared__ float bounds[R3D_CHAIN_MAX_OPS];
+    __shared__ float extv[R3D_CHAIN_MAX_EXT];
     const int n = blockIdx.x, tid = threadIdx.x;
+    // external bounds are read BEFORE the zero slots are cleared: a slot may be both (a fold that consumes a measured maximum and
+    // re-arms the slot for the next frame's measurement, e.g. the f16mx tail fold)
+    if (tid < a.next) extv[tid] = fabsf(a.ext[tid][n]);
+    __syncthreads();
     if (tid < a.nzero) a.zero[tid][n] = 0.f;                  // absmax slots of the tensors the following kernels measure
     for (int k = 0; k < a.nops; ++k) {
         const r3d_chain_op& op = a.ops[k];
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(256) void chain_fold_kernel(ChainArgs a)
         for (int j = 0; j < 2; ++j) {
             const int s = srcs[j];
             if (s >= 0) B = fmaxf(B, bounds[s]);
-            else if (s >= -R3D_CHAIN_MAX_EXT) B = fmaxf(B, fabsf(a.ext[-1 - s][n]));
+            else if (s >= -R3D_CHAIN_MAX_EXT) B = fmaxf(B, extv[-1 - s]);
         }
         float Bout;
         if (op.kind == R3D_CHAIN_SR_BLOCK || op.kind == R3D_CHAIN_SR_BLOCK_TAIL) {
@@ -754,7 +759,7 @@ extern "C" int r3d_chain_fold(const r3d_chain_op* ops, int nops, int N, const fl
         return R3D_ERR_INVALID_ARG;
     }
     ChainArgs a = {};
-    a.nops = nops; a.N = N; a.nzero = n_zero;
+    a.nops = nops; a.N = N; a.nzero = n_zero; a.next = n_ext;
     for (int j = 0; j < n_zero; ++j) {
         if (!zero_slots[j]) { set_error("chain_fold: zero slot %d is NULL", j); return R3D_ERR_INVALID_ARG; }
         a.zero[j] = zero_slots[j];

@@ -191,7 +191,7 @@ class ClipRenderer:
         if out is None:
             out = torch.empty(1, 512, 512, 3, dtype=torch.uint8, device=fimg.device)
         x = fimg._r3d_split if fimg._r3d_split is not None else fimg
-        if sr.block0.precision == "f16x3":
+        if sr.block0.precision in ("f16x3", "f16mx"):
             sr(fimg[:, :3], x, self.ws, noise_mode="none", _u8_out=out, _need_img=False)
         else:
             img = sr(fimg[:, :3], x, self.ws, noise_mode="none").contiguous()

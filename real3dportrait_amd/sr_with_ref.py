@@ -85,7 +85,7 @@ def warp_split_input_spec(self, ws, N, dev):
     from .superresolution import const_bound
     S = self._r3d_state
     b0 = self.block0
-    if b0.precision != "f16x3" or self.input_resolution != 128:
+    if b0.precision not in ("f16x3", "f16mx") or self.input_resolution != 128:
         return None
     ws3 = S.c_ws3.get(ws, lambda w: w[:, -1:, :].expand(N, 3, -1).contiguous())
     b0.prepare(ws3, dev, ws_key=ws)

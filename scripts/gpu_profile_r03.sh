@@ -7,7 +7,10 @@ python $R/bench.py --steps 40 --warmup 5 > $O/bench_n1.json 2> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o p -- python $R/bench.py --steps 10 --warmup 2 --streams 1 --no-cpu-baseline --no-extras > $O/stats.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --output-format csv -d $O/pmc_$c -o p -- python $R/bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline --no-extras > $O/pmc_$c.log 2>&1
+  # the fp32-class precision (alt_f16x3 of the bench line): same passes, its own directory (pmcx_*: not part of the table below)
+  R3D_SR_PRECISION=f16x3 rocprofv3 --pmc $c --output-format csv -d $O/pmcx_$c -o p -- python $R/bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline --no-extras > $O/pmcx_$c.log 2>&1
 done
+R3D_SR_PRECISION=f16x3 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_f16x3 -o p -- python $R/bench.py --steps 10 --warmup 2 --streams 1 --no-cpu-baseline --no-extras > $O/stats_f16x3.log 2>&1
 i=0
 for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_SALU" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE TCP_PENDING_STALL_CYCLES_sum TA_BUSY_avr"; do
   i=$((i+1))
@@ -18,6 +21,8 @@ import csv, glob, os, collections, json, shutil
 O = os.environ["R"] + "/gpurun_out/profile_r03"
 st = glob.glob(O + "/stats/**/p_kernel_stats.csv", recursive=True)
 if st: shutil.copy(st[0], O + "/kernel_stats_streams1.csv")
+st = glob.glob(O + "/stats_f16x3/**/p_kernel_stats.csv", recursive=True)
+if st: shutil.copy(st[0], O + "/kernel_stats_streams1_f16x3.csv")
 def collect(pattern):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(O + "/" + pattern + "/**/p_counter_collection.csv", recursive=True):
@@ -52,9 +57,17 @@ for k in sorted(cn):
     if v.get("TCC_HIT_sum", 0) + v.get("TCC_MISS_sum", 0):
         lines.append("    -> L2 hit rate TCC_HIT / (HIT + MISS)                 %.4f" % (v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])))
 open(O + "/pmc_summary.txt", "w").write("\n".join(lines) + "\n")
-conv = [v for k, v in per.items() if "conv_mfma_f16x3_kernel" in k]
-if conv:
-    json.dump({"conv_bytes_per_launch_f16x3": int(conv[0]), "source": "profiles/r03/pmc_summary.txt"}, open(O + "/traffic_f16x3.json", "w"), indent=1)
+tj = {"source": "profiles/r03/pmc_summary.txt (default precision) and the pmcx_* passes of scripts/gpu_profile_r03.sh (R3D_SR_PRECISION=f16x3)"}
+for k, v in per.items():
+    if "conv_mfma_f16x3_kernel" in k: tj["conv_bytes_per_launch_" + ("f16mx" if "true>" in k else "f16x3")] = int(v)
+trx = collect("pmcx_[FW]*")
+for k, v in trx.items():
+    if "conv_mfma_f16x3_kernel" in k and "true>" not in k:
+        f = sum(v.get("FETCH_SIZE", [0])) / max(1, len(v.get("FETCH_SIZE", [0]))); w = sum(v.get("WRITE_SIZE", [0])) / max(1, len(v.get("WRITE_SIZE", [0])))
+        tj["conv_bytes_per_launch_f16x3"] = int((2 * f + w) * 1024)
+json.dump(tj, open(O + "/traffic.json", "w"), indent=1)
+print(tj)
 print(open(O + "/pmc_summary.txt").read()[:6000])
 PY
 tail -c 1500 $O/bench_n1.json; echo; head -14 $O/kernel_stats_streams1.csv | cut -c1-160
+bash $R/scripts/gpu_torso_trace.sh > $O/torso_trace.log 2>&1; cp $R/gpurun_out/torso_trace/torso_kernel_stats.txt $O/ 2>/dev/null; tail -3 $O/torso_trace.log

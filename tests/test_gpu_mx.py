@@ -1,5 +1,6 @@
-"""GPU parity (`-m gpu`) of the opt-in R3D_SR_F16MX precision: f16x3 with the correction products of each block's 3x3 conv on the
-block-scaled fp8 MFMA.  Own tolerance tier: the correction is accurate to fp8 rounding (~2^-16 of each product), so
+"""GPU parity (`-m gpu`) of the 'f16mx' SR precision (the default since the end of round 3): f16x3 with the correction products of each
+block's 3x3 conv on the block-scaled fp8 MFMA.  Own, stated tolerance tier: the correction is accurate to fp8 rounding (~2^-16 of each
+product), so
 
     SR outputs   <= 5e-5 * max(1, max|ref|)        (f16x3 / f32 tier: 2e-4 with ~4e-6 measured; TF32 would be ~2e-4 measured)
     final image  <= 1e-3 abs after the clamp       (unchanged)

@@ -264,6 +264,7 @@ def test_sr_block_range_sweep(torch_cuda, what, k, up):
     blk = (SynthesisBlock if up else SynthesisBlockNoUp)(Cin, Cout, w_dim=512, resolution=2 * H if up else H, img_channels=3,
                                                          is_last=False, conv_clamp=None).cuda()
     load_block(torch, blk, p)
+    blk.precision = "f16x3"           # this test states the fp32-class tier; the default 'f16mx' has its own sweep (tests/test_gpu_mx.py)
     x = synth.hash_unitvar(72, (N, Cin, H, W), stream=1) * (sc if what == "input" else np.float32(1.0))
     img = synth.hash_unitvar(72, (N, 3, H, W), stream=2) * np.float32(0.5)
     ws = np.ones((N, 3, 512), np.float32) + synth.hash_unitvar(72, (N, 3, 512), stream=3) * np.float32(0.2)
