@@ -160,11 +160,12 @@ size_t r3d_run_model_workspace_bytes(void);
  *            R3D_SR_F16X3 fp32-accurate on the f16 matrix pipe: every operand is split x = hi + lo (two fp16
  *                         terms, 2^-24 relative) and hi*hi + hi*lo + lo*hi is accumulated in fp32 by
  *                         v_mfma_f32_32x32x16_f16 (3 MFMAs at 16x the f32 rate; ~1e-7 relative per dot product).
- *            R3D_SR_F16MX (opt-in; up = 1 blocks): as F16X3, but in the block's plain 3x3 conv (conv1, 80 % of the block's FLOPs) the two
+ *            R3D_SR_F16MX (what the Python operators pass by default since round 3; up = 1 blocks): as F16X3, but in the block's plain 3x3 conv (conv1, 80 % of the block's FLOPs) the two
  *                         2^-11-sized correction products hi*lo + lo*hi of two taps x 16 channels are ONE block-scaled fp8 MFMA
  *                         (v_mfma_scale_f32_32x32x64_f8f6f4, OCP e4m3, 2x the f16 rate) instead of four f16 MFMAs: 1.5x fewer matrix
  *                         cycles.  The correction is then accurate to fp8 rounding, i.e. ~2^-16 of each product (between fp32's
- *                         2^-24 and TF32's 2^-11); parity tier: <= 5e-5 * max|ref| per block (tests/test_gpu_mx.py).  Needs the
+ *                         2^-24 and TF32's 2^-11); parity tier: <= 5e-5 * max|ref| per block on the reference goldens, <= 1e-4 over
+ *                         the 2^-20..2^14 operand sweeps vs fp64 (measured 3.3e-5) (tests/test_gpu_mx.py).  Needs the
  *                         block's conv1 operand within one layer of a measured bound (fold the block with R3D_CHAIN_SR_BLOCK_TAIL
  *                         from a measured max|x| when its input bound is a propagated one).
  *            The prepacked buffer is precision-specific (same size). */
