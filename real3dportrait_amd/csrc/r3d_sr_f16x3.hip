@@ -61,6 +61,15 @@ __device__ __forceinline__ void split1_folded(float v, _Float16& hi, _Float16& l
 // from a measurement), which is what the block's range fold provides (see SuperresolutionHybrid8XDC.forward).
 // In memory the fp8 records take the place of the fp16 lo plane with the SAME addressing: "lo" chunk 2G holds xh8 (wl8) of the 16
 // channels 16G..16G+15, chunk 2G+1 holds xl8 (wh8) -- so every DMA of the f16x3 kernels is unchanged.
+#ifndef R3D_MX_A_PER_TILE
+#define R3D_MX_A_PER_TILE 0
+#endif
+#ifndef R3D_MX_FREE_SCHED
+#define R3D_MX_FREE_SCHED 0   // experiment switch: 1 = no scheduling fences around the fp8 part of a sub-stage
+#endif
+#ifndef R3D_MX_DRAIN
+#define R3D_MX_DRAIN 0        // experiment switch: 1 = the MX conv waits for ALL its DMAs at every sub-stage (the spilling build's behaviour)
+#endif
 static constexpr int kMxScaleA = 127, kMxScaleB = 126;     // E8M0 bytes: 2^0 * 2^-1
 static constexpr float kMxXh = 0.0078125f /* 2^-7 */, kMxXl = 16.0f /* 2^4 */, kMxWl = 256.0f /* 2^8 */, kMxWh = 0.125f /* 2^-3 */;
 
@@ -683,10 +692,10 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
                 const int st = T / 9, t = T - 9 * st;
                 const int hc = (wave_u >> 2) & 1, hl = (wave_u >> 1) & 1;
                 if constexpr (MX)
-                    dma64s(a.wp + m0 + (wave_u & 1) * 64 + (((size_t)ph.widx[t] * nchunks + (2 * st + hc)) * 2 + hl) * a.Cout, lane16,
+                    dma64s(a.wp + m0 + (wave_u & 1) * 64 + (((size_t)t * nchunks + (2 * st + hc)) * 2 + hl) * a.Cout, lane16,
                            dst + ts * 512 + wave_u * 64);
                 else
-                    dma64(WP + (((size_t)ph.widx[t] * nchunks + (2 * st + hc)) * 2 + hl) * a.Cout, dst + ts * 512 + wave_u * 64);
+                    dma64(WP + (((size_t)t * nchunks + (2 * st + hc)) * 2 + hl) * a.Cout, dst + ts * 512 + wave_u * 64);
             } else if (MX && ts == 1 && T0 < 9 * nst) {
                 dma64(g_zero16, dst + ts * 512 + wave_u * 64);       // the fp8 pair-MFMA reads both taps: a missing second tap contributes 0
             }
@@ -701,10 +710,11 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
         for (int uu = 0; uu < 9; ++uu) {
             const int T0 = 9 * sp + 2 * uu;                           // first linear tap of this sub-stage
             if (T0 >= 9 * nst) break;
-            // a patch DMA was issued AFTER the weights this sub-stage needs (at the top of uu = 0 / 5): leave it in flight
-            // (MX: the register allocator spills a few loop invariants to scratch, and scratch traffic shares vmcnt: the counted wait
-            // would no longer name the right instruction, so that instantiation always drains -- the patch DMA has had a full sub-stage)
-            const bool patch_behind = !MX && ((uu == 1 && sp + 1 < nst) || (uu == 6 && sp + 2 < nst));
+            // a patch DMA was issued AFTER the weights this sub-stage needs (at the top of uu = 0 / 5): leave it in flight.
+            // (Counted waits need a kernel without scratch traffic -- it shares vmcnt.  Until the end of round 3 the MX instantiation
+            // spilled: the tap offsets came from the ConvPhase argument, so hipcc kept 18 per-tap LDS addresses in VGPRs; as compile-time
+            // constants they are ds_read immediates: 128 + 23 spilled -> 119 VGPRs, 125 -> 117 for f16x3, and R3D_MX_DRAIN=1 is the old behaviour.)
+            const bool patch_behind = !(MX && R3D_MX_DRAIN) && ((uu == 1 && sp + 1 < nst) || (uu == 6 && sp + 2 < nst));
             if (patch_behind) {
                 if constexpr (KMAX == 3) { if (three) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
                 else { if (three) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
@@ -718,7 +728,7 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
             if (uu == 5 && sp + 2 < nst) dma_patch(sp + 2, pbuf);
 #pragma unroll
             for (int ts = 0; ts < 2; ++ts) {
-                const int Tl = 2 * uu + ts;                           // 0..17 within the stage pair (compile time)
+                const int Tl = 2 * uu + ts;                           // 0..17 within the stage pair (compile time after unrolling)
                 const int sl = Tl / 9, t = Tl - 9 * sl;
                 if (sp + sl < nst) {
                     const uint4* curP = pbuf + sl * PBUF;
@@ -733,7 +743,7 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
                         if (!MX) { uint4 q1 = curW[ts * 512 + aoff + mt * 32 + 128]; al[mt] = *reinterpret_cast<h8*>(&q1); }
 #endif
                     }
-                    const int toff = ph.dy[t] * F_PATCH_W + ph.dx[t];
+                    const int toff = (t / 3 - 1) * F_PATCH_W + (t % 3 - 1);       // the plain 3x3 taps (sr_fill_conv3x3_phase): compile-time LDS offsets
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         uint4 r0 = curP[boff[nt] + toff];
@@ -766,14 +776,32 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
                 // One B record and one A record live at a time (8 + 8 VGPRs): the kernel has 64 registers besides its accumulators.
                 const int Tl0 = 2 * uu, Tl1 = 2 * uu + 1;
                 const int sl0 = Tl0 / 9, t0 = Tl0 - 9 * sl0, sl1 = Tl1 / 9, t1 = Tl1 - 9 * sl1;
-                const int toffa = ph.dy[t0] * F_PATCH_W + ph.dx[t0], toffb = ph.dy[t1] * F_PATCH_W + ph.dx[t1];
+                const int toffa = (t0 / 3 - 1) * F_PATCH_W + (t0 % 3 - 1), toffb = (t1 / 3 - 1) * F_PATCH_W + (t1 % 3 - 1);
+#if !R3D_MX_FREE_SCHED
                 __builtin_amdgcn_sched_barrier(0);                  // fp8 operand loads stay behind this sub-stage's f16 MFMAs (register budget)
+#endif
                 int hh = h;
+#if !R3D_MX_FREE_SCHED
                 asm volatile("" : "+v"(hh));                        // keep the per-sub-stage address arithmetic inside the loop (9 hoisted VGPRs spill)
+#endif
                 // this lane half's tap: its stage's "lo" plane, pixel slot without the f16 chunk offset h * F_PATCH_PIX
                 const int p8 = 2 * PATCH_PIX + sl0 * PBUF + toffa + hh * ((sl1 - sl0) * PBUF + toffb - toffa - PATCH_PIX);
                 const uint4* P8 = pbuf + p8;
                 const uint4* W8 = curW + 128 + aoff + hh * 256;                                           // [ts = h][chunk][lo row][cout]: aoff has h * 256
+#if R3D_MX_A_PER_TILE
+                // register diet (8 VGPRs): ONE A record live at a time, re-read for each pixel tile (+4 ds_read_b128 per sub-stage)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const uint4 r0 = P8[boff[nt]], r1 = P8[boff[nt] + PATCH_PIX];
+                    const i8v b8 = (i8v){(int)r0.x, (int)r0.y, (int)r0.z, (int)r0.w, (int)r1.x, (int)r1.y, (int)r1.z, (int)r1.w};
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const uint4 q0 = W8[mt * 32], q1 = W8[mt * 32 + 256];
+                        const i8v a8 = (i8v){(int)q0.x, (int)q0.y, (int)q0.z, (int)q0.w, (int)q1.x, (int)q1.y, (int)q1.z, (int)q1.w};
+                        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[mt][nt], 0, 0, 0, kMxScaleA, 0, kMxScaleB);
+                    }
+                }
+#else
                 i8v a8[2];
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
@@ -793,7 +821,10 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
 #endif
                     }
                 }
+#endif
+#if !R3D_MX_FREE_SCHED
                 __builtin_amdgcn_sched_barrier(0);
+#endif
             }
         }
     }
