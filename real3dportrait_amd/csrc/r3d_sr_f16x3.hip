@@ -64,6 +64,9 @@ __device__ __forceinline__ void split1_folded(float v, _Float16& hi, _Float16& l
 #ifndef R3D_MX_A_PER_TILE
 #define R3D_MX_A_PER_TILE 0
 #endif
+#ifndef R3D_TAPS_CT
+#define R3D_TAPS_CT 3            // experiment switch (bisect): bit 0 = compile-time tap offsets in the f16 part, bit 1 = in the fp8 part
+#endif
 #ifndef R3D_MX_FREE_SCHED
 #define R3D_MX_FREE_SCHED 0   // experiment switch: 1 = no scheduling fences around the fp8 part of a sub-stage
 #endif
@@ -719,6 +722,12 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
                 if constexpr (KMAX == 3) { if (three) asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
                 else { if (three) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
             } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // ... and every LDS read this wave has issued is complete.  Not implied by anything: hipcc may (and, for the fp8 part of the MX
+            // instantiation, did) sink the MFMAs that consume the last operand reads of a sub-stage below this barrier, and its lgkmcnt wait
+            // with them -- the wave then passes the barrier with reads of weight buffer `par` in flight, and the DMAs issued right after
+            // the barrier (by any wave) refill that buffer.  L2-warm weights land in 250-400 cycles; next to a ray-kernel block that keeps the
+            // CU's LDS queue busy a read can take longer: 55 of 1 920 pipelined frames were off by one count in a few bytes.
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             const int par = (uu + (sp >> 1)) & 1;                     // 9 sub-stages per stage pair: the buffer parity alternates between pairs
@@ -743,7 +752,11 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
                         if (!MX) { uint4 q1 = curW[ts * 512 + aoff + mt * 32 + 128]; al[mt] = *reinterpret_cast<h8*>(&q1); }
 #endif
                     }
+#if R3D_TAPS_CT & 1
                     const int toff = (t / 3 - 1) * F_PATCH_W + (t % 3 - 1);       // the plain 3x3 taps (sr_fill_conv3x3_phase): compile-time LDS offsets
+#else
+                    const int toff = ph.dy[t] * F_PATCH_W + ph.dx[t];
+#endif
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
                         uint4 r0 = curP[boff[nt] + toff];
@@ -776,7 +789,11 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
                 // One B record and one A record live at a time (8 + 8 VGPRs): the kernel has 64 registers besides its accumulators.
                 const int Tl0 = 2 * uu, Tl1 = 2 * uu + 1;
                 const int sl0 = Tl0 / 9, t0 = Tl0 - 9 * sl0, sl1 = Tl1 / 9, t1 = Tl1 - 9 * sl1;
+#if R3D_TAPS_CT & 2
                 const int toffa = (t0 / 3 - 1) * F_PATCH_W + (t0 % 3 - 1), toffb = (t1 / 3 - 1) * F_PATCH_W + (t1 % 3 - 1);
+#else
+                const int toffa = ph.dy[t0] * F_PATCH_W + ph.dx[t0], toffb = ph.dy[t1] * F_PATCH_W + ph.dx[t1];
+#endif
 #if !R3D_MX_FREE_SCHED
                 __builtin_amdgcn_sched_barrier(0);                  // fp8 operand loads stay behind this sub-stage's f16 MFMAs (register budget)
 #endif
@@ -1021,7 +1038,7 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
 #if defined(R3D_ABLATE) && (R3D_ABLATE & 512)
         const unsigned long long st_a = clock64();
 #endif
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this stage's DMAs (issued one stage ago) have landed
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // this stage's DMAs (issued one stage ago) have landed; this wave's LDS reads too (see conv3x3_dma_block)
         __builtin_amdgcn_s_barrier();                               // ... everybody's; and the other buffer's readers are done
         asm volatile("" ::: "memory");
 #if defined(R3D_ABLATE) && (R3D_ABLATE & 512)
