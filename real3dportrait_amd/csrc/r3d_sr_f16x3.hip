@@ -61,9 +61,6 @@ __device__ __forceinline__ void split1_folded(float v, _Float16& hi, _Float16& l
 // from a measurement), which is what the block's range fold provides (see SuperresolutionHybrid8XDC.forward).
 // In memory the fp8 records take the place of the fp16 lo plane with the SAME addressing: "lo" chunk 2G holds xh8 (wl8) of the 16
 // channels 16G..16G+15, chunk 2G+1 holds xl8 (wh8) -- so every DMA of the f16x3 kernels is unchanged.
-#ifndef R3D_MX_A_PER_TILE
-#define R3D_MX_A_PER_TILE 0
-#endif
 #ifndef R3D_TAPS_CT
 #define R3D_TAPS_CT 3            // experiment switch (bisect): bit 0 = compile-time tap offsets in the f16 part, bit 1 = in the fp8 part
 #endif
@@ -805,20 +802,6 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
                 const int p8 = 2 * PATCH_PIX + sl0 * PBUF + toffa + hh * ((sl1 - sl0) * PBUF + toffb - toffa - PATCH_PIX);
                 const uint4* P8 = pbuf + p8;
                 const uint4* W8 = curW + 128 + aoff + hh * 256;                                           // [ts = h][chunk][lo row][cout]: aoff has h * 256
-#if R3D_MX_A_PER_TILE
-                // register diet (8 VGPRs): ONE A record live at a time, re-read for each pixel tile (+4 ds_read_b128 per sub-stage)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const uint4 r0 = P8[boff[nt]], r1 = P8[boff[nt] + PATCH_PIX];
-                    const i8v b8 = (i8v){(int)r0.x, (int)r0.y, (int)r0.z, (int)r0.w, (int)r1.x, (int)r1.y, (int)r1.z, (int)r1.w};
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        const uint4 q0 = W8[mt * 32], q1 = W8[mt * 32 + 256];
-                        const i8v a8 = (i8v){(int)q0.x, (int)q0.y, (int)q0.z, (int)q0.w, (int)q1.x, (int)q1.y, (int)q1.z, (int)q1.w};
-                        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[mt][nt], 0, 0, 0, kMxScaleA, 0, kMxScaleB);
-                    }
-                }
-#else
                 i8v a8[2];
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
@@ -838,7 +821,6 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
 #endif
                     }
                 }
-#endif
 #if !R3D_MX_FREE_SCHED
                 __builtin_amdgcn_sched_barrier(0);
 #endif
