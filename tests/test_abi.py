@@ -123,10 +123,30 @@ def test_no_hazardous_packed_f32_forms(tmp_path):
     subprocess.check_call([llvm + "/llvm-objdump", "--offloading", so], stdout=subprocess.DEVNULL)      # writes lib.so.<k>.hipv4-...-gfx950
     objs = [str(tmp_path / f) for f in sorted(os.listdir(tmp_path)) if "amdgcn" in f]
     assert len(objs) >= 4, objs
-    n_pk = n_bad = n_mix = 0
+    n_pk = n_bad = n_mix = n_bar = 0
+    bare_barriers = []
     for o in objs:
         dis = subprocess.run([llvm + "/llvm-objdump", "-d", "--no-show-raw-insn", o], capture_output=True, text=True, check=True).stdout
+        sym, reads_in_flight = "", 0
         for line in dis.splitlines():
+            # in the DMA-pipelined SR loops a wave must not pass a barrier with LDS reads in flight (the buffer they read is
+            # refilled right after it).  Straight-line model of lgkmcnt for ds_read*: a barrier of those kernels with a read issued and
+            # not yet waited for is the race that put 55 of 1 920 pipelined frames off by one count.
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                sym, reads_in_flight = m.group(1), 0
+                continue
+            ins = re.sub(r"\s*//.*", "", line).strip()
+            if ins.startswith("ds_read"):
+                reads_in_flight += 1
+            elif ins.startswith("s_waitcnt"):
+                w = re.search(r"lgkmcnt\((\d+)\)", ins)
+                if w:
+                    reads_in_flight = min(reads_in_flight, int(w.group(1)))
+            elif ins.startswith("s_barrier") and ("conv_mfma_f16x3" in sym or "upconv_fir_f16x3" in sym or "conv1x1_mfma_f16x3" in sym):
+                n_bar += 1
+                if reads_in_flight:
+                    bare_barriers.append(sym[:60])
             # fp16(a * b) fused into one rounding (v_fma_mixlo/hi_f16 a, b, 0): hipcc derives `hi` of an fp16 hi/lo split this way at one
             # use and by fl32 + v_cvt at another, so hi + lo misses the value by an ulp of hi where the roundings differ
             # (csrc/r3d_common.h as_rounded()); no split in this library may compile to it
@@ -140,6 +160,8 @@ def test_no_hazardous_packed_f32_forms(tmp_path):
                 n_bad += int(pk_opsel_fix.hazardous(p))
     assert n_pk > 1000, "disassembly found only %d packed-f32 instructions: is the extraction broken?" % n_pk
     assert n_bad == 0, "%d packed-f32 instructions with a crossed src1 / src2 op_sel in libr3d_hip.so" % n_bad
+    assert n_bar >= 30, "only %d barriers seen in the SR conv kernels: is the symbol tracking broken?" % n_bar
+    assert not bare_barriers, "s_barrier passed with ds_reads in flight in: %s" % sorted(set(bare_barriers))
     assert n_mix == 0, "%d fp16 roundings fused into their product (v_fma_mix*_f16 a, b, 0): a hi/lo split is missing as_rounded()" % n_mix
 
 
