@@ -49,13 +49,19 @@ def parse():
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("R3D_BENCH_STREAMS", "3")),
                     help="HIP streams that consecutive frames are issued on (frames are independent)")
+    ap.add_argument("--sr-precision", default=os.environ.get("R3D_SR_PRECISION", "f16mx"), choices=["f16mx", "f16x3", "f32"],
+                    help="SR precision of the timed frames, selected BY NAME (the library default is the fp32-class 'f16x3', reported as alt_f16x3): "
+                         "'f16mx' = the cross products of each SR block's convs on the block-scaled fp8 MFMA, parity tier <= 5e-5 * max|ref| on every "
+                         "reference golden (tests/test_gpu_mx.py, tests/test_gpu_pinned_config.py)")
+    ap.add_argument("--no-traffic", action="store_true", help="do not re-measure roofline.traffic with rocprofv3 --pmc child runs")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--clip", type=int, default=0,
                     help="strong-scaling mode (BASELINE config 3): render ONE clip of this many frames, frame-sharded over the ranks "
                          "(uneven tail), gathered to rank 0 inside the timed region; --steps is ignored")
     return ap.parse_args()
 
 
-def build_scene(torch, dev, seed=7, n_frames=64):
+def build_scene(torch, dev, seed=7, n_frames=64, precision=None):
     import numpy as np
     from real3dportrait_amd import TriPlaneGenerator, synth
     from real3dportrait_amd.frames import ClipRenderer
@@ -73,7 +79,7 @@ def build_scene(torch, dev, seed=7, n_frames=64):
     residuals = [T(synth.synth_planes(seed + 1 + i, N=1, scale=0.1)) for i in range(4)]
     cams = T(synth.camera_sweep(n_frames, -0.4, 0.4))
     ws = torch.ones(1, 14, 512, device=dev)
-    clip = ClipRenderer(G, cano, residuals, cams, ws, base_seed=seed)
+    clip = ClipRenderer(G, cano, residuals, cams, ws, base_seed=seed, precision=precision)
     return G, clip, dec, (cano, residuals, cams)
 
 
@@ -109,7 +115,9 @@ def cpu_baseline(seed=7):
                 t_render, t_sr = r, q
     sample = "1 full frame, best of %d: render R=128 48+48 (%.2fs) + SR 128^2->512^2 (%.2fs)" % (runs, t_render, t_sr)
     return {"value": 1.0 / (t_render + t_sr), "unit": "frames/s", "cores": orc.num_threads, "kind": "port",
-            "sample": sample}
+            "sample": sample,
+            "note": "the C oracle = the parity CHECKER (scalar restatement of the reference, OpenMP over rays / output rows), not a tuned CPU "
+                    "renderer: its SR does not scale with the core count; the reference's own PyTorch CPU path is `cpu_baseline_reference`"}
 
 
 def cpu_baseline_reference():
@@ -145,7 +153,45 @@ def cpu_baseline_reference():
             "measured": measured}
 
 
-def build_torso_frame(torch, dev, G, seed=7, fused_input=True):
+def measure_traffic(prec):
+    """HBM bytes per launch of the conv kernels, measured NOW: two `rocprofv3 --pmc` child runs of this script (FETCH_SIZE and WRITE_SIZE
+    need separate passes, MI355X_MICROARCH.md "rocprofv3 PMC slots"; --pmc only, no trace domain), 6 frames on one stream each.
+    bytes = 2 x FETCH_SIZE (gfx950's counter tallies 128-byte requests as 64 B, same guide, "HBM") + WRITE_SIZE, both reported in KiB.
+    Returns {kernel name: bytes per launch} or None when rocprofv3 is not on PATH / a pass fails (the committed figure is then used)."""
+    import collections
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    tool = shutil.which("rocprofv3")
+    if tool is None:
+        return None, "rocprofv3 not on PATH"
+    tmp = tempfile.mkdtemp(prefix="r3d_traffic_", dir="/tmp")
+    vals = collections.defaultdict(dict)
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [tool, "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(tmp, ctr), "-o", "p", "--", sys.executable,
+                   os.path.abspath(__file__), "--traffic-child", "--sr-precision", prec, "--steps", "6"]
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd="/tmp", env={**os.environ, "TMPDIR": "/tmp"})
+            files = glob.glob(os.path.join(tmp, ctr, "**", "p_counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s pass failed (rc %d)" % (ctr, r.returncode)
+            acc = collections.defaultdict(list)
+            for f in files:
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == ctr:
+                        acc[row["Kernel_Name"].split("(")[0].replace("void r3d::", "").strip()].append(float(row["Counter_Value"]))
+            for k, v in acc.items():
+                vals[k][ctr] = sum(v) / len(v)
+    except Exception as e:      # noqa: BLE001
+        return None, "traffic measurement failed (%s)" % type(e).__name__
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = {k: int((2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024) for k, v in vals.items() if len(v) == 2}
+    return out, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run (6 frames, one stream): 2 x FETCH_SIZE + WRITE_SIZE per launch"
+
+
+def build_torso_frame(torch, dev, G, seed=7, fused_input=True, precision=None):
     """BASELINE config 4 surrogate: everything real3d_infer.py:480-492 runs per frame with the shipped torso model that is on the
     hot path -- to_plane_cnn (segformer.py:691-700) -> flips + cano add + layout -> rays -> fused ray kernel -> fused
     SuperresolutionHybrid8XDC_Warp.forward (block0, torso/background fusion convs at 256^2, SynthesisBlockNoUp, block1) -> uint8.
@@ -167,6 +213,8 @@ def build_torso_frame(torch, dev, G, seed=7, fused_input=True):
         def forward(self, *a, **k):
             return self.rgb_torso, self.ret
     sr = SuperresolutionHybrid8XDC_Warp(32, 512, 0, True, torso_model=StandInTorso()).to(dev).eval()
+    from real3dportrait_amd.superresolution import set_sr_precision
+    set_sr_precision(sr, precision if precision is not None else G.superresolution.block0.precision)
     with torch.no_grad():
         for blk, p in ((sr.block0, synth.synth_sr_block(seed, 32, 256, 512, 100)), (sr.block1, synth.synth_sr_block(seed, 256, 128, 512, 200)),
                        (sr.head_torso_block, synth.synth_sr_block(seed, 256, 256, 512, 400))):
@@ -252,7 +300,7 @@ def clip125(torch, dev, G, scene, clip, streams):
             "fps": round(n / best, 1), "realtime_factor": round(n / best / 25.0, 1)}
 
 
-def cfg5_stress(torch, dev, lib):
+def cfg5_stress(torch, dev, lib, precision="f16mx"):
     """BASELINE configs[4]: N = 8 novel-view cameras of one tri-plane per batch, R = 256, 96 + 96 samples, SR 256^2 -> 512^2 -> 1024^2 (the
     reference SR asserts a 512 output, superresolution.py:334: as SURVEY 8(d) defines it, the same two SynthesisBlocks at twice the size)."""
     import ctypes
@@ -275,6 +323,7 @@ def cfg5_stress(torch, dev, lib):
                 l = getattr(blk, name); w, b, aw, ab = p[name]
                 l.weight.copy_(T(w)); l.bias.copy_(T(b)); l.affine.weight.copy_(T(aw)); l.affine.bias.copy_(T(ab))
     b0.out_format = "split"; b1.return_x = False
+    b0.precision = b1.precision = precision
     ren = ImportanceRenderer(hp={}); ren.noise_mode = "hash"; ren.seed = 5
     opts = {"ray_start": "auto", "ray_end": "auto", "box_warp": 1.0, "depth_resolution": Nc, "depth_resolution_importance": Nf,
             "disparity_space_sampling": False, "clamp_mode": "softplus", "white_back": False}
@@ -355,8 +404,14 @@ def main():
         K_mine = clip_hi - clip_lo
     else:
         K_mine = K
-    G, clip, dec, scene = build_scene(torch, dev, n_frames=max(64, K * world, args.clip))
+    prec = args.sr_precision
+    G, clip, dec, scene = build_scene(torch, dev, n_frames=max(64, K * world, args.clip), precision=prec)
     ring = torch.zeros(K, 512, 512, 3, dtype=torch.uint8, device=dev)
+    if args.traffic_child:                               # child of measure_traffic(): a few frames on one stream under rocprofv3 --pmc
+        for i in range(6):
+            clip.render_u8(i, out=ring[i % K:i % K + 1])
+        torch.cuda.synchronize()
+        return
 
     pipe = None
     if args.streams > 1:
@@ -451,8 +506,6 @@ def main():
     ms, cnt = ctypes.c_double(0), ctypes.c_int(0)
     _lib.check(lib.r3d_profile_read(1, ctypes.byref(ms), ctypes.byref(cnt)), "profile_read")
     flops = conv_flops_per_frame(128)
-    from real3dportrait_amd.superresolution import DEFAULT_SR_PRECISION
-    prec = os.environ.get("R3D_SR_PRECISION", DEFAULT_SR_PRECISION)
     ums, ucnt = ctypes.c_double(0), ctypes.c_int(0)
     _lib.check(lib.r3d_profile_read(2, ctypes.byref(ums), ctypes.byref(ucnt)), "profile_read")
     if prec == "f32":       # the exact-f32 path runs all four convs on one kernel (per-phase transposed conv + FIR kernel)
@@ -463,12 +516,22 @@ def main():
     achieved_tf = dom_flops / (conv_ms_per_frame * 1e-3) / 1e12 if cnt.value else 0.0
     up_ms_per_frame = ums.value / max(1, ucnt.value) * 2
     up_tf = (flops[0] + flops[2]) / (up_ms_per_frame * 1e-3) / 1e12 if (ucnt.value and prec != "f32") else None
-    traffic = None                                       # HBM bytes per launch from the PMC passes of scripts/gpu_profile.sh (committed, not re-measured here)
-    tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    # HBM bytes per launch of the dominant kernel: re-measured in this run when rocprofv3 is available (rank 0 of a 1-GPU run), else the
+    # committed figure of profiles/traffic.json
+    traffic, traffic_source, traffic_all = None, None, None
+    dom_pat = {"f32": lambda k: k.startswith("conv_mfma_kernel"), "f16mx": lambda k: "conv_mfma_f16x3_kernel" in k and "true>" in k,
+               "f16x3": lambda k: "conv_mfma_f16x3_kernel" in k and "true>" not in k}[prec]
+    if rank == 0 and world == 1 and not args.no_traffic:
+        traffic_all, traffic_source = measure_traffic(prec)
+        if traffic_all:
+            hits = [v for k, v in traffic_all.items() if dom_pat(k)]
+            traffic = hits[0] if hits else None
+    if traffic is None:
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
         try:
             traffic = json.load(open(tpath)).get("conv_bytes_per_launch_" + prec)
-        except Exception:
+            traffic_source = "profiles/traffic.json (committed rocprofv3 --pmc passes; not re-measured in this run: %s)" % (traffic_source or "multi-GPU run or --no-traffic")
+        except Exception:       # noqa: BLE001
             traffic = None
     if prec == "f32":       # exact fp32 on v_mfma_f32_32x32x2_f32
         kname, peak, products = "conv_mfma_kernel", PEAK_F32_MFMA_TFLOPS, 1
@@ -479,7 +542,9 @@ def main():
         kname, peak, products = "conv_mfma_f16x3_kernel", PEAK_F16_MFMA_TFLOPS, 3
     roofline = {"kernel": kname, "bound": "mfma", "achieved": round(achieved_tf, 2),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(achieved_tf / peak, 4),
-                "traffic": traffic, "traffic_source": "profiles/traffic.json (rocprofv3 --pmc passes, committed; not re-measured in this run)",
+                "traffic": traffic, "traffic_source": traffic_source,
+                # block0.conv1: 256 ch x 256^2 in + out (4 B per value in SPLIT) + weights; block1.conv1: 128 ch x 512^2 in + weights + 2 toRGB partial planes
+                "algorithmic_bytes_per_launch": (2 * 256 * 256 * 256 * 4 + 9 * 256 * 256 * 4 + 128 * 512 * 512 * 4 + 9 * 128 * 128 * 4 + 2 * 3 * 512 * 512 * 4) // 2 if prec != "f32" else None,
                 "launches_per_frame": launches,
                 "avg_launch_ms": round(ms.value / max(1, cnt.value), 4),
                 "avg_launch_ms_in_timed_region": round(in_region_ms, 4),
@@ -490,7 +555,12 @@ def main():
     if up_tf is not None:   # second kernel family, reported beside the dominant one (its time includes the fused FIR/activation)
         roofline["upconv_fir_f16x3_kernel"] = {"launches_per_frame": 2, "avg_launch_ms": round(ums.value / max(1, ucnt.value), 4),
                                                "achieved": round(up_tf, 2), "frac": round(up_tf / peak, 4),
-                                               "mfma_products_per_mac": 3, "pipe_frac": round(up_tf * 3 / peak, 4)}
+                                               "mfma_products_per_mac": 3, "pipe_frac": round(up_tf * 3 / peak, 4),
+                                               "traffic": next((v for k, v in (traffic_all or {}).items() if "upconv_fir" in k), None),
+                                               # block0.conv0: 32 ch x 128^2 in, 256 ch x 256^2 out; block1.conv0: 256 ch x 256^2 in, 128 ch x 512^2 out; + weights
+                                               "algorithmic_bytes_per_launch": (32 * 128 * 128 * 4 + 256 * 256 * 256 * 4 + 9 * 32 * 256 * 4 + 256 * 256 * 256 * 4 + 128 * 512 * 512 * 4 + 9 * 256 * 128 * 4) // 2}
+        if traffic_all:
+            roofline["traffic_all_kernels"] = {k: v for k, v in sorted(traffic_all.items(), key=lambda kv: -kv[1])[:6]}
 
     # ---- the same K frames on ONE stream (no frame pipelining), so that the gain of the multi-stream issue is visible ----
     single_stream_fps = None
@@ -578,7 +648,7 @@ def main():
         # NCHW as `cano + secc` (secc_img2plane.py:76-77), depth image + global clamp, image_raw, image_feature, the fp32 image, the dict.
         from real3dportrait_amd import patch_model
         from real3dportrait_amd.frames import clone_generator_shell, frame_seed
-        G_api = patch_model(clone_generator_shell(G))
+        G_api = patch_model(clone_generator_shell(G), precision=prec)
         G_api.renderer.noise_mode = "hash"
         ws_api = torch.ones(1, 14, 512, device=dev)
 
@@ -670,7 +740,7 @@ def main():
     # ---- BASELINE configs[2] on one GPU and configs[4] (stress) -- extras, rank 0 of a 1-GPU run ----------------------------------------
     if rank == 0 and world == 1 and not args.no_extras:
         out["clip125_1gpu"] = clip125(torch, dev, G, scene, clip, args.streams)
-        out["cfg5_stress"] = cfg5_stress(torch, dev, lib)
+        out["cfg5_stress"] = cfg5_stress(torch, dev, lib, prec)
 
     # ---- the other shipped SR precision on the same frames (default f16mx -> f16x3, the fp32-class tier; and vice versa) ----------------
     if rank == 0 and world == 1 and not args.no_extras and prec in ("f16x3", "f16mx"):

@@ -91,7 +91,10 @@ int r3d_raygen(const float* c2w, const float* intrinsics, int N, int R,
  *                the f16 matrix pipe with fp32 operands split into fp16 hi + lo; one small launch per call (decoder_fold_kernel) derives
  *                exact power-of-two factors from this bound and from the weights (features * 2^b against W1 * 2^-b, and -- only when a
  *                bound would reach 2^15 -- 2^c on the hidden values / 2^d on the colour rows), so that the result equals the reference's
- *                unbounded fp32 evaluation for any magnitude of planes and weights whose pre-activations fit fp32
+ *                unbounded fp32 evaluation for any magnitude of planes and weights whose pre-activations fit fp32.
+ *                The bound must be RIGOROUS (max of the array >= max |planes_nhwc| as the kernel will read them): the per-sample fp16
+ *                split has no saturation guard, so a stale or too small bound yields inf / NaN, not a clamp.  Pass NULL whenever the
+ *                planes were modified after the partials were written (the Python operator does: it ties them to the tensor version).
  *   workspace    r3d_render_workspace_bytes() bytes of device scratch, 64-byte aligned
  */
 size_t r3d_render_workspace_bytes(int N, int M, int Nc, int Nf);

@@ -240,9 +240,13 @@ __device__ __forceinline__ void decoder_fold_block(const float* __restrict__ par
     __shared__ float rowb[R3D_HIDDEN];
     if (tid < R3D_HIDDEN) {                              // |b1[u]| and ||W1[u]||_1 of hidden unit u (the Bx-dependent part is finished by thread 0)
         float a = 0.f;
-        const float4* r4 = reinterpret_cast<const float4*>(w1 + tid * R3D_FEATURES);
+        if (((uintptr_t)w1 & 15) == 0) {
+            const float4* r4 = reinterpret_cast<const float4*>(w1 + tid * R3D_FEATURES);
 #pragma unroll
-        for (int c = 0; c < R3D_FEATURES / 4; ++c) { const float4 v = r4[c]; a += fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w); }
+            for (int c = 0; c < R3D_FEATURES / 4; ++c) { const float4 v = r4[c]; a += fabsf(v.x) + fabsf(v.y) + fabsf(v.z) + fabsf(v.w); }
+        } else {                                         // a caller of the raw C ABI with an unaligned weight pointer: scalar loads
+            for (int c = 0; c < R3D_FEATURES; ++c) a += fabsf(w1[tid * R3D_FEATURES + c]);
+        }
         rowb[tid] = a;
     }
     __shared__ float rowbias[R3D_HIDDEN];

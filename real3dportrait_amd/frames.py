@@ -83,19 +83,37 @@ class ClipGatherer:
             self._comm = None
 
 
-_GATHERERS = {}
+_GATHERERS = {}      # (shape, device, group key) -> (weakref to the group or None, ClipGatherer)
+
+
+def clear_gatherers():
+    """Drop the receive buffers gather_frames() keeps between calls (world * per * H * W * 3 bytes of device memory per shape)."""
+    for _, g in _GATHERERS.values():
+        g.close()
+    _GATHERERS.clear()
 
 
 def gather_frames(local, num_frames, group=None):
-    """local: uint8 [per, H, W, 3] on every rank (per = ceil(T/W), tail rows unused).  Returns uint8 [T, H, W, 3] on rank 0 (a view of a
-    buffer that is allocated once per shape and reused by the next call) and None elsewhere."""
+    """local: uint8 [per, H, W, 3] on every rank (per = ceil(T/W), tail rows unused).  Returns a NEW uint8 [T, H, W, 3] tensor on rank 0
+    and None elsewhere.  The receive buffer is kept per (shape, device, process group) and reused by the next call -- the result is a
+    copy of it, so a second call cannot overwrite a clip handed out earlier (use ClipGatherer directly for the zero-copy view);
+    clear_gatherers() releases the buffers."""
+    import weakref
     if not (dist.is_available() and dist.is_initialized()):
-        return local[:num_frames]
+        return local[:num_frames].clone()
     key = (tuple(local.shape), str(local.device), id(group))
-    g = _GATHERERS.get(key)
-    if g is None:
-        g = _GATHERERS[key] = ClipGatherer(local.shape[0], local.shape[1:3], local.device, "torch", group)
-    return g.gather(local.contiguous(), num_frames)
+    ent = _GATHERERS.get(key)
+    if ent is not None and group is not None and ent[0]() is not group:      # id() of a destroyed group was recycled
+        ent[1].close()
+        ent = None
+    if ent is None:
+        try:
+            ref = weakref.ref(group) if group is not None else (lambda: None)
+        except TypeError:                                                   # (a group type without weak references: key on id only)
+            ref = (lambda g=group: g)
+        ent = _GATHERERS[key] = (ref, ClipGatherer(local.shape[0], local.shape[1:3], local.device, "torch", group))
+    out = ent[1].gather(local.contiguous(), num_frames)
+    return None if out is None else out.clone()
 
 
 def render_clip_sharded(render_frame, num_frames, frame_hw=(512, 512), device="cuda", group=None):
@@ -137,10 +155,18 @@ class ClipRenderer:
     secc2plane residual add, modules/real3d/secc_img2plane.py:73-81, fused into the layout kernel),
     render + SR, clamp, uint8 HWC conversion on device."""
 
-    def __init__(self, generator, cano_planes, residuals, cameras, ws, base_seed=0):
+    def __init__(self, generator, cano_planes, residuals, cameras, ws, base_seed=0, precision=None):
+        """precision: SR precision to set on the generator's blocks -- None = leave them as they are (library default 'f16x3'),
+        'throughput' = superresolution.THROUGHPUT_SR_PRECISION ('f16mx', unless R3D_SR_PRECISION names another: what bench.py asks for),
+        or a precision name."""
+        import os
         from . import _lib
+        from .superresolution import THROUGHPUT_SR_PRECISION, set_sr_precision
         self._lib = _lib
         self.G = generator
+        if precision == "throughput":
+            precision = os.environ.get("R3D_SR_PRECISION", THROUGHPUT_SR_PRECISION)
+        set_sr_precision(generator.superresolution, precision)
         self.cano = cano_planes            # [1,3,32,H,W]
         self.residuals = residuals         # list of [1,3,32,H,W] (cycled) or None
         self.cameras = cameras             # [T,25]
@@ -206,10 +232,11 @@ class PipelinedClipRenderer:
     own operator workspaces (clone_generator_shell): the latency-bound ray kernel of frame t+1 overlaps the MFMA-bound
     SR convolutions of frame t.  `sync()` joins the side streams back into the caller's stream."""
 
-    def __init__(self, generator, cano_planes, residuals, cameras, ws, base_seed=0, n_streams=2):
+    def __init__(self, generator, cano_planes, residuals, cameras, ws, base_seed=0, n_streams=2, precision=None):
         self.streams = [torch.cuda.Stream() for _ in range(n_streams)]
-        shells = [generator] + [clone_generator_shell(generator) for _ in range(n_streams - 1)]
-        self.clips = [ClipRenderer(g, cano_planes, residuals, cameras, ws, base_seed) for g in shells]
+        first = ClipRenderer(generator, cano_planes, residuals, cameras, ws, base_seed, precision)      # sets the precision the shells then copy
+        shells = [clone_generator_shell(generator) for _ in range(n_streams - 1)]
+        self.clips = [first] + [ClipRenderer(g, cano_planes, residuals, cameras, ws, base_seed, None) for g in shells]
         self._k = 0
 
     def render_u8(self, t, out=None):

@@ -123,3 +123,39 @@ def look_at_camera(yaw=0.0, pitch=0.0, radius=2.7, lookat=(0.0, 0.0, 0.2), focal
 def camera_sweep(n, yaw_lo=-0.4, yaw_hi=0.4, pitch=0.0):
     yaws = np.linspace(yaw_lo, yaw_hi, n) if n > 1 else np.array([0.0])
     return np.stack([look_at_camera(float(y), pitch) for y in yaws]).astype(np.float32)
+
+
+# ---- host mirror of the device's counter-based sampling noise (csrc/r3d_common.h: mix32 / hash_uniform) ---------------------------
+# noise_mode='hash' of ImportanceRenderer replaces the two RNG draws of the reference (torch.rand_like at
+# modules/eg3ds/volumetric_rendering/renderer.py:226, torch.rand at :281) by a function of (seed, stream, index): stream 0 = the coarse
+# jitter, index = ray * Nc + k; stream 1 = the importance u, index = ray * Nf + j; ray = n * M + m.  tests/test_gpu_pinned_config.py
+# holds this mirror bit-identical to the kernel (hash mode == the same arrays injected) and feeds them to the oracle.
+def _mix32(x):
+    x = x.astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    x = (x * np.uint32(0x7FEB352D)).astype(np.uint32)
+    x ^= x >> np.uint32(15)
+    x = (x * np.uint32(0x846CA68B)).astype(np.uint32)
+    x ^= x >> np.uint32(16)
+    return x
+
+
+def device_hash_uniform(seed, stream, idx):
+    """float32 [0,1) values of r3d::hash_uniform(seed, stream, idx) for an array of 64-bit indices."""
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    idx = np.asarray(idx, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        h0 = np.uint32((seed & 0xFFFFFFFF) ^ ((0x9E3779B9 * (int(stream) + 1)) & 0xFFFFFFFF))
+        h = _mix32(np.full(1, h0, np.uint32))
+        h = _mix32(h ^ np.uint32(seed >> 32))
+        h = _mix32(h ^ (idx & np.uint64(0xFFFFFFFF)).astype(np.uint32))
+        h = _mix32(h ^ (idx >> np.uint64(32)).astype(np.uint32) ^ np.uint32(0x85EBCA6B))
+    return ((h >> np.uint32(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)).astype(np.float32)
+
+
+def render_hash_noise(seed, rays, Nc, Nf):
+    """(noise_coarse [len(rays), Nc], u_fine [len(rays), Nf]) the ray kernel derives for the global ray indices `rays` (n * M + m)."""
+    rays = np.asarray(rays, dtype=np.uint64).reshape(-1, 1)
+    nc = device_hash_uniform(seed, 0, rays * np.uint64(Nc) + np.arange(Nc, dtype=np.uint64)[None, :])
+    uf = device_hash_uniform(seed, 1, rays * np.uint64(max(Nf, 1)) + np.arange(max(Nf, 1), dtype=np.uint64)[None, :])[:, :Nf]
+    return nc, uf

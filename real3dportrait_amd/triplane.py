@@ -180,9 +180,11 @@ def _reference_hparams(model):
     return hp
 
 
-def patch_model(model, fuse_warp_sr=True):
+def patch_model(model, fuse_warp_sr=True, precision=None):
     """Swap the hot-path operators of a constructed reference model for the HIP ones (in place).  INFERENCE ONLY: the HIP modules
     detach their inputs and build no autograd graph (the reference runs this path under torch.no_grad(), real3d_infer.py:435,479).
+    precision: SR precision of the installed blocks (None = the library default 'f16x3', fp32-class like the reference's fp32 layers;
+    'f16mx' = the throughput tier bench.py measures; superresolution.py "Precision policy").
 
     * model.ray_sampler  -> RaySampler            (created at img2plane_baseline.py:106 / triplane.py:38)
     * model.renderer     -> ImportanceRenderer    (img2plane_baseline.py:104-105 / triplane.py:36-37)
@@ -236,6 +238,8 @@ def patch_model(model, fuse_warp_sr=True):
             sr.split_input_spec = types.MethodType(sr_with_ref.warp_split_input_spec, sr)
     for owner in (getattr(model, "secc_img2plane_backbone", None), getattr(model, "img2plane_backbone", None)):
         _patch_sequential(owner, "to_plane_cnn", dev)       # per-frame plane producer tail (segformer.py:691-700)
+    from .superresolution import set_sr_precision
+    set_sr_precision(model.superresolution, precision)
     return model
 
 

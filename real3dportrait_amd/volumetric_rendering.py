@@ -149,8 +149,18 @@ class ImportanceRenderer(nn.Module):
         _lib.check(lib.r3d_planes_to_nhwc(_lib.ptr(planes), _lib.ptr(addc), _lib.ptr(out), N, C, H, W, D,
                                           int(add_flip), part.data_ptr(), ctypes.byref(nwritten), _lib.stream_ptr()), "planes_to_nhwc")
         out._r3d_nhwc = True
-        out._r3d_absmax = (part, int(nwritten.value))
+        out._r3d_absmax = (part, int(nwritten.value), out._version)
         return out
+
+    @staticmethod
+    def _absmax_of(planes_nhwc):
+        """(partials pointer, count) for r3d_render_forward / r3d_run_model, or (None, 0) = "measure the bound inside the call".  The
+        partials of prepare_planes are only trusted while the tensor is the one that pass wrote: an in-place update afterwards bumps
+        its version, and a stale bound would let the kernel's unguarded fp16 split (split8_bounded) overflow silently."""
+        tag = getattr(planes_nhwc, "_r3d_absmax", None)
+        if tag is None or tag[2] != planes_nhwc._version:
+            return None, 0
+        return tag[0].data_ptr(), tag[1]
 
     def _planes_nhwc(self, planes):
         """Channel-last copy of `planes`, cached for static planes.  The cache entry holds the SOURCE tensor itself and is valid
@@ -232,7 +242,7 @@ class ImportanceRenderer(nn.Module):
         need = int(lib.r3d_render_workspace_bytes(N, M, Nc, Nf))
         if self._workspace is None or self._workspace.numel() < need or self._workspace.device != dev:
             self._workspace = torch.empty(need, device=dev, dtype=torch.uint8)
-        part, npart = getattr(planes_nhwc, "_r3d_absmax", (None, 0))        # absent (caller's own layout): measured inside the call
+        part, npart = self._absmax_of(planes_nhwc)        # None (caller's own layout, or updated in place since): measured inside the call
         x_split, sp_scale, sp_stride = None, None, 0
         if _split_for is not None:
             sp_scale, sp_stride, consumer = _split_for
@@ -245,7 +255,7 @@ class ImportanceRenderer(nn.Module):
             int(bool(rendering_options.get("white_back", False))),
             _lib.ptr(noise_c), _lib.ptr(u_f), int(self.seed) & 0xFFFFFFFFFFFFFFFF,
             _lib.ptr(rgb_cm), int(self.rgb_channel_major), _lib.ptr(depth), _lib.ptr(wsum), _lib.ptr(valid),
-            None if part is None else part.data_ptr(), npart, _lib.ptr(c2w), _lib.ptr(K),
+            part, npart, _lib.ptr(c2w), _lib.ptr(K),
             _lib.ptr(x_split), None if sp_scale is None else sp_scale.data_ptr(), int(sp_stride),
             _lib.ptr(self._workspace), need, _lib.stream_ptr()), "render_forward")
         if x_split is not None:
@@ -271,9 +281,9 @@ class ImportanceRenderer(nn.Module):
         need = int(lib.r3d_run_model_workspace_bytes())
         if self._workspace is None or self._workspace.numel() < need or self._workspace.device != coords.device:
             self._workspace = torch.empty(need, device=coords.device, dtype=torch.uint8)
-        part, npart = getattr(planes_nhwc, "_r3d_absmax", (None, 0))
+        part, npart = self._absmax_of(planes_nhwc)
         _lib.check(lib.r3d_run_model(_lib.ptr(planes_nhwc), N, H, W, D, _lib.ptr(w1), _lib.ptr(b1), _lib.ptr(w2),
                                      _lib.ptr(b2), _lib.ptr(coords), npts, float(options["box_warp"]),
-                                     _lib.ptr(rgb), _lib.ptr(sigma), None if part is None else part.data_ptr(), npart,
+                                     _lib.ptr(rgb), _lib.ptr(sigma), part, npart,
                                      _lib.ptr(self._workspace), need, _lib.stream_ptr()), "run_model")
         return {"rgb": rgb, "sigma": sigma}

@@ -1,9 +1,10 @@
-"""GPU parity (`-m gpu`) of the fp32-class SR precision 'f16x3' on every test that takes the library default.
+"""GPU parity (`-m gpu`) of the throughput SR precision 'f16mx' on every test that takes the library default.
 
-Since the end of round 3 the default SR precision is 'f16mx' (DESIGN 4.2c), so the tests of test_gpu_parity / test_gpu_warp_sr /
-test_gpu_range_and_sizes that build SR modules without naming a precision exercise that path.  This file runs the same test bodies
-again with R3D_SR_PRECISION=f16x3 (read when a block is constructed), so both shipped precisions meet every reference golden, every
-bit-exactness property and the fused-path equalities."""
+The library default is the fp32-class 'f16x3' (round 4: superresolution.py "Precision policy"); bench.py and frames.ClipRenderer(precision=
+'throughput') select 'f16mx' by name.  The tests of test_gpu_parity / test_gpu_warp_sr / test_gpu_range_and_sizes that build SR modules
+without naming a precision therefore exercise f16x3; this file runs the same test bodies again with R3D_SR_PRECISION=f16mx (read when a
+block is constructed), so BOTH shipped precisions meet every reference golden, every bit-exactness property and the fused-path
+equalities.  (The file keeps its round-3 name; then the roles were the other way round.)"""
 import pytest
 
 import test_gpu_parity as tp
@@ -23,30 +24,48 @@ PLAIN = [tw.test_warp_sr_forward_v2_golden, tw.test_torso_frame_fused_input_equa
 
 
 @pytest.mark.parametrize("fn", WITH_TORCH, ids=lambda f: f.__name__)
-def test_f16x3(monkeypatch, torch_cuda, fn):
-    monkeypatch.setenv("R3D_SR_PRECISION", "f16x3")
+def test_f16mx(monkeypatch, torch_cuda, fn):
+    monkeypatch.setenv("R3D_SR_PRECISION", "f16mx")
     fn(torch_cuda)
 
 
 @pytest.mark.parametrize("fn", PLAIN, ids=lambda f: f.__name__)
-def test_f16x3_warp(monkeypatch, fn):
-    monkeypatch.setenv("R3D_SR_PRECISION", "f16x3")
+def test_f16mx_warp(monkeypatch, fn):
+    monkeypatch.setenv("R3D_SR_PRECISION", "f16mx")
     fn()
 
 
 @pytest.mark.parametrize("tag", ["down", "up"])
-def test_f16x3_sr_resize(monkeypatch, torch_cuda, tag):
-    monkeypatch.setenv("R3D_SR_PRECISION", "f16x3")
+def test_f16mx_sr_resize(monkeypatch, torch_cuda, tag):
+    monkeypatch.setenv("R3D_SR_PRECISION", "f16mx")
     tp.test_sr_resize_golden(torch_cuda, tag)
 
 
-def test_default_precision_is_f16mx_and_pinnable(monkeypatch):
-    from real3dportrait_amd.superresolution import DEFAULT_SR_PRECISION, SynthesisBlock, SynthesisBlockNoUp
-    assert DEFAULT_SR_PRECISION == "f16mx"
+def test_precision_policy(monkeypatch):
+    """Library default = fp32-class f16x3; the throughput tier is selected by name (ClipRenderer(precision='throughput'), patch_model(precision=),
+    set_sr_precision) or for a process by R3D_SR_PRECISION."""
+    import torch
+    from real3dportrait_amd import TriPlaneGenerator
+    from real3dportrait_amd.frames import ClipRenderer
+    from real3dportrait_amd.superresolution import DEFAULT_SR_PRECISION, THROUGHPUT_SR_PRECISION, SynthesisBlock, SynthesisBlockNoUp, set_sr_precision
+    assert DEFAULT_SR_PRECISION == "f16x3" and THROUGHPUT_SR_PRECISION == "f16mx"
     monkeypatch.delenv("R3D_SR_PRECISION", raising=False)
     b = SynthesisBlock(32, 64, w_dim=512, resolution=32, img_channels=3, is_last=False, conv_clamp=None)
-    assert b.precision == "f16mx" and b._prec() == 2
+    assert b.precision == "f16x3" and b._prec() == 1
+    G = TriPlaneGenerator()
+    z = torch.zeros(1)
+    ClipRenderer(G, z, None, z, z)
+    assert G.superresolution.block0.precision == "f16x3"                       # None: left alone
+    ClipRenderer(G, z, None, z, z, precision="throughput")
+    assert G.superresolution.block0.precision == G.superresolution.block1.precision == "f16mx"
+    set_sr_precision(G.superresolution, "f32")
+    assert G.superresolution.block1.precision == "f32"
+    with pytest.raises(ValueError):
+        set_sr_precision(G.superresolution, "fp8")
     n = SynthesisBlockNoUp(64, 64, w_dim=512, resolution=32, img_channels=3, is_last=False, conv_clamp=None)
+    n.precision = "f16mx"
     assert n._prec() == 1                       # no fp8 path in the block without up-sampling: computes as f16x3
-    monkeypatch.setenv("R3D_SR_PRECISION", "f16x3")
-    assert SynthesisBlock(32, 64, w_dim=512, resolution=32, img_channels=3, is_last=False, conv_clamp=None).precision == "f16x3"
+    monkeypatch.setenv("R3D_SR_PRECISION", "f16mx")
+    assert SynthesisBlock(32, 64, w_dim=512, resolution=32, img_channels=3, is_last=False, conv_clamp=None).precision == "f16mx"
+    ClipRenderer(G, z, None, z, z, precision="throughput")
+    assert G.superresolution.block0.precision == "f16mx"
