@@ -31,8 +31,6 @@ static constexpr int kC = R3D_FEATURES;      // 32
 static constexpr int kHid = R3D_HIDDEN;      // 64
 static constexpr int kOut = R3D_DECODER_OUT; // 33
 static constexpr int kWavesPerBlock = 4;
-static constexpr int kMaxSamples = 192;      // Nc + Nf
-static constexpr int kRayArr = kMaxSamples + 8;
 
 // -------------------------------------------------------------------------------------------------
 // layout kernel: NCHW [N*3][C][H*W] (+ optional add, optionally flipped along H / W per plane) -> [N*3][H*W][C]
@@ -575,11 +573,14 @@ __device__ __forceinline__ void gather_sample(const float4* __restrict__ planes4
 // of layer 1.  Out: col[ot] (4 regs) = colour channel 16ot+4q+reg of sample s (after the sigmoid clamp of
 // triplane.py:187); sig = density of sample s (replicated over q).
 // -------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void decode_tile(const DecoderLds& L, int lane, const h8 xh, const h8 xl, f32x4 (&col)[2], float& sig)
+// The decode of a tile in three segments (state: h[4] = hidden accumulators, col[2], sig), so that a pass can put the load / consume steps of
+// the NEXT tile's gather between them (render_kernel: the software pipeline of round 4); decode_tile = the three in a row.
+struct DecodeState { f32x4 h[4]; };
+
+// A: layer 1, H^T[16mt.., samples] = W1'[16mt.., ch] X^T (k-slot q <-> channels 8q..8q+7), softplus in the log2 domain, density row on the VALU
+__device__ __forceinline__ void decode_a(const DecoderLds& L, int lane, const h8 xh, const h8 xl, DecodeState& S, float& sig)
 {
     const int q = lane >> 4;
-    // layer 1: H^T[16mt.., samples] = W1'[16mt.., ch] X^T   (k-slot q <-> channels 8q..8q+7)
-    f32x4 h[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         f32x4 acc;
@@ -590,65 +591,80 @@ __device__ __forceinline__ void decode_tile(const DecoderLds& L, int lane, const
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc, 0, 0, 0);
-        h[mt] = acc;
+        S.h[mt] = acc;
     }
-    // softplus in the log2 domain, density row on the VALU
     float sg = 0.0f;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float x = h[mt][r];
+            const float x = S.h[mt][r];
             // max(x, 0) as (x + |x|) / 2 (exact; the |x| is a free source modifier, the halving rides in an fma): fmaxf costs two v_max (hipcc
             // canonicalises an operand it cannot prove quiet, e.g. an MFMA result) -- 96 softplus per lane and ray
             const float sp = __builtin_fmaf(x + fabsf(x), 0.5f, __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(-fabsf(x))));
-            h[mt][r] = sp;
+            S.h[mt][r] = sp;
             sg += sp * L.w2s[16 * mt + 4 * q + r];
         }
     sg += __shfl_xor(sg, 16);
     sg += __shfl_xor(sg, 32);
     sig = sg + L.b2[0];
-    const float hs = L.hs, ys = L.ys;                // range fold (DecFold): 1 unless a bound reaches 2^15 -- wave-uniform, not taken
+    const float hs = L.hs;                           // range fold (DecFold): 1 unless a bound reaches 2^15 -- wave-uniform, not taken
     if (hs != 1.0f) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) h[mt][r] *= hs;
+            for (int r = 0; r < 4; ++r) S.h[mt][r] *= hs;
     }
-    // layer 2: Y^T[1+16ot.., samples] = W2'[.., hidden] H^T, two k-steps of 32 hidden units; the B operand of k-step p is
-    // this lane's accumulator registers of tiles mt = 2p, 2p+1 (no data movement)
-#pragma unroll
-    for (int ot = 0; ot < 2; ++ot) {
-        col[ot][0] = L.b2[1 + 16 * ot + 4 * q + 0]; col[ot][1] = L.b2[1 + 16 * ot + 4 * q + 1];
-        col[ot][2] = L.b2[1 + 16 * ot + 4 * q + 2]; col[ot][3] = L.b2[1 + 16 * ot + 4 * q + 3];
-    }
-#pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {
-        const float hv[8] = {h[2 * pp][0], h[2 * pp][1], h[2 * pp][2], h[2 * pp][3],
-                             h[2 * pp + 1][0], h[2 * pp + 1][1], h[2 * pp + 1][2], h[2 * pp + 1][3]};
-        h8 bh, bl;
-        split8_bounded(hv, bh, bl);
+}
+
+// B / C: layer 2, Y^T[1+16ot.., samples] = W2'[.., hidden] H^T, k-step pp of 32 hidden units; the B operand of k-step pp is this lane's
+// accumulator registers of tiles mt = 2pp, 2pp+1 (no data movement).  C ends with the sigmoid clamp.
+template <int PP>
+__device__ __forceinline__ void decode_l2(const DecoderLds& L, int lane, const DecodeState& S, f32x4 (&col)[2])
+{
+    const int q = lane >> 4;
+    if (PP == 0) {
 #pragma unroll
         for (int ot = 0; ot < 2; ++ot) {
-            uint4 a0 = L.w2f[ot][pp][0][lane], a1 = L.w2f[ot][pp][1][lane];
-            const h8 wh = *reinterpret_cast<h8*>(&a0), wl = *reinterpret_cast<h8*>(&a1);
-            col[ot] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh, col[ot], 0, 0, 0);
-            col[ot] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl, col[ot], 0, 0, 0);
-            col[ot] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh, col[ot], 0, 0, 0);
+            col[ot][0] = L.b2[1 + 16 * ot + 4 * q + 0]; col[ot][1] = L.b2[1 + 16 * ot + 4 * q + 1];
+            col[ot][2] = L.b2[1 + 16 * ot + 4 * q + 2]; col[ot][3] = L.b2[1 + 16 * ot + 4 * q + 3];
         }
     }
-    if (ys != 1.0f) {
+    const float hv[8] = {S.h[2 * PP][0], S.h[2 * PP][1], S.h[2 * PP][2], S.h[2 * PP][3],
+                         S.h[2 * PP + 1][0], S.h[2 * PP + 1][1], S.h[2 * PP + 1][2], S.h[2 * PP + 1][3]};
+    h8 bh, bl;
+    split8_bounded(hv, bh, bl);
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+        uint4 a0 = L.w2f[ot][PP][0][lane], a1 = L.w2f[ot][PP][1][lane];
+        const h8 wh = *reinterpret_cast<h8*>(&a0), wl = *reinterpret_cast<h8*>(&a1);
+        col[ot] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, bh, col[ot], 0, 0, 0);
+        col[ot] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl, col[ot], 0, 0, 0);
+        col[ot] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh, col[ot], 0, 0, 0);
+    }
+    if (PP == 1) {
+        const float ys = L.ys;
+        if (ys != 1.0f) {
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) col[ot][r] *= ys;
+        }
+        // sigmoid clamp from MipNeRF: sigmoid(y)*(1+2*0.001)-0.001; col holds log2(e) * y
 #pragma unroll
         for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) col[ot][r] *= ys;
+            for (int r = 0; r < 4; ++r)
+                col[ot][r] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-col[ot][r])) * 1.002f - 0.001f;
     }
-    // sigmoid clamp from MipNeRF: sigmoid(y)*(1+2*0.001)-0.001; col holds log2(e) * y
-#pragma unroll
-    for (int ot = 0; ot < 2; ++ot)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-            col[ot][r] = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-col[ot][r])) * 1.002f - 0.001f;
+}
+
+__device__ __forceinline__ void decode_tile(const DecoderLds& L, int lane, const h8 xh, const h8 xl, f32x4 (&col)[2], float& sig)
+{
+    DecodeState S;
+    decode_a(L, lane, xh, xl, S, sig);
+    decode_l2<0>(L, lane, S, col);
+    decode_l2<1>(L, lane, S, col);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -711,17 +727,165 @@ __device__ __forceinline__ void gather_to_mfma(XchLds& E, int lane, const float 
     xl = *reinterpret_cast<h8*>(&rl);
 }
 
-// per-wave scratch
+// per-wave scratch, sized by the instantiation (NS = 16 (NTC + NTF) + 8 samples, NCD = 16 NTC + 8 cdf entries): 3.1 KB per wave for the
+// 48 + 48 shape instead of the 6.4 KB of the 96 + 96 one -- with the feature staging below a block of the REF shape stays at 45 KB
+template <int NS, int NCD>
 struct RayLds {
-    float t[kRayArr];      // depths: [0,Nc) coarse as generated, [Nc,Nc+Nf) fine
-    float sg[kRayArr];     // densities, same indexing
-    float ts[kRayArr];     // depth-sorted depths
-    float ss[kRayArr];     // depth-sorted densities
-    float wv[kRayArr];     // interval weights (coarse order first, later sorted order)
-    float om[kRayArr];     // omega per ORIGINAL sample index
-    float cdf[104];
-    int cnt[kRayArr];      // merge histogram / rank-collision check
+    float t[NS];           // depths: [0,Nc) coarse as generated, [Nc,Nc+Nf) fine
+    float sg[NS];          // densities, same indexing
+    float ts[NS];          // depth-sorted depths
+    float ss[NS];          // depth-sorted densities
+    float wv[NS];          // interval weights (coarse order first, later sorted order)
+    float om[NS];          // omega per ORIGINAL sample index
+    float cdf[NCD];
+    int cnt[NS];           // merge histogram / rank-collision check
 };
+
+// ---- the software pipeline of a pass (round 4) ---------------------------------------------------------------------------------------
+// Until round 3 a pass ran tile by tile: gather plane 0 -> wait -> plane 1 -> wait -> plane 2 -> wait -> exchange -> decode.  In-kernel
+// stamps (profiles/r04/ray_phase_stamps_*.txt) put 74 % of a ray's cycles there, and within it the gather at 1 450 cycles per (plane, tile)
+// step for ~300 cycles of issue: the eight 1 KB load instructions of a step are 16 cycles each on the CU's 64 B / clk vector-memory path,
+// and the CU's 8 waves run them at the same time -- the gather sits at ~70 % of that path's rate while it runs, and the path idles while
+// the waves decode.  Issuing a chunk's loads back to back (one gather phase, then one decode phase) changed nothing (0.224 -> 0.221 ms):
+// not latency, rate.  So the two are overlapped INSIDE a wave: the three (issue, consume) steps of tile t+1's gather sit between the three
+// segments of tile t's decode -- a step's loads are in flight during a segment's MFMAs and transcendentals -- and the finished features of
+// tile t+1 (times the range fold, split into fp16 hi / lo) wait in a two-slot LDS staging area (MFMA-operand order: the exchange of
+// gather_to_mfma) for their decode.  Only the first tile of a pass is gathered in the open (its depths depend on the previous pass).
+struct FeatLds { uint4 v[2][2 * 64]; };           // [hi|lo][slot parity * 64 + swizzled lane]: 4 KB per wave
+
+typedef __amdgpu_buffer_rsrc_t PlaneRsrc;
+struct TileGather {                               // one lane quad = one sample; lane q owns channels 8q..8q+7
+    f32x4 lo[2][4], hi[2][4];                     // two load buffers: the first tile of a pass keeps two planes in flight, the pipelined tiles one
+    float tw[2][4];
+    Tap tq[4];
+    float acc[8];
+    // the taps of the tile: this lane computes plane min(q, 2)'s (the quad shares them by DPP, see gather_sample)
+    // (tap addresses are BYTE offsets from the image's planes: 32 bits, through a buffer descriptor built from wave-uniform values ->
+    // buffer_load_dwordx4 with one VGPR per address; the 64-bit per-lane pointer arithmetic of a global_load was 2 VALU instructions per
+    // tap.  host: 3 * depth * H * W * 128 < 2^32)
+    __device__ __forceinline__ void start(int H, int W, int q, float px, float py, float pz, float scale)
+    {
+        const float qx = px * scale, qy = py * scale, qz = pz * scale;
+        const int pq = q < 2 ? q : 2;
+        plane_taps(pq == 2 ? qz : qx, pq == 0 ? qy : (pq == 1 ? qz : qx), H, W, pq * H * W * 8, tq);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tq[k].idx *= 16;
+    }
+    template <int P, int B>
+    __device__ __forceinline__ void issue(const PlaneRsrc rsrc, unsigned qoff)        // qoff = 32 q: this lane's 8 channels of a texel
+    {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int wbits = __builtin_bit_cast(int, tq[k].w);
+            const unsigned off = (unsigned)(P == 0 ? __builtin_amdgcn_mov_dpp(tq[k].idx, 0x00, 0xF, 0xF, true) : P == 1 ? __builtin_amdgcn_mov_dpp(tq[k].idx, 0x55, 0xF, 0xF, true) : __builtin_amdgcn_mov_dpp(tq[k].idx, 0xAA, 0xF, 0xF, true)) + qoff;
+            tw[B][k] = __builtin_bit_cast(float, P == 0 ? __builtin_amdgcn_mov_dpp(wbits, 0x00, 0xF, 0xF, true) : P == 1 ? __builtin_amdgcn_mov_dpp(wbits, 0x55, 0xF, 0xF, true) : __builtin_amdgcn_mov_dpp(wbits, 0xAA, 0xF, 0xF, true));
+            lo[B][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off, 0, 0));
+            hi[B][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off + 16u), 0, 0));
+        }
+    }
+    // "the loads of buffer B are consumed HERE, not earlier": sched_barrier only binds the machine scheduler -- the bilinear FMAs are pure
+    // nodes of the selection DAG and were linearised in FRONT of the decode segment they were meant to follow (the wait for the loads with
+    // them).  An asm statement that takes the loaded registers and the segment's outputs pins both: the FMAs read its outputs.
+    template <int B>
+    __device__ __forceinline__ void pin(f32x4& d0, f32x4& d1)
+    {
+        asm volatile("" : "+v"(lo[B][0]), "+v"(lo[B][1]), "+v"(lo[B][2]), "+v"(lo[B][3]), "+v"(hi[B][0]), "+v"(hi[B][1]), "+v"(hi[B][2]), "+v"(hi[B][3]),
+                          "+v"(d0), "+v"(d1));
+    }
+    // per-plane partial sums in the order of gather_sample (bit-identical features): plane sum first, then the three planes added
+    template <int P, int B>
+    __device__ __forceinline__ void consume()
+    {
+        float pa[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) pa[c] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float w = tw[B][k];
+            const f32x4 a4 = lo[B][k], b4 = hi[B][k];
+            pa[0] += a4[0] * w; pa[1] += a4[1] * w; pa[2] += a4[2] * w; pa[3] += a4[3] * w;
+            pa[4] += b4[0] * w; pa[5] += b4[1] * w; pa[6] += b4[2] * w; pa[7] += b4[3] * w;
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c] = P == 0 ? pa[c] : acc[c] + pa[c];
+    }
+    __device__ __forceinline__ void finish(FeatLds& F, int slot, int wi, float xs3)
+    {
+        float X[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) X[c] = acc[c] * xs3;
+        h8 xh, xl;
+        split8_bounded(X, xh, xl);
+        F.v[0][slot * 64 + wi] = *reinterpret_cast<uint4*>(&xh);
+        F.v[1][slot * 64 + wi] = *reinterpret_cast<uint4*>(&xl);
+    }
+};
+
+// One pass over NT tiles.  depth_of(t): depth of the sample this lane gathers for in tile t.  col0 / col1 / sig: the per-tile outputs.
+template <int NT, int GPF, bool TRI, typename DepthFn>
+__device__ __forceinline__ void decode_pass(FeatLds& F, const DecoderLds& dec, const float4* __restrict__ P, int H, int W, int D, int lane,
+                                            float ox, float oy, float oz, float dx, float dy, float dz, float scale, float xs3,
+                                            DepthFn depth_of, f32x4 (&col0)[NT], f32x4 (&col1)[NT], float (&sig)[NT])
+{
+    const int gq = lane & 3, gs = lane >> 2, q = lane >> 4, s = lane & 15;
+    const int wi = gs * 4 + (gq ^ (gs >> 2)), ri = s * 4 + (q ^ (s >> 2));     // swizzled staging slots (write: gather mapping, read: MFMA mapping)
+    // the image's planes as a wave-uniform base (a wave renders one ray, hence one image)
+    const uint64_t pb = (uint64_t)(uintptr_t)P;
+    void* pu = reinterpret_cast<void*>((uintptr_t)(((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(pb >> 32)) << 32) |
+                                                   (unsigned)__builtin_amdgcn_readfirstlane((int)(pb & 0xffffffffu))));
+    const PlaneRsrc pl = __builtin_amdgcn_make_buffer_rsrc(pu, 0, __builtin_amdgcn_readfirstlane(3 * (TRI ? D : 1) * H * W * 128), 0x00020000);
+    const unsigned qoff = 32u * (unsigned)gq;
+    TileGather g;
+    auto gather_whole = [&](int t) {                                           // tri-grids / the first tile of a pass: not overlapped with a decode
+        const float tg = depth_of(t);
+        if constexpr (TRI) {
+            float X[8]; h8 xh, xl;
+            gather_sample<GPF, true>(P, H, W, gq, ox + tg * dx, oy + tg * dy, oz + tg * dz, scale, xs3, X, D);
+            split8_bounded(X, xh, xl);
+            F.v[0][(t & 1) * 64 + wi] = *reinterpret_cast<uint4*>(&xh); F.v[1][(t & 1) * 64 + wi] = *reinterpret_cast<uint4*>(&xl);
+        } else {
+            f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = z0;
+            g.start(H, W, gq, ox + tg * dx, oy + tg * dy, oz + tg * dz, scale);
+            g.template issue<0, 0>(pl, qoff);
+            g.template issue<1, 1>(pl, qoff);                                        // two planes in flight
+            g.template pin<0>(z0, z1); g.template consume<0, 0>();
+            g.template issue<2, 0>(pl, qoff);
+            g.template pin<1>(z0, z1); g.template consume<1, 1>();
+            g.template pin<0>(z0, z1); g.template consume<2, 0>();
+            g.finish(F, t & 1, wi, xs3);
+        }
+    };
+    gather_whole(0);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        wave_lds_sync();
+        uint4 rh = F.v[0][(t & 1) * 64 + ri], rl4 = F.v[1][(t & 1) * 64 + ri];
+        const h8 xh = *reinterpret_cast<h8*>(&rh), xl = *reinterpret_cast<h8*>(&rl4);
+        const bool more = t + 1 < NT;
+        DecodeState S;
+        f32x4 c2[2];
+        if (more && !TRI) {
+            const float tg = depth_of(t + 1);
+            g.start(H, W, gq, ox + tg * dx, oy + tg * dy, oz + tg * dz, scale);
+            g.template issue<0, 0>(pl, qoff);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        decode_a(dec, lane, xh, xl, S, sig[t]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more && !TRI) { g.template pin<0>(S.h[0], S.h[3]); g.template consume<0, 0>(); g.template issue<1, 0>(pl, qoff); }
+        __builtin_amdgcn_sched_barrier(0);
+        decode_l2<0>(dec, lane, S, c2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more && !TRI) { g.template pin<0>(c2[0], c2[1]); g.template consume<1, 0>(); g.template issue<2, 0>(pl, qoff); }
+        __builtin_amdgcn_sched_barrier(0);
+        decode_l2<1>(dec, lane, S, c2);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more && !TRI) { g.template pin<0>(c2[0], c2[1]); g.template consume<2, 0>(); g.finish(F, (t + 1) & 1, wi, xs3); }
+        if (more && TRI) gather_whole(t + 1);
+        col0[t] = c2[0]; col1[t] = c2[1];
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
 
 // A6 on n samples T/S (LDS, in the order to march): writes interval weights to wv[0..n-2],
 // returns (sum w, sum w*tmid) wave-uniform.   ray_marcher.py:26-45
@@ -798,9 +962,10 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
     constexpr int SLOTS = (16 * (NTC + NTF) + 63) / 64;
     constexpr int CSLOTS = (16 * NTC + 63) / 64;
     constexpr int FSLOTS = NTF > 0 ? (16 * NTF + 63) / 64 : 1;
+    typedef RayLds<16 * (NTC + NTF) + 8, 16 * NTC + 8> RayL;
     __shared__ __attribute__((aligned(16))) DecoderLds dec;
-    __shared__ __attribute__((aligned(16))) RayLds rl[kWavesPerBlock];
-    __shared__ __attribute__((aligned(16))) XchLds xch[kWavesPerBlock];
+    __shared__ __attribute__((aligned(16))) RayL rl[kWavesPerBlock];
+    __shared__ __attribute__((aligned(16))) FeatLds feat[kWavesPerBlock];
 
     stage_decoder(dec, a.w1, a.b1, a.w2, a.b2, a.fold);
     __syncthreads();
@@ -808,9 +973,9 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = lane >> 4, s = lane & 15;          // MFMA / per-sample mapping
-    const int gq = gather_q(lane), gs = gather_s(lane);   // gather mapping
-    RayLds& L = rl[wave];
-    XchLds& E = xch[wave];
+    const int gs = gather_s(lane);                        // gather mapping: lane = 4 * sample + q
+    RayL& L = rl[wave];
+    FeatLds& F = feat[wave];
     const int Nc = a.Nc, Nf = a.Nf, S = Nc + Nf;
     // min / max of the valid rays' starts (renderer.py:123-126): reduce the per-block partials of ray_limits_kernel
     int pmin = 0x7fffffff, pmax = (int)0x80000000, pany = 0;
@@ -862,17 +1027,13 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
         // ---- coarse pass: gather + decode ----------------------------------------------------------------
         f32x4 colc[2][NTC];
         float sigc[NTC];
+        {
+            // depth of the sample this lane gathers for (lane gs of the per-sample mapping: q = 0, s = gs)
+            float tgs[NTC];
 #pragma unroll
-        for (int nt = 0; nt < NTC; ++nt) {            // per-tile pipeline: gather (24 loads in flight) -> decode
-            float X[8];
-            f32x4 c2[2];
-            h8 xh, xl;
-            const float tg = __shfl(tc[nt], gs);       // depth of the sample this lane gathers for (lane gs: q = 0, s = gs)
-            gather_sample<GPF, TRI>(P, a.H, a.W, gq, ox + tg * dx, oy + tg * dy, oz + tg * dz, a.scale, xs3, X, a.D);
-            gather_to_mfma(E, lane, X, xh, xl);
-            decode_tile(dec, lane, xh, xl, c2, sigc[nt]);
-            colc[0][nt] = c2[0]; colc[1][nt] = c2[1];
-            __builtin_amdgcn_sched_barrier(0);         // one tile at a time (VGPR budget)
+            for (int nt = 0; nt < NTC; ++nt) tgs[nt] = __shfl(tc[nt], gs);
+            auto dof = [&](int t) { return tgs[t]; };
+            decode_pass<NTC, GPF, TRI>(F, dec, P, a.H, a.W, a.D, lane, ox, oy, oz, dx, dy, dz, a.scale, xs3, dof, colc[0], colc[1], sigc);
         }
         if (q == 0) {
 #pragma unroll
@@ -936,18 +1097,9 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
             R3D_STAMP(2);
             // ---- fine pass ----------------------------------------------------------------------------------
             float sigf[NTF > 0 ? NTF : 1];
-#pragma unroll
-            for (int nt = 0; nt < NTF; ++nt) {
-                const int k = 16 * nt + gs;
-                const float tf = L.t[Nc + (k < Nf ? k : 0)];
-                float X[8];
-                f32x4 c2[2];
-                h8 xh, xl;
-                gather_sample<GPF, TRI>(P, a.H, a.W, gq, ox + tf * dx, oy + tf * dy, oz + tf * dz, a.scale, xs3, X, a.D);
-                gather_to_mfma(E, lane, X, xh, xl);
-                decode_tile(dec, lane, xh, xl, c2, sigf[nt]);
-                colf[0][nt] = c2[0]; colf[1][nt] = c2[1];
-                __builtin_amdgcn_sched_barrier(0);
+            {
+                auto dof = [&](int t) { const int k = 16 * t + gs; return L.t[Nc + (k < Nf ? k : 0)]; };
+                decode_pass<(NTF > 0 ? NTF : 1), GPF, TRI>(F, dec, P, a.H, a.W, a.D, lane, ox, oy, oz, dx, dy, dz, a.scale, xs3, dof, colf[0], colf[1], sigf);
             }
             if (q == 0) {
 #pragma unroll
@@ -1156,7 +1308,7 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
         wave_lds_sync();
         R3D_STAMP(6);
     }
-    R3D_STAMP_FLUSH(8, st_rays_);
+    R3D_STAMP_FLUSH(10, st_rays_);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         run_min = fminf(run_min, __shfl_xor(run_min, d));
@@ -1353,7 +1505,7 @@ extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
         set_error("render_forward: depth_resolution %d / importance %d outside [4,96] / [0,96]", Nc, Nf);
         return R3D_ERR_INVALID_ARG;
     }
-    if ((size_t)H * W * 3 * 8 * (size_t)1 >= (size_t)0x7fffffff) { set_error("render_forward: planes too large for 32-bit tap index"); return R3D_ERR_INVALID_ARG; }
+    if ((size_t)H * W * 3 * triplane_depth * 128 >= ((size_t)1 << 32)) { set_error("render_forward: planes too large for 32-bit tap offsets (3 * depth * H * W * 128 bytes per image must stay below 4 GiB)"); return R3D_ERR_INVALID_ARG; }
     if (!workspace || workspace_bytes < r3d_render_workspace_bytes(N, M, Nc, Nf)) { set_error("render_forward: workspace too small"); return R3D_ERR_WORKSPACE; }
     hipStream_t st = (hipStream_t)stream;
     const int nrays = N * M;

@@ -27,8 +27,9 @@ for _ in range(reps): ren.forward_camera(nhwc, dec, cam[:, :16].view(-1, 4, 4), 
 ev1.record(); torch.cuda.synchronize()
 assert lib.r3d_debug_stamps(buf) == 0
 rays = buf[31]
-names = ["setup+depths", "coarse gather+decode", "march+importance", "fine gather+decode", "merge", "final march+omega", "composite+store", "between rays"]
-tot = sum(buf[i] for i in range(8))
+names = ["setup+depths", "coarse decode", "march+importance", "fine decode", "merge", "final march+omega", "composite+store", "between rays",
+         "coarse gather", "fine gather"]
+tot = sum(buf[i] for i in range(10))
 print("R=%d %d+%d: %.3f ms per call (instrumented), %d rays, %.0f cycles per ray" % (R, Nc, Nf, ev0.elapsed_time(ev1) / reps, rays // reps, tot / rays))
 for i, n in enumerate(names):
     print("  %-22s %8.0f cycles  %5.1f %%" % (n, buf[i] / rays, 100.0 * buf[i] / tot))
