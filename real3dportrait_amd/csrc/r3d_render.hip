@@ -935,26 +935,47 @@ struct RenderArgs {
 // Ray order: XCD x (= blockIdx % 8, the observed dispatch rule -- speed only) renders the column strip
 // [x*R/8, (x+1)*R/8) of every image, walking DOWN columns, so that the waves resident on one XCD share
 // the XZ / ZX plane rows in that XCD's L2 and vertical neighbours hit the same taps in L1.
-__device__ __forceinline__ bool next_ray(const RenderArgs& a, int R, int iter, int wave, int& ray)
-{
-    const int nrays = a.N * a.M;
-    if (R > 0 && (R & 7) == 0 && (gridDim.x & 7) == 0) {
-        const int xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, nbx = gridDim.x >> 3;
-        const int strip = R >> 3;
-        const long long wj = (long long)iter * nbx * kWavesPerBlock + bx * kWavesPerBlock + wave;
-        const long long per_img = (long long)strip * R;
-        if (wj >= per_img * a.N) return false;
-        const int n = (int)(wj / per_img);
-        const int rem = (int)(wj - (long long)n * per_img);
-        const int col = xcd * strip + rem / R, row = rem % R;
-        ray = n * a.M + row * R + col;
-        return true;
+// A wave's rays are wj = w0 + iter * stride of the sequence (image n, strip column c, row): the position is carried from ray to ray on the
+// SCALAR unit (stride = sa * per_img + sb * R + sc decomposed once), because the closed form -- two 64-bit divisions by runtime values per
+// ray, on vector registers -- was ~200 VALU instructions per ray (5 % of the kernel's issue slots).
+struct RayIter {
+    int strips, n, c, row, sa, sb, sc, R, strip, N, M, col0;
+    long long lin, lstride, nrays;
+    __device__ __forceinline__ void init(const RenderArgs& a, int R_, int wave)
+    {
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        R = R_; N = a.N; M = a.M;
+        strips = (R > 0 && (R & 7) == 0 && (gridDim.x & 7) == 0) ? 1 : 0;
+        if (strips) {
+            const unsigned xcd = blockIdx.x & 7, bx = blockIdx.x >> 3, nbx = gridDim.x >> 3;
+            strip = R >> 3; col0 = (int)xcd * strip;
+            const unsigned per_img = (unsigned)strip * (unsigned)R;                 // < 2^31: R * R = M fits an int
+            const unsigned w0 = bx * kWavesPerBlock + (unsigned)wv, st = nbx * kWavesPerBlock;
+            n = (int)(w0 / per_img); const unsigned rem = w0 - (unsigned)n * per_img;
+            c = (int)(rem / (unsigned)R); row = (int)(rem - (unsigned)c * (unsigned)R);
+            sa = (int)(st / per_img); const unsigned srem = st - (unsigned)sa * per_img;
+            sb = (int)(srem / (unsigned)R); sc = (int)(srem - (unsigned)sb * (unsigned)R);
+        } else {
+            nrays = (long long)a.N * a.M;
+            lin = (long long)blockIdx.x * kWavesPerBlock + wv;
+            lstride = (long long)gridDim.x * kWavesPerBlock;
+        }
     }
-    const long long wi = (long long)iter * gridDim.x * kWavesPerBlock + blockIdx.x * kWavesPerBlock + wave;
-    if (wi >= nrays) return false;
-    ray = (int)wi;
-    return true;
-}
+    __device__ __forceinline__ bool get(int& ray, int& img) const
+    {
+        if (strips) { if (n >= N) return false; img = n; ray = n * M + row * R + col0 + c; return true; }
+        if (lin >= nrays) return false;
+        ray = (int)lin; img = ray / M; return true;
+    }
+    __device__ __forceinline__ void advance()
+    {
+        if (strips) {
+            row += sc; if (row >= R) { row -= R; ++c; }
+            c += sb;   if (c >= strip) { c -= strip; ++n; }
+            n += sa;
+        } else lin += lstride;
+    }
+};
 
 template <int NTC, int NTF, int OCC, int GPF, bool TRI = false>
 __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
@@ -966,6 +987,11 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
     __shared__ __attribute__((aligned(16))) DecoderLds dec;
     __shared__ __attribute__((aligned(16))) RayL rl[kWavesPerBlock];
     __shared__ __attribute__((aligned(16))) FeatLds feat[kWavesPerBlock];
+    // The coarse pass's colours (8 registers per tile) wait in LDS while the fine pass runs: they are only needed again for the composite,
+    // and the fine pass (its own colours + the gather pipeline's load buffers) is where the register file runs out (REF shape: 256 VGPRs and
+    // spills to scratch, whose loads share vmcnt with the gather).  6 KB per wave; only for shapes whose block stays under 80 KB of LDS.
+    constexpr bool PARK = NTF > 0 && NTC <= 3;
+    __shared__ __attribute__((aligned(16))) f32x4 park[PARK ? kWavesPerBlock : 1][PARK ? 2 * NTC : 1][64];
 
     stage_decoder(dec, a.w1, a.b1, a.w2, a.b2, a.fold);
     __syncthreads();
@@ -991,24 +1017,31 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
     R3D_STAMP_DECL;
     int st_rays_ = 0; (void)st_rays_;
 
-    for (int iter = 0;; ++iter) {
-        int ray;
-        if (!next_ray(a, R, iter, wave, ray)) break;
+    RayIter it;
+    it.init(a, R, wave);
+    for (;; it.advance()) {
+        // The kernel arguments are re-read from the kernarg segment where a ray needs them (scalar loads): kept in SGPRs across the whole ray
+        // loop they did not fit, and hipcc spilled ~120 of them to VGPR lanes -- ~170 v_readlane per ray on the VALU this kernel is bound by.
+        typedef const __attribute__((address_space(4))) RenderArgs* KArgs;
+        KArgs ap = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ap));
+        const auto& A = *ap;
+        int ray, n;
+        if (!it.get(ray, n)) break;
         ++st_rays_;
         R3D_STAMP(7);                                  // (between rays: loop overhead, prologue on the first ray)
-        const int n = ray / a.M;
-        const float4* P = a.planes4 + (size_t)n * 3 * (TRI ? a.D : 1) * a.H * a.W * 8;
+        const float4* P = A.planes4 + (size_t)n * 3 * (TRI ? A.D : 1) * A.H * A.W * 8;
         float ox, oy, oz, dx, dy, dz;
-        if (a.cam_c2w) {
+        if (A.cam_c2w) {
             float o3[3], d3[3];
-            make_ray(a.cam_c2w + 16 * n, a.cam_K + 9 * n, a.cam_R, ray - n * a.M, o3, d3);
+            make_ray(A.cam_c2w + 16 * n, A.cam_K + 9 * n, A.cam_R, ray - n * A.M, o3, d3);
             ox = o3[0]; oy = o3[1]; oz = o3[2]; dx = d3[0]; dy = d3[1]; dz = d3[2];
         } else {
-            ox = a.origins[3 * (size_t)ray]; oy = a.origins[3 * (size_t)ray + 1]; oz = a.origins[3 * (size_t)ray + 2];
-            dx = a.dirs[3 * (size_t)ray]; dy = a.dirs[3 * (size_t)ray + 1]; dz = a.dirs[3 * (size_t)ray + 2];
+            ox = A.origins[3 * (size_t)ray]; oy = A.origins[3 * (size_t)ray + 1]; oz = A.origins[3 * (size_t)ray + 2];
+            dx = A.dirs[3 * (size_t)ray]; dy = A.dirs[3 * (size_t)ray + 1]; dz = A.dirs[3 * (size_t)ray + 2];
         }
-        float start = a.ray_start[ray], end = a.ray_end[ray];
-        if (!a.valid[ray] && any_valid) { start = gmin_start; end = gmax_start; }   // renderer.py:125-126
+        float start = A.ray_start[ray], end = A.ray_end[ray];
+        if (!A.valid[ray] && any_valid) { start = gmin_start; end = gmax_start; }   // renderer.py:125-126
 
         // ---- A3 stratified depths: linspace(start,end,Nc) + U*delta  (renderer.py:223-226) --------------
         const float span = end - start;
@@ -1020,7 +1053,7 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
             const bool act = k < Nc;
             const float step = (float)k / (float)(Nc - 1);
             float u = 0.0f;
-            if (act) u = a.noise_c ? a.noise_c[(size_t)ray * Nc + k] : hash_uniform(a.seed, 0, (uint64_t)ray * Nc + k);
+            if (act) u = A.noise_c ? A.noise_c[(size_t)ray * Nc + k] : hash_uniform(A.seed, 0, (uint64_t)ray * Nc + k);
             tc[nt] = act ? (start + step * span) + u * delta : start;
         }
         R3D_STAMP(0);
@@ -1033,7 +1066,12 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
 #pragma unroll
             for (int nt = 0; nt < NTC; ++nt) tgs[nt] = __shfl(tc[nt], gs);
             auto dof = [&](int t) { return tgs[t]; };
-            decode_pass<NTC, GPF, TRI>(F, dec, P, a.H, a.W, a.D, lane, ox, oy, oz, dx, dy, dz, a.scale, xs3, dof, colc[0], colc[1], sigc);
+            decode_pass<NTC, GPF, TRI>(F, dec, P, A.H, A.W, A.D, lane, ox, oy, oz, dx, dy, dz, A.scale, xs3, dof, colc[0], colc[1], sigc);
+        }
+        constexpr bool parked = PARK;                  // (an instantiation with NTF > 0 is only launched with Nf > 0)
+        if (parked) {
+#pragma unroll
+            for (int nt = 0; nt < NTC; ++nt) { park[PARK ? wave : 0][PARK ? 2 * nt : 0][lane] = colc[0][nt]; park[PARK ? wave : 0][PARK ? 2 * nt + 1 : 0][lane] = colc[1][nt]; }
         }
         if (q == 0) {
 #pragma unroll
@@ -1081,7 +1119,7 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
             for (int sl = 0; sl < FSLOTS; ++sl) {
                 const int j = sl * 64 + lane;
                 if (j < Nf) {
-                    const float u = a.u_f ? a.u_f[(size_t)ray * Nf + j] : hash_uniform(a.seed, 1, (uint64_t)ray * Nf + j);
+                    const float u = A.u_f ? A.u_f[(size_t)ray * Nf + j] : hash_uniform(A.seed, 1, (uint64_t)ray * Nf + j);
                     int lo = 0, hi = ns + 1;          // searchsorted(cdf, u, right=True)
                     while (lo < hi) { const int mid = (lo + hi) >> 1; if (L.cdf[mid] <= u) lo = mid + 1; else hi = mid; }
                     const int below = max(lo - 1, 0), above = min(lo, ns);
@@ -1099,7 +1137,7 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
             float sigf[NTF > 0 ? NTF : 1];
             {
                 auto dof = [&](int t) { const int k = 16 * t + gs; return L.t[Nc + (k < Nf ? k : 0)]; };
-                decode_pass<(NTF > 0 ? NTF : 1), GPF, TRI>(F, dec, P, a.H, a.W, a.D, lane, ox, oy, oz, dx, dy, dz, a.scale, xs3, dof, colf[0], colf[1], sigf);
+                decode_pass<(NTF > 0 ? NTF : 1), GPF, TRI>(F, dec, P, A.H, A.W, A.D, lane, ox, oy, oz, dx, dy, dz, A.scale, xs3, dof, colf[0], colf[1], sigf);
             }
             if (q == 0) {
 #pragma unroll
@@ -1237,8 +1275,10 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
         for (int nt = 0; nt < NTC; ++nt) {
             const int k = 16 * nt + s;
             const float om = k < Nc ? L.om[k] : 0.0f;
-            acc[0] += colc[0][nt] * om;
-            acc[1] += colc[1][nt] * om;
+            f32x4 cc0 = colc[0][nt], cc1 = colc[1][nt];
+            if (parked) { cc0 = park[PARK ? wave : 0][PARK ? 2 * nt : 0][lane]; cc1 = park[PARK ? wave : 0][PARK ? 2 * nt + 1 : 0][lane]; }
+            acc[0] += cc0 * om;
+            acc[1] += cc1 * om;
         }
         if constexpr (NTF > 0) {
 #pragma unroll
@@ -1256,15 +1296,15 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
                 float v = acc[ot][r];
                 // sum over the 16 samples of the tile row (all 16 lanes end with the total): rotations inside the DPP row
                 v += dpp_f<0x128>(0.0f, v); v += dpp_f<0x124>(0.0f, v); v += dpp_f<0x122>(0.0f, v); v += dpp_f<0x121>(0.0f, v);
-                if (a.white_back) v = v + 1.0f - wsum;
+                if (A.white_back) v = v + 1.0f - wsum;
                 acc[ot][r] = v * 2.0f - 1.0f;            // ray_marcher.py:52-55
             }
-        if (s == 0 && a.split_out) {
+        if (s == 0 && A.split_out) {
             // the feature image a second time, as the SR's first operand wants it: times block0.conv0's folded style vector, split into
             // fp16 hi + lo, [n][hi|lo][c/8][pixel][8] -- what to_split_kernel would produce from the fp32 copy (its launch and the 2 MB
             // round trip are gone).  Lane q: channels 4q..4q+3 = half (q & 1) of chunk q >> 1, channels 16+4q.. = chunk 2 + (q >> 1).
-            const float* sc = a.split_scale + (size_t)n * a.split_scale_stride;
-            const size_t pix = (size_t)(ray - n * a.M), plane = (size_t)(kC / 8) * a.M;
+            const float* sc = A.split_scale + (size_t)n * A.split_scale_stride;
+            const size_t pix = (size_t)(ray - n * A.M), plane = (size_t)(kC / 8) * A.M;
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot) {
                 const float4 s4 = *reinterpret_cast<const float4*>(sc + 16 * ot + 4 * q);
@@ -1277,18 +1317,18 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
                     split_scaled(acc[ot][r], sv[r], hh, ll);              // r3d_common.h: bit for bit what to_split_kernel stores
                     hi[r] = hh; lo[r] = ll;
                 }
-                uint2* dst = a.split_out + (((size_t)n * 2 * plane + (size_t)(2 * ot + (q >> 1)) * a.M + pix) * 2 + (q & 1));
+                uint2* dst = A.split_out + (((size_t)n * 2 * plane + (size_t)(2 * ot + (q >> 1)) * A.M + pix) * 2 + (q & 1));
                 dst[0] = *reinterpret_cast<uint2*>(&hi);
                 dst[2 * plane] = *reinterpret_cast<uint2*>(&lo);
             }
         }
         if (s == 0) {
-            if (a.rgb_cm) {                                 // lane q holds channels 4q..4q+3 and 16+4q..16+4q+3 of the ray
-                float* o = a.rgb + ((size_t)n * kC + 4 * q) * a.M + (ray - n * a.M);
+            if (A.rgb_cm) {                                 // lane q holds channels 4q..4q+3 and 16+4q..16+4q+3 of the ray
+                float* o = A.rgb + ((size_t)n * kC + 4 * q) * A.M + (ray - n * A.M);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { o[(size_t)r * a.M] = acc[0][r]; o[(size_t)(16 + r) * a.M] = acc[1][r]; }
+                for (int r = 0; r < 4; ++r) { o[(size_t)r * A.M] = acc[0][r]; o[(size_t)(16 + r) * A.M] = acc[1][r]; }
             } else {
-                float4* o4 = reinterpret_cast<float4*>(a.rgb + (size_t)ray * kC);
+                float4* o4 = reinterpret_cast<float4*>(A.rgb + (size_t)ray * kC);
                 o4[q] = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
                 o4[4 + q] = make_float4(acc[1][0], acc[1][1], acc[1][2], acc[1][3]);
             }
@@ -1302,8 +1342,8 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
         }
         run_min = fminf(run_min, lmin); run_max = fmaxf(run_max, lmax);
         if (lane == 0) {
-            if (a.depth) a.depth[ray] = dsum / wsum;     // NaN handled + clamped by depth_clamp_kernel
-            a.wsum[ray] = wsum;
+            if (A.depth) A.depth[ray] = dsum / wsum;     // NaN handled + clamped by depth_clamp_kernel
+            A.wsum[ray] = wsum;
         }
         wave_lds_sync();
         R3D_STAMP(6);
