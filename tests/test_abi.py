@@ -154,6 +154,7 @@ def test_no_hazardous_packed_f32_forms(tmp_path):
                 n_mix += 1
             if "v_pk_" not in line:
                 continue
+            n_bad += int(pk_opsel_fix.other_pk64_hazard(re.sub(r"\s*//.*", "", line)))      # v_pk_mov_b32 with a crossed src1: not allowed in
             p = pk_opsel_fix.parse(re.sub(r"\s*//.*", "", line))
             if p is not None:
                 n_pk += 1
@@ -165,17 +166,29 @@ def test_no_hazardous_packed_f32_forms(tmp_path):
     assert n_mix == 0, "%d fp16 roundings fused into their product (v_fma_mix*_f16 a, b, 0): a hi/lo split is missing as_rounded()" % n_mix
 
 
-def test_pk_opsel_rewriter_rules():
-    """The rewriter's three rules on literal instructions (source swap, v_swap_b32 for a crossed src2 / both sources, constants untouched)."""
+def test_pk_opsel_rewriter_rules(monkeypatch):
+    """The rewriter's rules on literal instructions: source swap; the v_swap_b32 path (crossed src2 / both sources) is REFUSED unless
+    explicitly allowed (not validated on hardware) and still produces the documented sequence when it is; constants and a crossed
+    src0 are left alone; any other packed op with a crossed src1 is refused."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "real3dportrait_amd", "csrc", "tools"))
     import pk_opsel_fix as pf
+    import pytest
+    monkeypatch.delenv("R3D_PK_ALLOW_DWORD_SWAP", raising=False)
     st = {"pk": 0, "swapped": 0, "dword_swapped": 0}
     assert pf.fix_line("\tv_pk_mul_f32 v[4:5], v[2:3], v[0:1] op_sel:[0,1] op_sel_hi:[1,0]", st) == \
         ["\tv_pk_mul_f32 v[4:5], v[0:1], v[2:3] op_sel:[1,0] op_sel_hi:[0,1]"]
     assert pf.fix_line("\tv_pk_mul_f32 v[4:5], v[2:3], s[8:9] op_sel:[0,1]", st) == ["\tv_pk_mul_f32 v[4:5], s[8:9], v[2:3] op_sel:[1,0]"]
-    assert pf.fix_line("\tv_pk_fma_f32 v[4:5], v[72:73], v[2:3], v[4:5] op_sel:[0,0,1] op_sel_hi:[1,0,0]", st) == \
-        ["\tv_swap_b32 v4, v5", "\tv_pk_fma_f32 v[4:5], v[72:73], v[2:3], v[4:5] op_sel_hi:[1,0,1]"]
+    src2_crossed = "\tv_pk_fma_f32 v[4:5], v[72:73], v[2:3], v[4:5] op_sel:[0,0,1] op_sel_hi:[1,0,0]"
+    with pytest.raises(RuntimeError):
+        pf.fix_line(src2_crossed, st)
+    with pytest.raises(RuntimeError):
+        pf.fix_line("\tv_pk_mul_f32 v[2:3], v[4:5], v[6:7] op_sel:[1,1] op_sel_hi:[0,0]", st)
+    with pytest.raises(RuntimeError):
+        pf.fix_line("\tv_pk_mov_b32 v[2:3], v[4:5], v[6:7] op_sel:[0,1]", st)
+    assert pf.fix_line("\tv_pk_mov_b32 v[2:3], v[4:5], v[6:7] op_sel:[1,0]", st) == ["\tv_pk_mov_b32 v[2:3], v[4:5], v[6:7] op_sel:[1,0]"]
+    monkeypatch.setenv("R3D_PK_ALLOW_DWORD_SWAP", "1")
+    assert pf.fix_line(src2_crossed, st) == ["\tv_swap_b32 v4, v5", "\tv_pk_fma_f32 v[4:5], v[72:73], v[2:3], v[4:5] op_sel_hi:[1,0,1]"]
     assert pf.fix_line("\tv_pk_fma_f32 v[8:9], v[0:1], v[2:3], v[4:5] op_sel:[0,0,1] op_sel_hi:[1,1,0]", st) == \
         ["\tv_swap_b32 v4, v5", "\tv_pk_fma_f32 v[8:9], v[0:1], v[2:3], v[4:5]", "\tv_swap_b32 v4, v5"]
     same = "\tv_pk_add_f32 v[0:1], v[0:1], 1.0 op_sel_hi:[1,0]"
@@ -183,3 +196,12 @@ def test_pk_opsel_rewriter_rules():
     crossed0 = "\tv_pk_mul_f32 v[30:31], v[14:15], v[14:15] op_sel:[1,0] op_sel_hi:[0,1]"
     assert pf.fix_line(crossed0, st) == [crossed0]                       # src0 crossing is exact on the hardware: left alone
     assert st["swapped"] == 2 and st["dword_swapped"] == 2
+
+
+def test_pk_opsel_rewriter_assembler_round_trip():
+    """The selftest the build runs first: known hazardous forms -> rewriter -> this ROCm's gfx950 assembler -> expected encodings."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "real3dportrait_amd", "csrc", "tools", "pk_opsel_fix.py"), "--selftest",
+                          "/opt/rocm/lib/llvm/bin"], capture_output=True, text=True)
+    assert out.returncode == 0 and "round-tripped" in out.stdout, out.stdout + out.stderr
