@@ -151,6 +151,10 @@ size_t r3d_run_model_workspace_bytes(void);
  *   by the consumer conv's style vector -- as input it must have been scaled with this block's conv0 styles; as
  *   output it is scaled with `next_scale` ([N][Cout] floats, stride next_scale_stride: the next block's conv0 styles,
  *   i.e. the start of that block's styles buffer).
+ *   R3D_FMT_SPLIT_MX (R3D_SR_F16MX, up = 1 blocks): R3D_FMT_SPLIT whose lo plane holds, byte for byte in its place, the fp8 correction
+ *   records of the f16mx precision (lo chunk 2G: xh8 = e4m3(hi * 2^-7) of channels 16G..16G+15, lo chunk 2G+1: xl8 = e4m3(lo * 2^4)).
+ *   As x_out_format the block's conv1 epilogue writes them; as x_format the block's up-sampling conv runs its cross products on the
+ *   block-scaled fp8 MFMA (2 instead of 3 matrix passes per MAC).  A producer / consumer pair must agree (same next_scale as SPLIT).
  *   clamp < 0 disables conv_clamp (the fp32 configuration Real3D uses, img2plane_baseline.py:102-104).
  *   img_u8 (may be NULL; R3D_SR_F16X3 only): [N,OH,OW,3] uint8 -- the block is the last one of the network and the frame leaves
  *   as clamp(-1,1) -> ((x + 1) / 2 * 255).int() (triplane.py:136 + inference/real3d_infer.py:472,518-522), fused into the
@@ -173,7 +177,7 @@ size_t r3d_run_model_workspace_bytes(void);
  *                         from a measured max|x| when its input bound is a propagated one).
  *            The prepacked buffer is precision-specific (same size). */
 enum r3d_sr_precision { R3D_SR_F32 = 0, R3D_SR_F16X3 = 1, R3D_SR_F16MX = 2 };
-enum r3d_act_format { R3D_FMT_NONE = -1, R3D_FMT_NCHW = 0, R3D_FMT_CB8 = 1, R3D_FMT_SPLIT = 2 };
+enum r3d_act_format { R3D_FMT_NONE = -1, R3D_FMT_NCHW = 0, R3D_FMT_CB8 = 1, R3D_FMT_SPLIT = 2, R3D_FMT_SPLIT_MX = 3 };
 size_t r3d_sr_block_prepacked_bytes(int Cin, int Cout);
 size_t r3d_sr_block_styles_bytes(int N, int Cin, int Cout);
 size_t r3d_sr_block_workspace_bytes(int N, int Cin, int Cout, int Hin, int Win);

@@ -537,8 +537,9 @@ using namespace r3d;
 
 extern "C" size_t r3d_sr_block_prepacked_bytes(int Cin, int Cout)
 {
-    // conv0 (plain layout) + conv1 + conv0 again in the fused up-conv layout (f16x3) + the two per-cout weight-row tails
-    return ((size_t)2 * 9 * Cin * Cout + (size_t)9 * Cout * Cout + 2 * conv_tail_layout(Cout).total) * sizeof(float);
+    // conv0 (plain layout) + conv1 + conv0 again in the fused up-conv layout (f16x3) + the two per-cout weight-row tails + conv0 in the
+    // up-conv layout with fp8 records (R3D_SR_F16MX, inputs in R3D_FMT_SPLIT_MX)
+    return ((size_t)3 * 9 * Cin * Cout + (size_t)9 * Cout * Cout + 2 * conv_tail_layout(Cout).total) * sizeof(float);
 }
 
 extern "C" size_t r3d_sr_block_styles_bytes(int N, int Cin, int Cout)
@@ -650,9 +651,11 @@ extern "C" int r3d_sr_block_forward(const void* prepacked, const void* styles, i
     }
     if (!x_out) x_out_format = R3D_FMT_NONE;
     const bool f16 = precision != R3D_SR_F32;
-    if (x_format < R3D_FMT_NCHW || x_format > R3D_FMT_SPLIT || x_out_format < R3D_FMT_NONE || x_out_format > R3D_FMT_SPLIT ||
-        (!f16 && (x_format == R3D_FMT_SPLIT || x_out_format == R3D_FMT_SPLIT)) ||
-        (x_out_format == R3D_FMT_SPLIT && !next_scale)) {
+    const bool mxp = precision == R3D_SR_F16MX;
+    if (x_format < R3D_FMT_NCHW || x_format > R3D_FMT_SPLIT_MX || x_out_format < R3D_FMT_NONE || x_out_format > R3D_FMT_SPLIT_MX ||
+        (!f16 && (x_format >= R3D_FMT_SPLIT || x_out_format >= R3D_FMT_SPLIT)) ||
+        ((x_format == R3D_FMT_SPLIT_MX || x_out_format == R3D_FMT_SPLIT_MX) && (!mxp || !up)) ||
+        (x_out_format >= R3D_FMT_SPLIT && !next_scale)) {
         set_error("sr_block_forward: unsupported activation format (x %d, x_out %d, precision %d)", x_format, x_out_format, precision);
         return R3D_ERR_INVALID_ARG;
     }

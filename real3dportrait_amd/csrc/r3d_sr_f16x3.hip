@@ -230,6 +230,7 @@ struct Conv2Args {
     float* y_f32; size_t y_f32_stride_n; int OH, OW;       // fp32 CB8 output (T buffer / x_out) or null
     float* y_nchw; size_t y_nchw_stride_n;                 // fp32 NCHW output or null
     uint4* y_split; size_t y_split_stride_n;               // SPLIT output scaled by next_scale (null = 1), or null
+    int y_split_mx;                                        // 1: the lo plane of y_split holds fp8 records (R3D_FMT_SPLIT_MX) for an f16mx consumer
     const float* next_scale; size_t next_scale_stride_n;
     unsigned* y_absmax;                                    // [N] max |activated output| (uint bits of a non-negative float) or null
     const float* wrgb; size_t wrgb_stride_n; float* rgb_partial; size_t rgbp_stride_n;   // toRGB partials [Cout/128][3][OH*OW] or null
@@ -344,11 +345,28 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
                 }
                 if (Ys) {
                     h4 hi, lo;
+                    float lf[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { _Float16 x0, x1; split1_folded(v[r] * sv[r], x0, x1); hi[r] = x0; lo[r] = x1; }
+                    for (int r = 0; r < 4; ++r) {
+                        const float sv_ = as_rounded(v[r] * sv[r]);
+                        const _Float16 x0 = (_Float16)sv_;
+                        lf[r] = sv_ - (float)x0;
+                        hi[r] = x0; lo[r] = (_Float16)lf[r];
+                    }
                     uint2* dst = reinterpret_cast<uint2*>(Ys + pix) + h;
                     dst[0] = *reinterpret_cast<uint2*>(&hi);
-                    dst[2 * oplane] = *reinterpret_cast<uint2*>(&lo);
+                    if (a.y_split_mx) {
+                        // fp8 records in place of the lo words (see "f16mx" at the top): lo chunk 2G <- xh8, 2G+1 <- xl8 of the 16 channels of
+                        // group G; this lane's 4 couts are bytes [8 (chunk & 1) + 4 h, +4) of both records
+                        const unsigned xh8 = pack4_fp8((float)hi[0] * kMxXh, (float)hi[1] * kMxXh, (float)hi[2] * kMxXh, (float)hi[3] * kMxXh);
+                        const unsigned xl8 = pack4_fp8(lf[0] * kMxXl, lf[1] * kMxXl, lf[2] * kMxXl, lf[3] * kMxXl);
+                        const unsigned c8 = (unsigned)(m0 + cu) >> 3;
+                        unsigned* rec = reinterpret_cast<unsigned*>(Ys + oplane + (size_t)((c8 & ~1u) * cs + p0[nt]));
+                        rec[2 * (c8 & 1u) + h] = xh8;
+                        rec[(size_t)4 * cs + 2 * (c8 & 1u) + h] = xl8;
+                    } else {
+                        dst[2 * oplane] = *reinterpret_cast<uint2*>(&lo);
+                    }
                 }
             }
         }
@@ -898,7 +916,8 @@ static constexpr int U_WSTAGE = 9 * 2 * 2 * 32;                     // uint4 per
 static constexpr int U_PW = 17, U_PPLANE = 320;                     // patch: 17x17 pixels per (plane, chunk), padded to 5 x 64 slots
 static constexpr int U_PATCH = 4 * U_PPLANE;                        // uint4: [hi|lo][chunk][320]
 static constexpr int U_STAGE = U_PATCH + U_WSTAGE;                  // 2432 uint4 per stage buffer
-static constexpr int U_LDS_UINT4 = 2 * U_STAGE;                     // double-buffered: 77.8 KB (epilogue slice: 2048 uint4)
+static constexpr int U_LDS_UINT4 = 2 * U_STAGE + 2;                 // double-buffered: 77.8 KB (epilogue slice: 2048 uint4) + a 32-byte zero record (MXIN)
+static constexpr int U_ZERO = 2 * U_STAGE;                          // the zero A record of the unpaired centre tap's second K half
 
 
 struct UpArgs {
@@ -931,6 +950,44 @@ __global__ void sr_prepack_up_kernel(const float* __restrict__ w, int Cin, int C
     out[e] = *reinterpret_cast<uint4*>(&v8);
 }
 
+// The same layout for an input that arrives as R3D_FMT_SPLIT_MX (upconv_fir_f16x3_kernel<.., .., MXIN = true>): the hi rows are unchanged, the
+// "lo" row of chunk 0 holds wl8 = fp8(lo * 2^8) of the stage's 16 channels, the "lo" row of chunk 1 their wh8 = fp8(hi * 2^-3) -- the A
+// record [wl8 | wh8] of a (tap, cout) is rows 1 and 3 of that tap's four 32-cout rows.
+__global__ void sr_prepack_up_mx_kernel(const float* __restrict__ w, int Cin, int Cout, const float* __restrict__ winv, uint4* __restrict__ out)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t total = (size_t)9 * (Cin / 8) * Cout * 2;
+    if (e >= total) return;
+    const int co = e & 31, hl = (e >> 5) & 1, hc = (e >> 6) & 1;
+    const int t = (int)((e >> 7) % 9);
+    const size_t r = (e >> 7) / 9;
+    const int nst = Cin / 16;
+    const int st = (int)(r % nst), cg = (int)(r / nst);
+    const int cout = cg * 32 + co;
+    const float ws = 1.0f / winv[cout];
+    if (!hl) {
+        h8 v8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { _Float16 a, b; split1(w[((size_t)cout * Cin + st * 16 + hc * 8 + j) * 9 + t] * ws, a, b); v8[j] = a; }
+        out[e] = *reinterpret_cast<uint4*>(&v8);
+        return;
+    }
+    uint4 rec;
+    unsigned* pr = reinterpret_cast<unsigned*>(&rec);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float f[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float v = w[((size_t)cout * Cin + st * 16 + 4 * q + j) * 9 + t] * ws;
+            _Float16 a, b; split1(v, a, b);
+            f[j] = hc ? (float)a * kMxWh : (v - (float)a) * kMxWl;
+        }
+        pr[q] = pack4_fp8(f[0], f[1], f[2], f[3]);
+    }
+    out[e] = rec;
+}
+
 // MX = true (R3D_SR_F16MX): the output feeds the f16mx 3x3 conv: hi plane as usual, and in place of the fp16 lo words the fp8 records
 // (lo chunk 2G <- xh8 of channels 16G..16G+15, lo chunk 2G+1 <- xl8): slice g (8 couts) owns bytes [8 (g & 1), +8) of both words.
 #if defined(R3D_ABLATE) && (R3D_ABLATE & 512)            // experiment build: per-block s_memtime stamps (scripts/gpu_up_stamps.py)
@@ -939,7 +996,11 @@ __device__ unsigned long long g_up_stamps[8 * 4096];
 #else
 #define UP_STAMP(i, v) do { } while (0)
 #endif
-template <bool CLAMP, bool MX = false>
+// MXIN = true: the input is R3D_FMT_SPLIT_MX (hi plane + fp8 records, written by the MX epilogue of the previous block's conv1) and the
+// main loop spends, per 16-channel stage and N tile, 9 f16 MFMAs (hi * hi) + 5 fp8 K = 64 MFMAs -- the cross products of the tap pairs
+// (0,2) (6,8) -> phase 0, (1,7) -> phase 1, (3,5) -> phase 2 and of the centre tap 4 (phase 3, its second K half reads a zero record) --
+// instead of 27 f16 MFMAs: 608 instead of 864 matrix cycles.  Lane half h <-> the pair's tap h, as in conv3x3_dma_block<.., MX>.
+template <bool CLAMP, bool MX = false, bool MXIN = false>
 __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
 {
     __shared__ uint4 lds[U_LDS_UINT4];
@@ -983,6 +1044,18 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) boff[nt] = (row0 + nt * 2 + prow + 1) * U_PW + (pcol + 1) + h * U_PPLANE;
     const int aoff = U_PATCH + h * 64 + li;
+    // MXIN: per-lane slots of the fp8 operands.  B record of (pixel, tap_h) = the lo-plane words of chunk 0 (xh8) and chunk 1 (xl8) at the
+    // tap's window shift: pairs (0,2) (3,5) differ by one column, (1,7) by one row, (6,8) = one row up and one column.  A record of
+    // (cout, tap_h) = rows 1 and 3 of the tap: taps of a pair are 2 or 6 taps apart.
+    int b8c[2], b8r[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int pix = (row0 + nt * 2 + prow + 1) * U_PW + (pcol + 1) + 2 * U_PPLANE;
+        b8c[nt] = pix - h; b8r[nt] = pix - h * U_PW;
+    }
+    const int a8d2 = U_PATCH + 32 + li + h * 256, a8d6 = U_PATCH + 32 + li + h * 768;
+    const int a8c = U_PATCH + 32 + li + 4 * 128;                   // centre tap: lanes h = 1 read the zero record instead
+    if (MXIN && tid < 2) lds[U_ZERO + tid] = make_uint4(0, 0, 0, 0);
 
     // patch DMA: wave w fills segment sg = 4k + w (k = 0..4) of the 20 x 64-slot patch image; slot idx = (sg % 5) * 64 + lane of
     // (plane, chunk) = sg / 5 holds patch pixel (idx / 17, idx % 17) <-> input (i0 - 2 + py, j0 - 2 + px); slots outside the
@@ -1028,6 +1101,45 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
 #endif
         const uint4* cur = lds + (st & 1) * U_STAGE;
         if (st + 1 < nst) dma_stage(st + 1, lds + ((st + 1) & 1) * U_STAGE);
+        if constexpr (MXIN) {
+            // hi * hi on the f16 pipe, window by window (the B window is read once for its 4 / 2 / 2 / 1 taps)
+#pragma unroll
+            for (int win = 0; win < 4; ++win) {
+                const int sy = win >> 1, sx = win & 1;
+                const int toff = -(sy * U_PW + sx);
+                h8 bh[2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) { uint4 r0 = cur[boff[nt] + toff]; bh[nt] = *reinterpret_cast<h8*>(&r0); }
+#pragma unroll
+                for (int ky = 2 * sy; ky <= (sy ? 2 : 1); ++ky)
+#pragma unroll
+                    for (int kx = 2 * sx; kx <= (sx ? 2 : 1); ++kx) {
+                        const int t = ky * 3 + kx, p = (ky & 1) * 2 + (kx & 1);
+                        uint4 q0 = cur[t * 128 + aoff];
+                        const h8 ah = *reinterpret_cast<h8*>(&q0);
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[nt], acc[p][nt], 0, 0, 0);
+                    }
+            }
+            // the cross products: one K = 64 fp8 MFMA per tap pair and N tile
+            auto mx_pair = [&](const int p, const int a0, const int a1, const int b_off, const int* bsel) {      // a0 / a1: absolute LDS slots of [wl8] / [wh8]
+                const uint4 q0 = lds[a0], q1 = lds[a1];
+                const i8v a8 = (i8v){(int)q0.x, (int)q0.y, (int)q0.z, (int)q0.w, (int)q1.x, (int)q1.y, (int)q1.z, (int)q1.w};
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const uint4 r0 = cur[bsel[nt] + b_off], r1 = cur[bsel[nt] + b_off + U_PPLANE];
+                    const i8v b8 = (i8v){(int)r0.x, (int)r0.y, (int)r0.z, (int)r0.w, (int)r1.x, (int)r1.y, (int)r1.z, (int)r1.w};
+                    acc[p][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[p][nt], 0, 0, 0, kMxScaleA, 0, kMxScaleB);
+                }
+            };
+            const int cb = (st & 1) * U_STAGE;
+            mx_pair(0, cb + a8d2 + 0 * 128, cb + a8d2 + 0 * 128 + 64, 0, b8c);        // taps (0, 2): windows (0,0) / (0,1)
+            mx_pair(0, cb + a8d2 + 6 * 128, cb + a8d2 + 6 * 128 + 64, -U_PW, b8c);    // taps (6, 8): windows (1,0) / (1,1)
+            mx_pair(1, cb + a8d6 + 1 * 128, cb + a8d6 + 1 * 128 + 64, 0, b8r);        // taps (1, 7): windows (0,0) / (1,0)
+            mx_pair(2, cb + a8d2 + 3 * 128, cb + a8d2 + 3 * 128 + 64, 0, b8c);        // taps (3, 5): windows (0,0) / (0,1)
+            mx_pair(3, h ? U_ZERO : cb + a8c, h ? U_ZERO + 1 : cb + a8c + 64, 0, b8c); // tap 4 alone: zero A record for the K half h = 1 (whatever B it meets)
+            continue;
+        }
 #pragma unroll
         for (int win = 0; win < 4; ++win) {                         // input shift (sy, sx): x(i - sy, j - sx)
             const int sy = win >> 1, sx = win & 1;
@@ -1456,7 +1568,8 @@ int upsample2x_bilinear_f16x3(const float* x_cb8, int N, int C, int H, int W, vo
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------
-// prepacked = conv0 (plain layout) ++ conv1 ++ conv0 (fused up-conv layout) ++ ConvTail(conv0) ++ ConvTail(conv1)
+// prepacked = conv0 (plain layout) ++ conv1 ++ conv0 (fused up-conv layout) ++ ConvTail(conv0) ++ ConvTail(conv1) ++ conv0 (up-conv layout
+// with fp8 records, for R3D_FMT_SPLIT_MX inputs; written for R3D_SR_F16MX only)
 int sr_prepack_f16x3(int Cin, int Cout, const float* c0_w, const float* c1_w, void* prepacked, hipStream_t st, bool mx)
 {
     float* out = reinterpret_cast<float*>(prepacked);
@@ -1478,6 +1591,9 @@ int sr_prepack_f16x3(int Cin, int Cout, const float* c0_w, const float* c1_w, vo
     const size_t mu = (size_t)9 * (Cin / 8) * Cout * 2;
     hipLaunchKernelGGL(sr_prepack_up_kernel, dim3((unsigned)((mu + 255) / 256)), dim3(256), 0, st, c0_w, Cin, Cout, tail0 + T.winv,
                        reinterpret_cast<uint4*>(out + (size_t)9 * Cin * Cout + (size_t)9 * Cout * Cout));
+    if (mx)
+        hipLaunchKernelGGL(sr_prepack_up_mx_kernel, dim3((unsigned)((mu + 255) / 256)), dim3(256), 0, st, c0_w, Cin, Cout, tail0 + T.winv,
+                           reinterpret_cast<uint4*>(tail1 + T.total));
     return check_launch("sr_block_prepack");
 }
 
@@ -1535,7 +1651,8 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
     float* rgbp = reinterpret_cast<float*>(wsb + align256((size_t)N * Cout * 4 * Hin * Win * 4));
 
     const uint4* xs = reinterpret_cast<const uint4*>(x);
-    if (x_format != R3D_FMT_SPLIT) {
+    const bool mx_in = x_format == R3D_FMT_SPLIT_MX;          // (validated by the caller: up = 1, R3D_SR_F16MX)
+    if (x_format != R3D_FMT_SPLIT && !mx_in) {
         ProfScope ps(R3D_PROF_LAYOUT, st);
         hipLaunchKernelGGL(to_split_kernel, dim3((Hin * Win + 255) / 256, Cin / 8, N), dim3(256), 0, st,
                            reinterpret_cast<const float*>(x), x_format == R3D_FMT_CB8 ? 1 : 0, pk + L.s0f, L.total, xin, Cin, Cin, Hin * Win);
@@ -1547,6 +1664,7 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
         UpArgs u = {};
         u.x = xs; u.x_stride_n = (size_t)Cin / 8 * Hin * Win * 2;
         u.wp = reinterpret_cast<const uint4*>(wpk + (size_t)9 * Cin * Cout + (size_t)9 * Cout * Cout);
+        if (mx_in) u.wp = reinterpret_cast<const uint4*>(wpk + (size_t)2 * 9 * Cin * Cout + (size_t)9 * Cout * Cout + 2 * conv_tail_layout(Cout).total);
         u.out_scale = pk + L.d0f; u.bias = pk + L.b0; u.next_scale = pk + L.s1f; u.vec_stride_n = L.total;
         u.y = y0; u.y_stride_n = (size_t)Cout / 8 * OH * OW * 2;
         u.Cin = Cin; u.Cout = Cout; u.H = Hin; u.W = Win;
@@ -1556,7 +1674,9 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
         u.clamp = clamp;
         ProfScope ps(R3D_PROF_UPCONV, st);
         const dim3 ugrid(8 * u.tiles_per_xcd * (Cout / 32), N);
-        if (mx && clamp >= 0.f) hipLaunchKernelGGL((upconv_fir_f16x3_kernel<true, true>), ugrid, dim3(256), 0, st, u);
+        if (mx_in && clamp >= 0.f) hipLaunchKernelGGL((upconv_fir_f16x3_kernel<true, true, true>), ugrid, dim3(256), 0, st, u);
+        else if (mx_in) hipLaunchKernelGGL((upconv_fir_f16x3_kernel<false, true, true>), ugrid, dim3(256), 0, st, u);
+        else if (mx && clamp >= 0.f) hipLaunchKernelGGL((upconv_fir_f16x3_kernel<true, true>), ugrid, dim3(256), 0, st, u);
         else if (mx) hipLaunchKernelGGL((upconv_fir_f16x3_kernel<false, true>), ugrid, dim3(256), 0, st, u);
         else if (clamp >= 0.f) hipLaunchKernelGGL(upconv_fir_f16x3_kernel<true>, ugrid, dim3(256), 0, st, u);
         else hipLaunchKernelGGL(upconv_fir_f16x3_kernel<false>, ugrid, dim3(256), lds_pad(), st, u);
@@ -1605,9 +1725,10 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
         a.OH = OH; a.OW = OW;
         if (x_out && x_out_format == R3D_FMT_CB8) { a.y_f32 = reinterpret_cast<float*>(x_out); a.y_f32_stride_n = (size_t)Cout * OH * OW; }
         if (x_out && x_out_format == R3D_FMT_NCHW) { a.y_nchw = reinterpret_cast<float*>(x_out); a.y_nchw_stride_n = (size_t)Cout * OH * OW; }
-        if (x_out && x_out_format == R3D_FMT_SPLIT) {
+        if (x_out && (x_out_format == R3D_FMT_SPLIT || x_out_format == R3D_FMT_SPLIT_MX)) {
             a.y_split = reinterpret_cast<uint4*>(x_out); a.y_split_stride_n = (size_t)Cout / 8 * OH * OW * 2;
             a.next_scale = next_scale; a.next_scale_stride_n = next_scale_stride;
+            a.y_split_mx = x_out_format == R3D_FMT_SPLIT_MX ? 1 : 0;
         }
         a.y_absmax = reinterpret_cast<unsigned*>(x_absmax);
         a.wrgb = pk + L.wrgb; a.wrgb_stride_n = L.total; a.rgb_partial = rgbp; a.rgbp_stride_n = (size_t)(Cout / 64) * 3 * OH * OW;

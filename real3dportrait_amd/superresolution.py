@@ -85,6 +85,7 @@ def const_bound(value, N, device):
 # ask for THROUGHPUT_SR_PRECISION by name; R3D_SR_PRECISION overrides both for a process.  DESIGN 4.2c states the tiers.
 DEFAULT_SR_PRECISION = "f16x3"
 THROUGHPUT_SR_PRECISION = "f16mx"
+_MX_UPCONV = os.environ.get("R3D_MX_UPCONV", "1") != "0"      # A/B switch: 0 = f16mx keeps block1's up-sampling conv on the 3-term fp16 split
 
 
 def set_sr_precision(module, precision):
@@ -235,7 +236,7 @@ class SynthesisBlock(nn.Module):
             setattr(self, name, t)
         return t
 
-    _FMT = {"none": -1, "nchw": 0, "cb8": 1, "split": 2}
+    _FMT = {"none": -1, "nchw": 0, "cb8": 1, "split": 2, "split_mx": 3}      # split_mx: SPLIT with fp8 records in the lo plane (f16mx hand-off between up blocks)
     _PREC = {"f32": 0, "f16x3": 1, "f16mx": 2}
 
     def _prec(self):
@@ -308,7 +309,7 @@ class SynthesisBlock(nn.Module):
         if img is None:
             raise NotImplementedError("img=None (first block of a synthesis network) is not on the SR path")
         x_fmt = getattr(x, "_r3d_fmt", "nchw")
-        if x_fmt == "split":
+        if x_fmt in ("split", "split_mx"):
             if getattr(x, "_r3d_for", None) is not self:
                 raise RuntimeError("SPLIT activation was scaled for a different consumer")
             _folded = True
@@ -335,8 +336,9 @@ class SynthesisBlock(nn.Module):
         next_scale, next_stride = None, 0
         if out_fmt == "none":
             x_out = None
-        elif out_fmt == "split":
+        elif out_fmt in ("split", "split_mx"):
             assert _next is not None, "out_format='split' needs the consumer (its folded in-multiplier)"
+            assert out_fmt == "split" or (prec == 2 and _next._prec() == 2 and _next._UP), "split_mx is the hand-off between two f16mx up blocks"
             next_scale, next_stride = _next.in_scale()
             x_out = torch.empty(N, 2, Cout // 8, OH, OW, 8, device=dev, dtype=torch.float16)
         elif out_fmt == "cb8":
@@ -350,7 +352,7 @@ class SynthesisBlock(nn.Module):
         if x_out is not None:
             if out_fmt != "nchw":
                 x_out._r3d_fmt = out_fmt
-            if out_fmt == "split":
+            if out_fmt in ("split", "split_mx"):
                 x_out._r3d_for = _next
             elif prec >= 1:
                 _tag(x_out, self.bound_out(N), self._depth_in + 2)
@@ -772,7 +774,8 @@ class SuperresolutionHybrid8XDC(nn.Module):
         ws3, prep0, prep1, x_absmax = self._prepare_and_fold(ws, N, dev, bx, dx)
         mx = b0.precision == "f16mx"
         if b0.precision in ("f16x3", "f16mx"):
-            b0.out_format, nxt = "split", b1
+            # f16mx: block0's conv1 epilogue leaves fp8 records in the lo plane and block1's up-sampling conv runs its cross products on them
+            b0.out_format, nxt = ("split_mx" if mx and _MX_UPCONV else "split"), b1
         else:
             b0.out_format, nxt = "cb8", None
         x, rgb = b0(x, rgb, ws3, _prepared=prep0, _next=nxt, _folded=True, _x_absmax=x_absmax, **block_kwargs)
