@@ -250,7 +250,8 @@ int r3d_absmax(const float* x, size_t count_per_sample, int N, float* out, float
  *   x / y formats as for the SR blocks; blocked formats (CB8, SPLIT) need Cin % 16 == 0 / Cout % 8 == 0, NCHW takes
  *   any Cin (zero padded to 16 inside).  A SPLIT x must have been written with this layer's in-multiplier (the start of
  *   `scales`); a SPLIT y is multiplied by next_scale = the CONSUMER's in-multiplier vector (start of its scales / styles
- *   buffer, already folded), NULL = 1.
+ *   buffer, already folded), NULL = 1.  y_format = R3D_FMT_SPLIT_MX (Cout % 16 == 0): a SPLIT y whose lo plane holds the fp8 records
+ *   an R3D_SR_F16MX SynthesisBlock reads when it takes y as x (x_format = R3D_FMT_SPLIT_MX there).
  *   workspace (r3d_conv_workspace_bytes) is only used for non-SPLIT inputs. */
 size_t r3d_conv_prepacked_bytes(int Cin, int Cout, int ksize);
 size_t r3d_conv_workspace_bytes(int N, int Cin, int H, int W);

@@ -816,7 +816,8 @@ extern "C" int r3d_conv_forward(const void* prepacked, const void* scales, const
     if (!prepacked || !scales || !x || !y || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (ksize != 1 && ksize != 3)) {
         set_error("conv_forward: bad argument"); return R3D_ERR_INVALID_ARG;
     }
-    if (x_format < R3D_FMT_NCHW || x_format > R3D_FMT_SPLIT || y_format < R3D_FMT_NCHW || y_format > R3D_FMT_SPLIT) {
+    if (x_format < R3D_FMT_NCHW || x_format > R3D_FMT_SPLIT || y_format < R3D_FMT_NCHW || y_format > R3D_FMT_SPLIT_MX ||
+        (y_format == R3D_FMT_SPLIT_MX && (Cout & 15))) {           // (SPLIT_MX out: fp8 records for an f16mx SR block that consumes y; 16-channel groups)
         set_error("conv_forward: unsupported activation format (x %d, y %d)", x_format, y_format); return R3D_ERR_INVALID_ARG;
     }
     if (Cout & 3) { set_error("conv_forward: Cout = %d must be a multiple of 4", Cout); return R3D_ERR_INVALID_ARG; }

@@ -1800,7 +1800,8 @@ int conv_forward_f16x3(const void* prepacked, const float* scales, size_t scales
     a.OH = H; a.OW = W;
     if (y_format == R3D_FMT_CB8) { a.y_f32 = reinterpret_cast<float*>(y); a.y_f32_stride_n = (size_t)Cout * H * W; }
     else if (y_format == R3D_FMT_NCHW) { a.y_nchw = reinterpret_cast<float*>(y); a.y_nchw_stride_n = (size_t)Cout * H * W; }
-    else { a.y_split = reinterpret_cast<uint4*>(y); a.y_split_stride_n = (size_t)Cout / 8 * H * W * 2; a.next_scale = next_scale; a.next_scale_stride_n = next_scale_stride; }
+    else { a.y_split = reinterpret_cast<uint4*>(y); a.y_split_stride_n = (size_t)Cout / 8 * H * W * 2; a.next_scale = next_scale; a.next_scale_stride_n = next_scale_stride;
+           a.y_split_mx = y_format == R3D_FMT_SPLIT_MX ? 1 : 0; }
     a.y_absmax = reinterpret_cast<unsigned*>(y_absmax);
     a.Cin = Ci; a.Cout = Co; a.CoutReal = Cout; a.H = H; a.W = W; a.nphase = 1;
     a.act = act; a.act_slope = slope; a.act_gain = gain; a.clamp = clamp;

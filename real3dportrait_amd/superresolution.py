@@ -457,7 +457,7 @@ class Conv2d(nn.Module):
         need = int(lib.r3d_conv_workspace_bytes(N, Cin, H, W))
         work = self._buf("_workspace", need, dev) if x_fmt != "split" else None
         next_scale, next_stride = None, 0
-        if out_format == "split":
+        if out_format in ("split", "split_mx"):      # split_mx: fp8 records in the lo plane, for an f16mx SynthesisBlock that consumes y
             assert _next is not None, "out_format='split' needs the consumer (its folded in-multiplier)"
             next_scale, next_stride = _next.in_scale()
             y = torch.empty(N, 2, Cout // 8, H, W, 8, device=dev, dtype=torch.float16)
@@ -472,7 +472,7 @@ class Conv2d(nn.Module):
                                         _lib.ptr(work), need if work is not None else 0, st), "conv_forward")
         if out_format != "nchw":
             y._r3d_fmt = out_format
-        if out_format == "split":
+        if out_format in ("split", "split_mx"):
             y._r3d_for = _next
         else:
             _tag(y, self.bound_out(N), self._depth_in + 1)
