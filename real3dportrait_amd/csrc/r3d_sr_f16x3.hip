@@ -1194,14 +1194,16 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
     const float* NS = a.next_scale + (size_t)n * a.vec_stride_n + co0;
     const int OH = 2 * a.H, OW = 2 * a.W;
     const size_t oplane = (size_t)(a.Cout >> 3) * OH * OW;
-    const float c0 = 0.25f, c1 = 0.75f;                             // [1,3,3,1]/8 * 2 per axis (gain 4 in 2-D)
     // all per-cout vectors of the four slices in one batch of loads, waited for ONCE here: loaded inside the slice loop,
     // hipcc re-waited with s_waitcnt vmcnt(0) in front of every conditional store group (loads and stores share vmcnt), which
     // serialised the epilogue on store latency
+    // (round 4: the FIR runs UNNORMALISED -- taps (1, 3, 3, 1) per axis instead of (1, 3, 3, 1) / 4 -- on the raw accumulators, and the
+    // demodulation d[co] / 16 is one factor of the fma that adds the bias in the vertical pass: two multiplies per T value and one per H
+    // value less, and the horizontal pass is 3 instead of 4 operations per output.  The epilogue is VALU-issue bound)
     float4 dv4[4], bv4[4], nv4[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        dv4[g] = *reinterpret_cast<const float4*>(D + 8 * g + 4 * h);
+        dv4[g] = *reinterpret_cast<const float4*>(D + 8 * g + 4 * (tid & 1));
         bv4[g] = *reinterpret_cast<const float4*>(Bv + 8 * g + 4 * (tid & 1));
         nv4[g] = *reinterpret_cast<const float4*>(NS + 8 * g + 4 * (tid & 1));
     }
@@ -1216,9 +1218,8 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         float4* hls = hls0 + (g & 1) * 2048;
-        const float dv[4] = {dv4[g].x, dv4[g].y, dv4[g].z, dv4[g].w};
         // horizontal pass of this slice: (T[pa][pb=0], T[pa][pb=1]) at this lane's grid point -> (H column 2X, H column 2X+1)
-        //   T column 2X+1+cc = phase (cc+1)&1 at grid column X + (cc+1)/2;  H(dx) = (T[dx] + T[dx+3]) c0 + (T[dx+1] + T[dx+2]) c1
+        //   T column 2X+1+cc = phase (cc+1)&1 at grid column X + (cc+1)/2;  4 H(dx) = (T[dx] + T[dx+3]) + 3 (T[dx+1] + T[dx+2])
 #pragma unroll
         for (int pa = 0; pa < 2; ++pa)
 #pragma unroll
@@ -1226,15 +1227,17 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
                 float hx[2][4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float t0 = acc[2 * pa][nt][4 * g + r] * dv[r], t1 = acc[2 * pa + 1][nt][4 * g + r] * dv[r];
+                    const float t0 = acc[2 * pa][nt][4 * g + r], t1 = acc[2 * pa + 1][nt][4 * g + r];
                     // lane i <- lane (i + 1) % 16 / (i + 2) % 16 of its 16-lane row: row_ror:15 = 0x12F, row_ror:14 = 0x12E (a rotation has no
-                    // invalid source lane: mov_dpp with bound_ctrl, no `old` operand to initialise -- update_dpp(0, ...) cost one v_mov per DPP)
+                    // invalid source lane: mov_dpp with bound_ctrl, which hipcc folds into the consuming v_add / v_fmac as a DPP operand)
+                    const float ts = t0 + t1;                                        // (t0 + t1) one column on = t0p1 + t1p1: one rotation for both
+                    const float tsp1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, ts), 0x12F, 0xF, 0xF, true));
                     const float t0p1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t0), 0x12F, 0xF, 0xF, true));
                     const float t1p1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t1), 0x12F, 0xF, 0xF, true));
                     const float t0p2 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t0), 0x12E, 0xF, 0xF, true));
                     const float t1p2 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, t1), 0x12E, 0xF, 0xF, true));
-                    hx[0][r] = (t1 + t0p2) * c0 + (t0p1 + t1p1) * c1;
-                    hx[1][r] = (t0p1 + t1p2) * c0 + (t1p1 + t0p2) * c1;
+                    hx[0][r] = __builtin_fmaf(tsp1, 3.0f, t1 + t0p2);
+                    hx[1][r] = __builtin_fmaf(t1p1 + t0p2, 3.0f, t0p1 + t1p2);
                 }
                 const int gy = row0 + nt * 2 + prow;
 #pragma unroll
@@ -1243,8 +1246,9 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
             }
         __syncthreads();                                            // (buffer g & 1 was last read by slice g - 2's vertical pass: done before barrier g - 1)
         {   // vertical: item (row pair rp, column oc, half): H rows 2rp+1 .. 2rp+5 -> y rows 2rp, 2rp+1 (4 couts each)
-            const float4 b4 = bv4[g], n4 = nv4[g];
+            const float4 b4 = bv4[g], n4 = nv4[g], d4 = dv4[g];
             const f2 ba = f2{b4.x, b4.y}, bb = f2{b4.z, b4.w};
+            const f2 da = f2{d4.x, d4.y} * 0.0625f, db = f2{d4.z, d4.w} * 0.0625f;      // demodulation / 16 (the two unnormalised FIR passes)
             const float m = 1.4142135623730951f;
             const f2 ma = f2{n4.x, n4.y} * m, mb = f2{n4.z, n4.w} * m;
             uint4* d = a.y + (size_t)n * a.y_stride_n + (size_t)((co0 >> 3) + g) * OH * OW;
@@ -1262,8 +1266,8 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
                 }
 #pragma unroll
                 for (int dy = 0; dy < 2; ++dy) {
-                    f2 va = ba + (ha[dy] + ha[dy + 3]) * c0 + (ha[dy + 1] + ha[dy + 2]) * c1;
-                    f2 vb = bb + (hb[dy] + hb[dy + 3]) * c0 + (hb[dy + 1] + hb[dy + 2]) * c1;
+                    f2 va = ((ha[dy] + ha[dy + 3]) + (ha[dy + 1] + ha[dy + 2]) * 3.0f) * da + ba;
+                    f2 vb = ((hb[dy] + hb[dy + 3]) + (hb[dy + 1] + hb[dy + 2]) * 3.0f) * db + bb;
                     va = __builtin_elementwise_max(va, va * 0.2f);  // leaky relu (slope 0.2); sqrt(2) gain is inside ma/mb
                     vb = __builtin_elementwise_max(vb, vb * 0.2f);
                     if constexpr (CLAMP) {                          // conv_clamp acts on the gained activation
