@@ -23,9 +23,6 @@
 #include "r3d_stamps.h"
 
 namespace r3d {
-#ifdef R3D_STAMPS
-__device__ unsigned long long g_stamps[32];
-#endif
 
 static constexpr int kC = R3D_FEATURES;      // 32
 static constexpr int kHid = R3D_HIDDEN;      // 64
@@ -1458,15 +1455,7 @@ static void launch_render_tri(const RenderArgs& a, int R, int grid, hipStream_t 
 
 using namespace r3d;
 
-#ifdef R3D_STAMPS
-// experiment builds: out[0..30] = summed cycles per phase over all waves, out[31] = units (rays); clears the table
-extern "C" int r3d_debug_stamps(unsigned long long* host)
-{
-    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 32) != hipSuccess) return -1;
-    unsigned long long z[32] = {};
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) == hipSuccess ? 0 : -1;
-}
-#endif
+R3D_STAMP_READER(r3d_debug_stamps)
 
 // number of per-block |max| partials r3d_planes_to_nhwc writes for this shape (the same kernel choice as below)
 static inline bool nhwc32_fast_path(const void* a, const void* b, const void* c, int C, int HW, int depth, int add_flip)

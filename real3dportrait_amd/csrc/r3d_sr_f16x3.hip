@@ -25,6 +25,7 @@
 #include <stdlib.h>
 
 #include "r3d_sr_common.h"
+#include "r3d_stamps.h"
 
 namespace r3d {
 
@@ -721,8 +722,10 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
     };
 
     // prologue: patch(0) and the first weight sub-stage
+    R3D_STAMP_DECL;
     dma_weights2(0, wbuf);
     dma_patch(0, pbuf);
+    R3D_STAMP(4);
     for (int sp = 0; sp < nst; sp += 2) {
 #pragma unroll
         for (int uu = 0; uu < 9; ++uu) {
@@ -761,11 +764,7 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
                     for (int mt = 0; mt < 2; ++mt) {
                         uint4 q0 = curW[ts * 512 + aoff + mt * 32];
                         ah[mt] = *reinterpret_cast<h8*>(&q0);
-#if defined(R3D_ABLATE) && (R3D_ABLATE & 2048)          // experiment build (wrong results): half the operand reads from LDS, same MFMAs
-                        if (!MX) al[mt] = ah[mt];
-#else
                         if (!MX) { uint4 q1 = curW[ts * 512 + aoff + mt * 32 + 128]; al[mt] = *reinterpret_cast<h8*>(&q1); }
-#endif
                     }
 #if R3D_TAPS_CT & 1
                     const int toff = (t / 3 - 1) * F_PATCH_W + (t % 3 - 1);       // the plain 3x3 taps (sr_fill_conv3x3_phase): compile-time LDS offsets
@@ -777,23 +776,14 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
                         uint4 r0 = curP[boff[nt] + toff];
                         const h8 bh = *reinterpret_cast<h8*>(&r0);
                         h8 bl;
-#if defined(R3D_ABLATE) && (R3D_ABLATE & 2048)
-                        if (!MX) bl = bh;
-#else
                         if (!MX) { uint4 r1 = curP[boff[nt] + toff + 2 * PATCH_PIX]; bl = *reinterpret_cast<h8*>(&r1); }
-#endif
 #pragma unroll
                         for (int mt = 0; mt < 2; ++mt) {
-#if defined(R3D_ABLATE) && (R3D_ABLATE & 1)     // experiment build: operands are still read (kept alive), no MFMAs
-                            asm volatile("" :: "v"(bh), "v"(ah[mt]));
-                            if (!MX) asm volatile("" :: "v"(bl), "v"(al[mt]));
-#else
                             if (!MX) {
                                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh, acc[mt][nt], 0, 0, 0);
                                 acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl, acc[mt][nt], 0, 0, 0);
                             }
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh, acc[mt][nt], 0, 0, 0);
-#endif
                         }
                     }
                 }
@@ -832,11 +822,7 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
                     const i8v b8 = (i8v){(int)r0.x, (int)r0.y, (int)r0.z, (int)r0.w, (int)r1.x, (int)r1.y, (int)r1.z, (int)r1.w};
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
-#if defined(R3D_ABLATE) && (R3D_ABLATE & 4)     // experiment build: no fp8 MFMAs
-                        asm volatile("" :: "v"(a8[mt]), "v"(b8));
-#else
                         acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[mt], b8, acc[mt][nt], 0, 0, 0, kMxScaleA, 0, kMxScaleB);
-#endif
                     }
                 }
 #if !R3D_MX_FREE_SCHED
@@ -846,11 +832,14 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
         }
     }
     __syncthreads();
-#if defined(R3D_ABLATE) && (R3D_ABLATE & 2)             // experiment build: no epilogue (the store keeps the accumulators alive)
-    if (acc[0][0][0] == 123.456f) a.rgb_partial[0] = acc[1][1][3] + acc[0][1][5] + acc[1][0][9];
-    return;
-#endif
+    R3D_STAMP(5);
     conv_epilogue<FULL_EPI, WN, NT>(a, ph, n, acc, i0, j0, m0, reinterpret_cast<float*>(lds));
+    R3D_STAMP(6);
+#ifdef R3D_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    R3D_STAMP(7);
+    if ((threadIdx.x & 63) == 0) { for (int i_ = 4; i_ < 8; ++i_) atomicAdd(&r3d::g_stamps[8 + i_], st_acc_[i_]); atomicAdd(&r3d::g_stamps[30], 1ull); }
+#endif
 }
 
 static constexpr int F_LDS_UINT4 = 2 * 2 * F_PATCH_PIX + 2 * 3 * 2 * 256;      // patch (20.7 KB) + 2 x 3-tap weight sub-stage (2 x 24.6 KB)
@@ -990,29 +979,21 @@ __global__ void sr_prepack_up_mx_kernel(const float* __restrict__ w, int Cin, in
 
 // MX = true (R3D_SR_F16MX): the output feeds the f16mx 3x3 conv: hi plane as usual, and in place of the fp16 lo words the fp8 records
 // (lo chunk 2G <- xh8 of channels 16G..16G+15, lo chunk 2G+1 <- xl8): slice g (8 couts) owns bytes [8 (g & 1), +8) of both words.
-#if defined(R3D_ABLATE) && (R3D_ABLATE & 512)            // experiment build: per-block s_memtime stamps (scripts/gpu_up_stamps.py)
-__device__ unsigned long long g_up_stamps[8 * 4096];
-#define UP_STAMP(i, v) do { if (threadIdx.x == 0 && blockIdx.x < 4096) g_up_stamps[8 * blockIdx.x + (i)] = (v); } while (0)
-#else
-#define UP_STAMP(i, v) do { } while (0)
-#endif
 // MXIN = true: the input is R3D_FMT_SPLIT_MX (hi plane + fp8 records, written by the MX epilogue of the previous block's conv1) and the
 // main loop spends, per 16-channel stage and N tile, 9 f16 MFMAs (hi * hi) + 5 fp8 K = 64 MFMAs -- the cross products of the tap pairs
 // (0,2) (6,8) -> phase 0, (1,7) -> phase 1, (3,5) -> phase 2 and of the centre tap 4 (phase 3, its second K half reads a zero record) --
 // instead of 27 f16 MFMAs: 608 instead of 864 matrix cycles.  Lane half h <-> the pair's tap h, as in conv3x3_dma_block<.., MX>.
-template <bool CLAMP, bool MX = false, bool MXIN = false>
-__global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
+// NW = waves per block: 4 (two N tiles = 128 accumulator registers per wave, 2 waves per SIMD: the shape of the MFMA-bound layers) or
+// 8 (one N tile, 64 accumulators, ~110 VGPRs: 4 waves per SIMD at the same 2 blocks per CU) for layers with a handful of K stages --
+// block0.conv0 (Cin = 32: two stages) is ALL epilogue, and the epilogue's dependent LDS -> VALU -> store chains ran at 30 % of the VALU
+// rate with two waves per SIMD (round 4: 39.8 -> see DESIGN 4.2).  Same tile, same K order per output: bit-identical results.
+template <bool CLAMP, bool MX = false, bool MXIN = false, int NW = 4>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void upconv_fir_f16x3_kernel(UpArgs a)
 {
+    constexpr int NTL = 8 / NW;                                     // N tiles (2 grid rows x 16 columns) per wave
+    constexpr int NTHR = 64 * NW;
+    R3D_STAMP_DECL;
     __shared__ uint4 lds[U_LDS_UINT4];
-#if defined(R3D_ABLATE) && (R3D_ABLATE & 512)
-    const unsigned long long st_t0 = clock64(); unsigned long long st_wait = 0, st_first = 0;
-#endif
-#if defined(R3D_ABLATE) && (R3D_ABLATE & 1024)           // experiment build: the second block of every CU starts half a main loop late
-    if ((((blockIdx.x >> 3) >> 5) & 1) && (blockIdx.x >> 3) < 64) {
-#pragma unroll 1
-        for (int i = 0; i < R3D_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
-    }
-#endif
     const int G = a.Cout >> 5;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;         // the cout groups of one tile share an XCD (one L2)
     const int tl = slot / G, cg = slot - tl * G;
@@ -1028,28 +1009,28 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
     const size_t plane = (size_t)(a.Cin >> 3) * chunk_stride;
     const uint4* X = a.x + (size_t)n * a.x_stride_n;
 
-    f32x16 acc[4][2];
+    f32x16 acc[4][NTL];
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NTL; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[p][nt][r] = 0.f;
 
     // grid point of this lane in N tile nt: row 4*wave + 2*nt + prow, col pcol (odd rows rotated by the row stride mod 16:
     // every ds_read_b128 lane group then covers 16 distinct 16-byte slots)
     const int prow = li >> 4, pcol = ((li & 15) - prow) & 15;
-    const int row0 = wave * 4;
-    int boff[2];
+    const int row0 = wave * 2 * NTL;
+    int boff[NTL];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) boff[nt] = (row0 + nt * 2 + prow + 1) * U_PW + (pcol + 1) + h * U_PPLANE;
+    for (int nt = 0; nt < NTL; ++nt) boff[nt] = (row0 + nt * 2 + prow + 1) * U_PW + (pcol + 1) + h * U_PPLANE;
     const int aoff = U_PATCH + h * 64 + li;
     // MXIN: per-lane slots of the fp8 operands.  B record of (pixel, tap_h) = the lo-plane words of chunk 0 (xh8) and chunk 1 (xl8) at the
     // tap's window shift: pairs (0,2) (3,5) differ by one column, (1,7) by one row, (6,8) = one row up and one column.  A record of
     // (cout, tap_h) = rows 1 and 3 of the tap: taps of a pair are 2 or 6 taps apart.
-    int b8c[2], b8r[2];
+    int b8c[NTL], b8r[NTL];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int nt = 0; nt < NTL; ++nt) {
         const int pix = (row0 + nt * 2 + prow + 1) * U_PW + (pcol + 1) + 2 * U_PPLANE;
         b8c[nt] = pix - h; b8r[nt] = pix - h * U_PW;
     }
@@ -1061,15 +1042,17 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
     // (plane, chunk) = sg / 5 holds patch pixel (idx / 17, idx % 17) <-> input (i0 - 2 + py, j0 - 2 + px); slots outside the
     // image / beyond 289 read the zero block
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    unsigned pf_off[5];
+    constexpr int PK = (20 + NW - 1) / NW;                          // patch DMA rounds: 20 segments of 64 slots over NW waves
+    constexpr int WKF = 18 / NW, WKR = 18 - WKF * NW;               // weight DMA: 18 segments = WKF full rounds + WKR waves of a last one
+    unsigned pf_off[PK];
     unsigned pf_valid = 0;
 #pragma unroll
-    for (int k = 0; k < 5; ++k) {
-        const int sg = 4 * k + wave_u, pc = sg / 5, idx = (sg - pc * 5) * 64 + lane;
+    for (int k = 0; k < PK; ++k) {
+        const int sg = NW * k + wave_u, pc = sg / 5, idx = (sg - pc * 5) * 64 + lane;
         const int py = idx / U_PW, px = idx - py * U_PW;
         const int iy = i0 - 2 + py, ix = j0 - 2 + px;
         unsigned off = 0;
-        if (idx < U_PW * U_PW && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+        if (sg < 20 && idx < U_PW * U_PW && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
             off = (unsigned)((pc >> 1) * plane) + (unsigned)((pc & 1) * chunk_stride + iy * a.W + ix);
             pf_valid |= 1u << k;
         }
@@ -1077,28 +1060,25 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
     }
     const uint4* WP = a.wp + (size_t)cg * nst * U_WSTAGE;
     auto dma_stage = [&](int st, uint4* buf) {
-        const uint4* src = WP + (size_t)st * U_WSTAGE + tid;        // weights: 1152 uint4, linear: 4.5 rounds of 256 lanes
+        const uint4* src = WP + (size_t)st * U_WSTAGE + tid;        // weights: 1152 uint4, linear: 18 segments of 64 lanes
 #pragma unroll
-        for (int k = 0; k < 5; ++k)
-            if (k < 4 || wave_u < 2) dma64(src + 256 * k, buf + U_PATCH + 256 * k + 64 * wave_u);
+        for (int k = 0; k <= WKF; ++k)
+            if (k < WKF || wave_u < WKR) dma64(src + NTHR * k, buf + U_PATCH + NTHR * k + 64 * wave_u);
         const uint4* Xs = X + (size_t)(2 * st) * chunk_stride;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const uint4* g = (pf_valid & (1u << k)) ? Xs + pf_off[k] : g_zero16;
-            dma64(g, buf + 64 * (4 * k + wave_u));
+        for (int k = 0; k < PK; ++k) {
+            if (NW * k + wave_u < 20) {
+                const uint4* g = (pf_valid & (1u << k)) ? Xs + pf_off[k] : g_zero16;
+                dma64(g, buf + 64 * (NW * k + wave_u));
+            }
         }
     };
     dma_stage(0, lds);
+    R3D_STAMP(0);
     for (int st = 0; st < nst; ++st) {
-#if defined(R3D_ABLATE) && (R3D_ABLATE & 512)
-        const unsigned long long st_a = clock64();
-#endif
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // this stage's DMAs (issued one stage ago) have landed; this wave's LDS reads too (see conv3x3_dma_block)
         __builtin_amdgcn_s_barrier();                               // ... everybody's; and the other buffer's readers are done
         asm volatile("" ::: "memory");
-#if defined(R3D_ABLATE) && (R3D_ABLATE & 512)
-        { const unsigned long long d = clock64() - st_a; st_wait += d; if (st == 0) st_first = d; }
-#endif
         const uint4* cur = lds + (st & 1) * U_STAGE;
         if (st + 1 < nst) dma_stage(st + 1, lds + ((st + 1) & 1) * U_STAGE);
         if constexpr (MXIN) {
@@ -1107,9 +1087,9 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
             for (int win = 0; win < 4; ++win) {
                 const int sy = win >> 1, sx = win & 1;
                 const int toff = -(sy * U_PW + sx);
-                h8 bh[2];
+                h8 bh[NTL];
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) { uint4 r0 = cur[boff[nt] + toff]; bh[nt] = *reinterpret_cast<h8*>(&r0); }
+                for (int nt = 0; nt < NTL; ++nt) { uint4 r0 = cur[boff[nt] + toff]; bh[nt] = *reinterpret_cast<h8*>(&r0); }
 #pragma unroll
                 for (int ky = 2 * sy; ky <= (sy ? 2 : 1); ++ky)
 #pragma unroll
@@ -1118,7 +1098,7 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
                         uint4 q0 = cur[t * 128 + aoff];
                         const h8 ah = *reinterpret_cast<h8*>(&q0);
 #pragma unroll
-                        for (int nt = 0; nt < 2; ++nt) acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[nt], acc[p][nt], 0, 0, 0);
+                        for (int nt = 0; nt < NTL; ++nt) acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[nt], acc[p][nt], 0, 0, 0);
                     }
             }
             // the cross products: one K = 64 fp8 MFMA per tap pair and N tile
@@ -1126,7 +1106,7 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
                 const uint4 q0 = lds[a0], q1 = lds[a1];
                 const i8v a8 = (i8v){(int)q0.x, (int)q0.y, (int)q0.z, (int)q0.w, (int)q1.x, (int)q1.y, (int)q1.z, (int)q1.w};
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
+                for (int nt = 0; nt < NTL; ++nt) {
                     const uint4 r0 = cur[bsel[nt] + b_off], r1 = cur[bsel[nt] + b_off + U_PPLANE];
                     const i8v b8 = (i8v){(int)r0.x, (int)r0.y, (int)r0.z, (int)r0.w, (int)r1.x, (int)r1.y, (int)r1.z, (int)r1.w};
                     acc[p][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[p][nt], 0, 0, 0, kMxScaleA, 0, kMxScaleB);
@@ -1144,9 +1124,9 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
         for (int win = 0; win < 4; ++win) {                         // input shift (sy, sx): x(i - sy, j - sx)
             const int sy = win >> 1, sx = win & 1;
             const int toff = -(sy * U_PW + sx);
-            h8 bh[2], bl[2];
+            h8 bh[NTL], bl[NTL];
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
+            for (int nt = 0; nt < NTL; ++nt) {
                 uint4 r0 = cur[boff[nt] + toff];
                 uint4 r1 = cur[boff[nt] + toff + 2 * U_PPLANE];
                 bh[nt] = *reinterpret_cast<h8*>(&r0); bl[nt] = *reinterpret_cast<h8*>(&r1);
@@ -1159,14 +1139,10 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
                     uint4 q0 = cur[t * 128 + aoff], q1 = cur[t * 128 + aoff + 32];
                     const h8 ah = *reinterpret_cast<h8*>(&q0), al = *reinterpret_cast<h8*>(&q1);
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-#if defined(R3D_ABLATE) && (R3D_ABLATE & 32)             // experiment build: operands read, no MFMAs
-                        asm volatile("" :: "v"(al), "v"(ah), "v"(bh[nt]), "v"(bl[nt]));
-#else
+                    for (int nt = 0; nt < NTL; ++nt) {
                         acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[nt], acc[p][nt], 0, 0, 0);
                         acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[nt], acc[p][nt], 0, 0, 0);
                         acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[nt], acc[p][nt], 0, 0, 0);
-#endif
                     }
                 }
         }
@@ -1179,9 +1155,7 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
     // accumulator layout (lane = pixel), so the neighbours arrive by row rotations (v_mov_dpp row_ror:15 / :14; the rotation also covers
     // the odd rows, whose columns are stored rotated by one lane).  Round 1 wrote T to LDS and ran the pass LDS -> LDS: 56 b128 LDS
     // operations per thread and slice, now 28 -- the ablations of round 2 had the epilogue at 56 % of this kernel.
-#if defined(R3D_ABLATE) && (R3D_ABLATE & 512)
-    const unsigned long long st_t1 = clock64();
-#endif
+    R3D_STAMP(1);
     typedef float f2 __attribute__((ext_vector_type(2)));
     typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
     // (Round 3 tried an XOR swizzle of the H columns against the write pattern's even-slot stride and a software pipeline of the four slices
@@ -1210,10 +1184,6 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
 #pragma unroll
     for (int g = 0; g < 4; ++g)
         asm volatile("" :: "v"(dv4[g].x), "v"(dv4[g].w), "v"(bv4[g].x), "v"(bv4[g].w), "v"(nv4[g].x), "v"(nv4[g].w));
-#if defined(R3D_ABLATE) && (R3D_ABLATE & 8)              // experiment build: no epilogue
-    if (acc[0][0][0] == 123.456f) a.y[0] = make_uint4(__float_as_uint(acc[1][1][3] + acc[2][0][5] + acc[3][1][9]), 0, 0, 0);
-    return;
-#endif
     __syncthreads();                                                // the main loop's LDS reads are done
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -1223,7 +1193,7 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
 #pragma unroll
         for (int pa = 0; pa < 2; ++pa)
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
+            for (int nt = 0; nt < NTL; ++nt) {
                 float hx[2][4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -1253,8 +1223,8 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
             const f2 ma = f2{n4.x, n4.y} * m, mb = f2{n4.z, n4.w} * m;
             uint4* d = a.y + (size_t)n * a.y_stride_n + (size_t)((co0 >> 3) + g) * OH * OW;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int q = tid + 256 * k;
+            for (int k = 0; k < 1024 / NTHR; ++k) {
+                const int q = tid + NTHR * k;
                 const int half = q & 1, oc = (q >> 1) & 31, rp = q >> 6;
                 const bool live = rp < U_TILE && oc < 2 * U_TILE;
                 f2 ha[5], hb[5];
@@ -1285,10 +1255,6 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
                     // hi word and of the lo word (a wave store covers 32 pixels x 16 contiguous bytes per plane)
                     const uint2 hw = make_uint2(*reinterpret_cast<const unsigned*>(&hia), *reinterpret_cast<const unsigned*>(&hib));
                     const int oy = 2 * (i0 + rp) + dy, ox = 2 * j0 + oc;
-#if defined(R3D_ABLATE) && (R3D_ABLATE & 16)             // experiment build: the epilogue computes everything but stores nothing
-                    if (hw.x == 0x12345678u && oy >= 0) a.y[0] = make_uint4(hw.x, hw.y, 0, 0);
-                    continue;
-#endif
                     if constexpr (MX) {
                         const f2 fha = __builtin_convertvector(hia, f2), fhb = __builtin_convertvector(hib, f2);
                         const f2 fla = va - fha, flb = vb - fhb;
@@ -1314,22 +1280,14 @@ __global__ __launch_bounds__(256, 2) void upconv_fir_f16x3_kernel(UpArgs a)
             }
         }
     }
-#if defined(R3D_ABLATE) && (R3D_ABLATE & 512)
-    {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long st_t2 = clock64();
-        UP_STAMP(0, st_t0); UP_STAMP(1, st_first); UP_STAMP(2, st_wait); UP_STAMP(3, st_t1 - st_t0); UP_STAMP(4, st_t2 - st_t0);
-        UP_STAMP(5, (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)));   // HW_ID
-        UP_STAMP(6, (unsigned long long)wall_clock64());
-    }
+    R3D_STAMP(2);
+#ifdef R3D_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    R3D_STAMP(3);
+    R3D_STAMP_FLUSH(4, 1);
 #endif
 }
-#if defined(R3D_ABLATE) && (R3D_ABLATE & 512)
-extern "C" int r3d_debug_up_stamps(unsigned long long* host, int nblocks)
-{
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_up_stamps), sizeof(unsigned long long) * 8 * (size_t)nblocks);
-}
-#endif
+R3D_STAMP_READER(r3d_debug_stamps_sr)
 
 // ---- FIR 4x4 (gain 4, pad 1) + bias + lrelu*sqrt2 on the transposed-conv output; writes SPLIT scaled by the next
 // conv's styles.  T is PHASE-MAJOR: T[p=(r&1)*2+(c&1)][C/8][Hin+1][Win+1][8] holds row r, col c of the (2Hin+1)x(2Win+1)
@@ -1678,8 +1636,15 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
         u.clamp = clamp;
         ProfScope ps(R3D_PROF_UPCONV, st);
         const dim3 ugrid(8 * u.tiles_per_xcd * (Cout / 32), N);
+        // (NW = 8 -- one N tile per wave, 4 waves per SIMD -- was built for block0.conv0, the all-epilogue launch, and measured NEUTRAL in
+        // round 4 (0.173 vs 0.169-0.177 ms per frame for the family, bit-identical results), as was a first-round stagger of the CU's second
+        // block: that launch is bound by the LDS-DMA fill rate of its two K stages and by the VALU work of its epilogue one after the other,
+        // not by latency.  The instantiation stays available behind R3D_UPCONV_NW8=1 for experiments.)
+        static const int up8 = getenv("R3D_UPCONV_NW8") ? atoi(getenv("R3D_UPCONV_NW8")) : 0;
+        const bool nw8 = up8 && Cin <= 64 && !mx_in && !mx && clamp < 0.f;
         if (mx_in && clamp >= 0.f) hipLaunchKernelGGL((upconv_fir_f16x3_kernel<true, true, true>), ugrid, dim3(256), 0, st, u);
         else if (mx_in) hipLaunchKernelGGL((upconv_fir_f16x3_kernel<false, true, true>), ugrid, dim3(256), 0, st, u);
+        else if (nw8) hipLaunchKernelGGL((upconv_fir_f16x3_kernel<false, false, false, 8>), ugrid, dim3(512), 0, st, u);
         else if (mx && clamp >= 0.f) hipLaunchKernelGGL((upconv_fir_f16x3_kernel<true, true>), ugrid, dim3(256), 0, st, u);
         else if (mx) hipLaunchKernelGGL((upconv_fir_f16x3_kernel<false, true>), ugrid, dim3(256), 0, st, u);
         else if (clamp >= 0.f) hipLaunchKernelGGL(upconv_fir_f16x3_kernel<true>, ugrid, dim3(256), 0, st, u);
