@@ -251,7 +251,9 @@ int r3d_absmax(const float* x, size_t count_per_sample, int N, float* out, float
  *   any Cin (zero padded to 16 inside).  A SPLIT x must have been written with this layer's in-multiplier (the start of
  *   `scales`); a SPLIT y is multiplied by next_scale = the CONSUMER's in-multiplier vector (start of its scales / styles
  *   buffer, already folded), NULL = 1.  y_format = R3D_FMT_SPLIT_MX (Cout % 16 == 0): a SPLIT y whose lo plane holds the fp8 records
- *   an R3D_SR_F16MX SynthesisBlock reads when it takes y as x (x_format = R3D_FMT_SPLIT_MX there).
+ *   the consumer's f16mx main loop reads (an R3D_SR_F16MX SynthesisBlock[NoUp], or the next r3d_conv_forward called with
+ *   x_format = R3D_FMT_SPLIT_MX).  x_format = R3D_FMT_SPLIT_MX (ksize 3, Cin % 16 == 0): this conv's cross products run on the
+ *   block-scaled fp8 MFMA (precision tier of R3D_SR_F16MX); r3d_conv_prepack writes both weight layouts, the input format selects.
  *   workspace (r3d_conv_workspace_bytes) is only used for non-SPLIT inputs. */
 size_t r3d_conv_prepacked_bytes(int Cin, int Cout, int ksize);
 size_t r3d_conv_workspace_bytes(int N, int Cin, int H, int W);
@@ -267,10 +269,11 @@ int r3d_conv_forward(const void* prepacked, const void* scales, const float* bia
  *   y = cat([a * mask, b * (1 - mask)], dim=1),  a [N,Ca,H,W], b [N,Cb,H,W] (NCHW or CB8 fp32), mask [N,1,H,W]
  * replaces `torch.cat([x * head_torso_alpha, x_torso * (1 - head_torso_alpha)], dim=1)` and the person_occlusion / x_bg
  * twin in SuperresolutionHybrid8XDC_Warp.forward (modules/real3d/super_resolution/sr_with_ref.py:104,114,126,136).
- * y_split: [N][hi|lo][(Ca+Cb)/8][H][W][8] halfs, multiplied by next_scale ([N][Ca+Cb], the consumer's in-multiplier; NULL = 1).
+ * y_split: [N][hi|lo][(Ca+Cb)/8][H][W][8] halfs, multiplied by next_scale ([N][Ca+Cb], the consumer's in-multiplier; NULL = 1);
+ * y_format R3D_FMT_SPLIT, or R3D_FMT_SPLIT_MX (fp8 records in the lo plane) when the consumer runs the f16mx main loop (since 0.4.0).
  * Ca % 8 == Cb % 8 == 0, (Ca + Cb) % 16 == 0. */
 int r3d_blend_cat_to_split(const float* a, int a_format, int Ca, const float* b, int b_format, int Cb, const float* mask,
-                           int N, int H, int W, void* y_split, const float* next_scale, size_t next_scale_stride,
+                           int N, int H, int W, void* y_split, int y_format, const float* next_scale, size_t next_scale_stride,
                            r3d_stream_t stream);
 
 /* torch.nn.UpsamplingBilinear2d(scale_factor=2) (align_corners=True), the resampling step inside to_plane_cnn

@@ -22,7 +22,7 @@ SIGNATURES = {
     "r3d_last_error": (ctypes.c_char_p, []),
     "r3d_planes_to_nhwc": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, ctypes.POINTER(c_int), P]),
     "r3d_planes_absmax_partials": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
-    "r3d_blend_cat_to_split": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, P, P, c_size_t, P]),
+    "r3d_blend_cat_to_split": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, P, c_int, P, c_size_t, P]),
     "r3d_upsample2x_bilinear": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P, c_size_t, P]),
     "r3d_raygen": (c_int, [P, P, c_int, c_int, P, P, P]),
     "r3d_render_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),

@@ -137,7 +137,7 @@ __global__ void person_occlusion_kernel(const float* __restrict__ alpha, const f
 
 using namespace r3d;
 
-extern "C" int r3d_version(void) { return 30; }   // 0.3.0: decoder range fold (plane_absmax arguments), packed-f32 op_sel rewrite in the build
+extern "C" int r3d_version(void) { return 40; }   // 0.4.0: R3D_FMT_SPLIT_MX (f16mx on the up-sampling conv, SynthesisBlockNoUp and the plain 3x3 convs), r3d_blend_cat_to_split y_format
 
 extern "C" int r3d_resize_bilinear(const float* x, int planes, int H, int W, float* y, int OH, int OW, int antialias, r3d_stream_t stream)
 {

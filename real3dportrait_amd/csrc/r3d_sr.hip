@@ -537,9 +537,9 @@ using namespace r3d;
 
 extern "C" size_t r3d_sr_block_prepacked_bytes(int Cin, int Cout)
 {
-    // conv0 (plain layout) + conv1 + conv0 again in the fused up-conv layout (f16x3) + the two per-cout weight-row tails + conv0 in the
-    // up-conv layout with fp8 records (R3D_SR_F16MX, inputs in R3D_FMT_SPLIT_MX)
-    return ((size_t)3 * 9 * Cin * Cout + (size_t)9 * Cout * Cout + 2 * conv_tail_layout(Cout).total) * sizeof(float);
+    // conv0 (plain layout) + conv1 + conv0 again in the fused up-conv layout (f16x3) + the two per-cout weight-row tails + conv0 with fp8
+    // records in the up-conv layout and in the plain layout (R3D_SR_F16MX: SynthesisBlock / SynthesisBlockNoUp on R3D_FMT_SPLIT_MX inputs)
+    return ((size_t)4 * 9 * Cin * Cout + (size_t)9 * Cout * Cout + 2 * conv_tail_layout(Cout).total) * sizeof(float);
 }
 
 extern "C" size_t r3d_sr_block_styles_bytes(int N, int Cin, int Cout)
@@ -636,7 +636,6 @@ extern "C" int r3d_sr_block_forward(const void* prepacked, const void* styles, i
                                     void* workspace, size_t workspace_bytes, r3d_stream_t stream)
 {
     if (precision < R3D_SR_F32 || precision > R3D_SR_F16MX) { set_error("sr_block_forward: unknown precision %d", precision); return R3D_ERR_INVALID_ARG; }
-    if (precision == R3D_SR_F16MX && !up) { set_error("sr_block_forward: R3D_SR_F16MX covers up=1 blocks (SynthesisBlockNoUp: use R3D_SR_F16X3)"); return R3D_ERR_UNSUPPORTED; }
     if ((img_u8 || x_absmax) && precision == R3D_SR_F32) { set_error("sr_block_forward: the fused uint8 output / x_absmax need R3D_SR_F16X3"); return R3D_ERR_INVALID_ARG; }
     if (!prepacked || !styles || !x || !img || (!img_out && !img_u8) || N <= 0 || Hin <= 0 || Win <= 0 || (Cin & 15) || (Cout % BLOCK_M) || (up != 0 && up != 1)) {
         set_error("sr_block_forward: bad argument"); return R3D_ERR_INVALID_ARG;
@@ -654,7 +653,7 @@ extern "C" int r3d_sr_block_forward(const void* prepacked, const void* styles, i
     const bool mxp = precision == R3D_SR_F16MX;
     if (x_format < R3D_FMT_NCHW || x_format > R3D_FMT_SPLIT_MX || x_out_format < R3D_FMT_NONE || x_out_format > R3D_FMT_SPLIT_MX ||
         (!f16 && (x_format >= R3D_FMT_SPLIT || x_out_format >= R3D_FMT_SPLIT)) ||
-        ((x_format == R3D_FMT_SPLIT_MX || x_out_format == R3D_FMT_SPLIT_MX) && (!mxp || !up)) ||
+        ((x_format == R3D_FMT_SPLIT_MX || x_out_format == R3D_FMT_SPLIT_MX) && !mxp) ||
         (x_out_format >= R3D_FMT_SPLIT && !next_scale)) {
         set_error("sr_block_forward: unsupported activation format (x %d, x_out %d, precision %d)", x_format, x_out_format, precision);
         return R3D_ERR_INVALID_ARG;
@@ -816,8 +815,8 @@ extern "C" int r3d_conv_forward(const void* prepacked, const void* scales, const
     if (!prepacked || !scales || !x || !y || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || (ksize != 1 && ksize != 3)) {
         set_error("conv_forward: bad argument"); return R3D_ERR_INVALID_ARG;
     }
-    if (x_format < R3D_FMT_NCHW || x_format > R3D_FMT_SPLIT || y_format < R3D_FMT_NCHW || y_format > R3D_FMT_SPLIT_MX ||
-        (y_format == R3D_FMT_SPLIT_MX && (Cout & 15))) {           // (SPLIT_MX out: fp8 records for an f16mx SR block that consumes y; 16-channel groups)
+    if (x_format < R3D_FMT_NCHW || x_format > R3D_FMT_SPLIT_MX || y_format < R3D_FMT_NCHW || y_format > R3D_FMT_SPLIT_MX ||
+        (y_format == R3D_FMT_SPLIT_MX && (Cout & 15)) || (x_format == R3D_FMT_SPLIT_MX && (ksize != 3 || (Cin & 15)))) {           // (SPLIT_MX out: fp8 records for an f16mx SR block that consumes y; 16-channel groups)
         set_error("conv_forward: unsupported activation format (x %d, y %d)", x_format, y_format); return R3D_ERR_INVALID_ARG;
     }
     if (Cout & 3) { set_error("conv_forward: Cout = %d must be a multiple of 4", Cout); return R3D_ERR_INVALID_ARG; }
@@ -828,7 +827,7 @@ extern "C" int r3d_conv_forward(const void* prepacked, const void* scales, const
     if ((x_format != R3D_FMT_NCHW && (Cin & 15)) || (y_format != R3D_FMT_NCHW && (Cout & 7))) {
         set_error("conv_forward: blocked formats need Cin %% 16 == 0 and Cout %% 8 == 0 (Cin %d, Cout %d)", Cin, Cout); return R3D_ERR_INVALID_ARG;
     }
-    if (x_format != R3D_FMT_SPLIT && (!workspace || workspace_bytes < r3d_conv_workspace_bytes(N, Cin, H, W))) {
+    if (x_format < R3D_FMT_SPLIT && (!workspace || workspace_bytes < r3d_conv_workspace_bytes(N, Cin, H, W))) {
         set_error("conv_forward: workspace too small"); return R3D_ERR_WORKSPACE;
     }
     const size_t stride = conv_scales_layout((Cin + 15) / 16 * 16, (Cout + BLOCK_M - 1) / BLOCK_M * BLOCK_M).total;
@@ -847,9 +846,10 @@ extern "C" int r3d_upsample2x_bilinear(const float* x_cb8, int N, int C, int H, 
 }
 
 extern "C" int r3d_blend_cat_to_split(const float* a, int a_format, int Ca, const float* b, int b_format, int Cb, const float* mask,
-                                      int N, int H, int W, void* y_split, const float* next_scale, size_t next_scale_stride,
+                                      int N, int H, int W, void* y_split, int y_format, const float* next_scale, size_t next_scale_stride,
                                       r3d_stream_t stream)
 {
+    if (y_format != R3D_FMT_SPLIT && y_format != R3D_FMT_SPLIT_MX) { set_error("blend_cat_to_split: y_format %d must be SPLIT or SPLIT_MX", y_format); return R3D_ERR_INVALID_ARG; }
     using namespace r3d;
     if (!a || !b || !mask || !y_split || N <= 0 || H <= 0 || W <= 0 || Ca <= 0 || Cb <= 0 || (Ca & 7) || (Cb & 7) || ((Ca + Cb) & 15)) {
         set_error("blend_cat_to_split: bad argument (Ca %d, Cb %d: multiples of 8, sum a multiple of 16)", Ca, Cb); return R3D_ERR_INVALID_ARG;
@@ -857,5 +857,5 @@ extern "C" int r3d_blend_cat_to_split(const float* a, int a_format, int Ca, cons
     if ((a_format != R3D_FMT_NCHW && a_format != R3D_FMT_CB8) || (b_format != R3D_FMT_NCHW && b_format != R3D_FMT_CB8)) {
         set_error("blend_cat_to_split: inputs must be NCHW or CB8 (a %d, b %d)", a_format, b_format); return R3D_ERR_INVALID_ARG;
     }
-    return blend_cat_to_split_f16x3(a, a_format, Ca, b, b_format, Cb, mask, N, H, W, y_split, next_scale, next_scale_stride, (hipStream_t)stream);
+    return blend_cat_to_split_f16x3(a, a_format, Ca, b, b_format, Cb, mask, N, H, W, y_split, y_format, next_scale, next_scale_stride, (hipStream_t)stream);
 }

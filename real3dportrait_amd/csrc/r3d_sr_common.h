@@ -115,6 +115,6 @@ int upsample2x_bilinear_f16x3(const float* x_cb8, int N, int C, int H, int W, vo
                               const float* next_scale, size_t next_scale_stride, hipStream_t st);
 
 int blend_cat_to_split_f16x3(const float* a, int a_format, int Ca, const float* b, int b_format, int Cb, const float* mask,
-                             int N, int H, int W, void* y_split, const float* next_scale, size_t next_scale_stride, hipStream_t st);
+                             int N, int H, int W, void* y_split, int y_format, const float* next_scale, size_t next_scale_stride, hipStream_t st);
 
 }  // namespace r3d

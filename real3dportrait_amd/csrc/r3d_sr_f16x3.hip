@@ -1428,9 +1428,11 @@ __global__ void cb8_to_nchw2_kernel(const float* __restrict__ src, float* __rest
 // SuperresolutionHybrid8XDC_Warp.forward (modules/real3d/super_resolution/sr_with_ref.py:104,114,126,136), written
 // directly in the SPLIT format of fuse_head_torso_convs / fuse_fg_bg_convs' first conv (no fp32 concat tensor).
 // blockIdx.y < Ca/8: channels of a (scaled by m); else channels of b (scaled by 1 - m).
+// mx: the lo plane receives the fp8 records of R3D_FMT_SPLIT_MX (lo chunk 2G <- xh8 of the 16 channels of group G, lo chunk 2G + 1 <- xl8;
+// this thread's 8-channel chunk is half (cb & 1) of both records)
 __global__ void blend_cat_to_split_kernel(const float* __restrict__ a, int a_cb8, int Ca, const float* __restrict__ b, int b_cb8, int Cb,
                                           const float* __restrict__ mask, uint4* __restrict__ dst, int HW,
-                                          const float* __restrict__ next_scale, size_t next_scale_stride_n)
+                                          const float* __restrict__ next_scale, size_t next_scale_stride_n, int mx)
 {
     const int n = blockIdx.z, cb = blockIdx.y;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1451,24 +1453,33 @@ __global__ void blend_cat_to_split_kernel(const float* __restrict__ a, int a_cb8
         for (int c = 0; c < 8; ++c) v[c] = s1[(size_t)c * HW];
     }
     h8 hi, lo;
+    float hf[8], lf[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const float ns = next_scale ? next_scale[n * next_scale_stride_n + cb * 8 + c] : 1.f;   // consumer's input multiplier (2^e)
-        _Float16 x0, x1; split1(v[c] * sc * ns, x0, x1); hi[c] = x0; lo[c] = x1;
+        const float t = as_rounded(v[c] * sc * ns);
+        const float cl = fminf(fmaxf(t, -65504.f), 65504.f);
+        hi[c] = (_Float16)cl; hf[c] = (float)hi[c]; lf[c] = t - hf[c]; lo[c] = (_Float16)lf[c];
     }
     const size_t plane = (size_t)((Ca + Cb) / 8) * HW;
     uint4* d = dst + (size_t)n * 2 * plane + (size_t)cb * HW + p;
     d[0] = *reinterpret_cast<uint4*>(&hi);
-    d[plane] = *reinterpret_cast<uint4*>(&lo);
+    if (mx) {
+        uint2* rec = reinterpret_cast<uint2*>(dst + (size_t)n * 2 * plane + plane + (size_t)(cb & ~1) * HW + p) + (cb & 1);
+        rec[0] = make_uint2(pack4_fp8(hf[0] * kMxXh, hf[1] * kMxXh, hf[2] * kMxXh, hf[3] * kMxXh), pack4_fp8(hf[4] * kMxXh, hf[5] * kMxXh, hf[6] * kMxXh, hf[7] * kMxXh));
+        rec[2 * (size_t)HW] = make_uint2(pack4_fp8(lf[0] * kMxXl, lf[1] * kMxXl, lf[2] * kMxXl, lf[3] * kMxXl), pack4_fp8(lf[4] * kMxXl, lf[5] * kMxXl, lf[6] * kMxXl, lf[7] * kMxXl));
+    } else {
+        d[plane] = *reinterpret_cast<uint4*>(&lo);
+    }
 }
 
 int blend_cat_to_split_f16x3(const float* a, int a_format, int Ca, const float* b, int b_format, int Cb, const float* mask,
-                             int N, int H, int W, void* y_split, const float* next_scale, size_t next_scale_stride, hipStream_t st)
+                             int N, int H, int W, void* y_split, int y_format, const float* next_scale, size_t next_scale_stride, hipStream_t st)
 {
     ProfScope ps(R3D_PROF_LAYOUT, st);
     hipLaunchKernelGGL(blend_cat_to_split_kernel, dim3((H * W + 255) / 256, (Ca + Cb) / 8, N), dim3(256), 0, st,
                        a, a_format == R3D_FMT_CB8 ? 1 : 0, Ca, b, b_format == R3D_FMT_CB8 ? 1 : 0, Cb, mask,
-                       reinterpret_cast<uint4*>(y_split), H * W, next_scale, next_scale_stride);
+                       reinterpret_cast<uint4*>(y_split), H * W, next_scale, next_scale_stride, y_format == R3D_FMT_SPLIT_MX ? 1 : 0);
     return check_launch("blend_cat_to_split");
 }
 
@@ -1553,9 +1564,13 @@ int sr_prepack_f16x3(int Cin, int Cout, const float* c0_w, const float* c1_w, vo
     const size_t mu = (size_t)9 * (Cin / 8) * Cout * 2;
     hipLaunchKernelGGL(sr_prepack_up_kernel, dim3((unsigned)((mu + 255) / 256)), dim3(256), 0, st, c0_w, Cin, Cout, tail0 + T.winv,
                        reinterpret_cast<uint4*>(out + (size_t)9 * Cin * Cout + (size_t)9 * Cout * Cout));
-    if (mx)
+    if (mx) {
         hipLaunchKernelGGL(sr_prepack_up_mx_kernel, dim3((unsigned)((mu + 255) / 256)), dim3(256), 0, st, c0_w, Cin, Cout, tail0 + T.winv,
                            reinterpret_cast<uint4*>(tail1 + T.total));
+        if ((Cin & 15) == 0)        // conv0 in the plain layout with fp8 records: SynthesisBlockNoUp's conv0 on an R3D_FMT_SPLIT_MX input
+            hipLaunchKernelGGL(sr_prepack_mx_kernel, dim3((unsigned)((m0 / 2 + 255) / 256)), dim3(256), 0, st, c0_w, Cin, Cout, 9, Cin, Cout,
+                               tail0 + T.winv, reinterpret_cast<uint4*>(tail1 + T.total + (size_t)9 * Cin * Cout));
+    }
     return check_launch("sr_block_prepack");
 }
 
@@ -1679,11 +1694,13 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
         a.out_scale = pk + L.d0f; a.out_scale_stride_n = L.total; a.bias = pk + L.b0; a.bias_stride_n = L.total;
         a.OH = OH; a.OW = OW;
         a.y_split = y0; a.y_split_stride_n = (size_t)Cout / 8 * OH * OW * 2; a.next_scale = pk + L.s1f; a.next_scale_stride_n = L.total;
+        a.y_split_mx = mx ? 1 : 0;                                   // f16mx: conv1 reads fp8 records
+        if (mx_in) a.wp = reinterpret_cast<const uint4*>(wpk + (size_t)3 * 9 * Cin * Cout + (size_t)9 * Cout * Cout + 2 * conv_tail_layout(Cout).total);
         a.Cin = Cin; a.Cout = Cout; a.CoutReal = Cout; a.H = Hin; a.W = Win; a.nphase = 1;
         a.act = 1; a.act_slope = 0.2f; a.act_gain = 1.4142135623730951f; a.clamp = clamp;
         sr_fill_conv3x3_phase(a.ph, OH, OW);
         ProfScope ps(R3D_PROF_CONV, st);
-        launch_conv2(a, tiles_of(OH, OW), N, st);
+        launch_conv2(a, tiles_of(OH, OW), N, st, mx_in);
     }
     // ---- conv1 (3x3) + bias/lrelu + toRGB partials (+ optional x outputs) ------------------------------------------
     {
@@ -1723,10 +1740,11 @@ static inline int pad_to(int v, int m) { return (v + m - 1) / m * m; }
 size_t conv_prepacked_bytes_f16x3(int Cin, int Cout, int ksize)
 {
     const int Co = pad_to(Cout, BLOCK_M);
-    return ((size_t)(ksize * ksize) * pad_to(Cin, 16) * Co + conv_tail_layout(Co).total) * sizeof(float);
+    const size_t w = (size_t)(ksize * ksize) * pad_to(Cin, 16) * Co;
+    return (w + conv_tail_layout(Co).total + (ksize == 3 ? w : 0)) * sizeof(float);      // 3x3: the weights again with fp8 records (R3D_FMT_SPLIT_MX inputs)
 }
 
-// prepacked = split weights (rows pre-scaled by 2^kw[co]) ++ ConvTail {2^-kw[co], sum|w[co]|}
+// prepacked = split weights (rows pre-scaled by 2^kw[co]) ++ ConvTail {2^-kw[co], sum|w[co]|} ++ (3x3 only) the weights in the f16mx layout
 int conv_prepack_f16x3(const float* w, int Cin, int Cout, int ksize, void* prepacked, hipStream_t st)
 {
     const int Ci = pad_to(Cin, 16), Co = pad_to(Cout, BLOCK_M), nt = ksize * ksize;
@@ -1736,6 +1754,9 @@ int conv_prepack_f16x3(const float* w, int Cin, int Cout, int ksize, void* prepa
     hipLaunchKernelGGL(weight_row_stats_kernel, dim3(Co), dim3(256), 0, st, w, Cin * nt, Cout, Co, tail);
     hipLaunchKernelGGL(sr_prepack_f16_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, w, Cin, Cout, nt, Ci, Co,
                        tail + conv_tail_layout(Co).winv, reinterpret_cast<uint4*>(prepacked));
+    if (ksize == 3)
+        hipLaunchKernelGGL(sr_prepack_mx_kernel, dim3((unsigned)((m / 2 + 255) / 256)), dim3(256), 0, st, w, Cin, Cout, nt, Ci, Co,
+                           tail + conv_tail_layout(Co).winv, reinterpret_cast<uint4*>(tail + conv_tail_layout(Co).total));
     return check_launch("conv_prepack");
 }
 
@@ -1755,7 +1776,8 @@ int conv_forward_f16x3(const void* prepacked, const float* scales, size_t scales
     const int Ci = pad_to(Cin, 16), Co = pad_to(Cout, BLOCK_M);
     const ConvScales S = conv_scales_layout(Ci, Co);
     const uint4* xs = reinterpret_cast<const uint4*>(x);
-    if (x_format != R3D_FMT_SPLIT) {
+    const bool mx_in = x_format == R3D_FMT_SPLIT_MX;          // (validated by the caller: ksize 3, Cin % 16 == 0): the f16mx main loop
+    if (x_format != R3D_FMT_SPLIT && !mx_in) {
         uint4* xin = reinterpret_cast<uint4*>(workspace);
         ProfScope ps(R3D_PROF_LAYOUT, st);
         hipLaunchKernelGGL(to_split_kernel, dim3((H * W + 255) / 256, Ci / 8, N), dim3(256), 0, st,
@@ -1765,6 +1787,7 @@ int conv_forward_f16x3(const void* prepacked, const float* scales, size_t scales
     Conv2Args a = {};
     a.x = xs; a.x_stride_n = (size_t)Ci / 8 * H * W * 2;
     a.wp = reinterpret_cast<const uint4*>(prepacked);
+    if (mx_in) a.wp = reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(prepacked) + (size_t)ksize * ksize * Ci * Co + conv_tail_layout(Co).total);
     a.out_scale = scales + S.out_vec; a.out_scale_stride_n = scales_stride; a.bias = bias; a.bias_stride_n = 0;
     a.OH = H; a.OW = W;
     if (y_format == R3D_FMT_CB8) { a.y_f32 = reinterpret_cast<float*>(y); a.y_f32_stride_n = (size_t)Cout * H * W; }
@@ -1781,7 +1804,7 @@ int conv_forward_f16x3(const void* prepacked, const float* scales, size_t scales
         p.ntaps = 1; p.dy[0] = 0; p.dx[0] = 0; p.widx[0] = 0;
     }
     ProfScope ps(R3D_PROF_CONV, st);
-    launch_conv2(a, tiles_of(H, W), N, st);
+    launch_conv2(a, tiles_of(H, W), N, st, mx_in);
     return check_launch("conv_forward");
 }
 

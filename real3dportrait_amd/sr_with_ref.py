@@ -172,7 +172,7 @@ def _forward_v2(self, S, rgb, x, ws, ref_torso_rgb, ref_bg_rgb, weights_img, seg
     ops, head, last = fuse_ht.chain_ops(N, dev, -1, -2, base=0)
     chain_fold(ops + [hb.chain_op(last)], N, [m_x0, bound_of(x_torso, S.meter_hid, 3)[0]], zero=[m_y])
     xs = blend_cat(x0, x_torso, alpha, fuse_ht, _folded_head=head)                                      # :104
-    y = fuse_ht(xs, out_format="split", _next=hb, _y_absmax=m_y)                                        # :105
+    y = fuse_ht(xs, out_format="split_mx" if hb.wants_mx() else "split", _next=hb, _y_absmax=m_y)       # :105
     chain_fold([hb.chain_op(-1, tail=True)], N, [m_y], zero=[m_x2])
     hb.out_format, hb.return_x = "cb8", True
     x2, rgb2 = hb(y, rgb1, ws3, _prepared=preph, _folded=True, _x_absmax=m_x2, **kw)                   # :106
@@ -185,9 +185,8 @@ def _forward_v2(self, S, rgb, x, ws, ref_torso_rgb, ref_bg_rgb, weights_img, seg
     ops, head, last = fuse_fg.chain_ops(N, dev, -1, -2, base=0)
     chain_fold(ops + [b1.chain_op(last)], N, [m_x2, x_bg._r3d_bound], zero=[m_z])
     xs2 = blend_cat(x2, x_bg, pocc, fuse_fg, _folded_head=head)                                         # :113
-    from .superresolution import _MX_UPCONV
     # f16mx: the last fusion conv leaves fp8 records for block1's up-sampling conv (R3D_FMT_SPLIT_MX), as block0 does in the head-only network
-    z = fuse_fg(xs2, out_format="split_mx" if (b1._prec() == 2 and _MX_UPCONV) else "split", _next=b1, _y_absmax=m_z)   # :114
+    z = fuse_fg(xs2, out_format="split_mx" if b1.wants_mx() else "split", _next=b1, _y_absmax=m_z)      # :114
     chain_fold([b1.chain_op(-1, tail=True)], N, [m_z])
     b1.return_x = False
     _, rgb_out = b1(z, rgb3, ws3, _prepared=prep1, _folded=True, **kw)                                 # :115

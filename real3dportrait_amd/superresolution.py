@@ -89,13 +89,14 @@ _MX_UPCONV = os.environ.get("R3D_MX_UPCONV", "1") != "0"      # A/B switch: 0 = 
 
 
 def set_sr_precision(module, precision):
-    """Set `.precision` on every SR block under `module` (SynthesisBlock / SynthesisBlockNoUp; a block without an fp8 path computes its
-    layers as 'f16x3' under 'f16mx').  None: leave as constructed.  Returns the module."""
+    """Set `.precision` on every SR block (SynthesisBlock / SynthesisBlockNoUp) and every HIP Conv2d under `module` (the torso / background
+    fusion stacks of SuperresolutionHybrid8XDC_Warp; a 1x1 conv or one fed with fp32 has no fp8 path and computes as 'f16x3' under
+    'f16mx').  None: leave as constructed.  Returns the module."""
     if precision is not None:
         if precision not in SynthesisBlock._PREC:
             raise ValueError("SR precision must be one of %s, got %r" % (sorted(SynthesisBlock._PREC), precision))
         for m in module.modules():
-            if isinstance(m, SynthesisBlock):
+            if isinstance(m, (SynthesisBlock, Conv2d)):
                 m.precision = precision
     return module
 
@@ -240,8 +241,12 @@ class SynthesisBlock(nn.Module):
     _PREC = {"f32": 0, "f16x3": 1, "f16mx": 2}
 
     def _prec(self):
-        p = self._PREC[self.precision]
-        return 1 if (p == 2 and not self._UP) else p          # SynthesisBlockNoUp has no fp8 path: f16x3
+        return self._PREC[self.precision]
+
+    def wants_mx(self):
+        """True when a producer of this block's SPLIT input should leave fp8 records in the lo plane (out_format 'split_mx'): the block's
+        conv0 then runs the f16mx main loop (the up-sampling conv of SynthesisBlock, the plain 3x3 conv0 of SynthesisBlockNoUp)."""
+        return self._prec() == 2 and self.in_channels % 16 == 0 and (_MX_UPCONV or not self._UP)
 
     def _clamp(self):
         return -1.0 if self.conv_clamp is None else float(self.conv_clamp)
@@ -338,7 +343,7 @@ class SynthesisBlock(nn.Module):
             x_out = None
         elif out_fmt in ("split", "split_mx"):
             assert _next is not None, "out_format='split' needs the consumer (its folded in-multiplier)"
-            assert out_fmt == "split" or (prec == 2 and _next._prec() == 2 and _next._UP), "split_mx is the hand-off between two f16mx up blocks"
+            assert out_fmt == "split" or (prec == 2 and _next.wants_mx()), "split_mx is the hand-off to an f16mx consumer"
             next_scale, next_stride = _next.in_scale()
             x_out = torch.empty(N, 2, Cout // 8, OH, OW, 8, device=dev, dtype=torch.float16)
         elif out_fmt == "cb8":
@@ -392,9 +397,16 @@ class Conv2d(nn.Module):
         self._bias32 = None
         self._meter = _BoundMeter()
         self._depth_in = 0
+        # 'f16x3' (library default, fp32-class) | 'f16mx': a 3x3 conv whose SPLIT input carries fp8 records (R3D_FMT_SPLIT_MX) runs its
+        # cross products on the block-scaled fp8 MFMA; the PRODUCER of the input asks `wants_mx()` and writes the records.  'f32' = 'f16x3'
+        # here (the plain convs have no exact-f32 kernel).  R3D_SR_PRECISION / set_sr_precision() as for the SR blocks.
+        self.precision = os.environ.get("R3D_SR_PRECISION", DEFAULT_SR_PRECISION)
 
     _buf = SynthesisBlock._buf
     _FMT = SynthesisBlock._FMT
+
+    def wants_mx(self):
+        return self.precision == "f16mx" and self.kernel_size[0] == 3 and self.in_channels % 16 == 0
 
     def prepare(self, N, dev):
         """Static weight re-layout (cached on the parameter version) and this call's scales buffer."""
@@ -437,7 +449,7 @@ class Conv2d(nn.Module):
         ('split' needs `_next`, the consumer module, folded by the caller in the same chain)."""
         lib = _lib.load()
         x_fmt = getattr(x, "_r3d_fmt", "nchw")
-        if x_fmt == "split":
+        if x_fmt in ("split", "split_mx"):
             if getattr(x, "_r3d_for", None) is not self:
                 raise RuntimeError("SPLIT activation was scaled for a different consumer")
             _folded = True
@@ -455,7 +467,7 @@ class Conv2d(nn.Module):
             bx, self._depth_in = bound_of(x, self._meter, layers=1)
             chain_fold([self.chain_op(-1, negative_slope=negative_slope)], N, [bx])
         need = int(lib.r3d_conv_workspace_bytes(N, Cin, H, W))
-        work = self._buf("_workspace", need, dev) if x_fmt != "split" else None
+        work = self._buf("_workspace", need, dev) if x_fmt not in ("split", "split_mx") else None
         next_scale, next_stride = None, 0
         if out_format in ("split", "split_mx"):      # split_mx: fp8 records in the lo plane, for an f16mx SynthesisBlock that consumes y
             assert _next is not None, "out_format='split' needs the consumer (its folded in-multiplier)"
@@ -547,9 +559,10 @@ def blend_cat(a, b, mask, consumer, ws=None, _folded_head=None):
         head = consumer.fold_for_input(N, a.device, [ba, bb], ws=ws, depth=max(da, db))
     ns, stride = head.in_scale()
     y = torch.empty(N, 2, (Ca + Cb) // 8, H, W, 8, device=a.device, dtype=torch.float16)
-    _lib.check(lib.r3d_blend_cat_to_split(_lib.ptr(a), fa, Ca, _lib.ptr(b), fb, Cb, _lib.ptr(mask), N, H, W, _lib.ptr(y),
+    fmt = "split_mx" if head.wants_mx() else "split"       # an f16mx consumer: fp8 records in the lo plane
+    _lib.check(lib.r3d_blend_cat_to_split(_lib.ptr(a), fa, Ca, _lib.ptr(b), fb, Cb, _lib.ptr(mask), N, H, W, _lib.ptr(y), SynthesisBlock._FMT[fmt],
                                           _lib.ptr(ns), stride, _lib.stream_ptr()), "blend_cat_to_split")
-    y._r3d_fmt = "split"
+    y._r3d_fmt = fmt
     y._r3d_for = head
     return y
 
@@ -647,7 +660,7 @@ class ConvStack(nn.Sequential):
         _y_absmax: device float[N] slot the last conv measures max|y| into (zeroed by a preceding fold)."""
         plan = self._plan()
         x_fmt = getattr(x, "_r3d_fmt", "nchw")
-        if x_fmt == "split":
+        if x_fmt in ("split", "split_mx"):
             if getattr(x, "_r3d_for", None) is not plan[0][0]:
                 raise RuntimeError("SPLIT activation was scaled for a different consumer")
         else:
@@ -661,7 +674,7 @@ class ConvStack(nn.Sequential):
             if up:
                 x = upsample2x_bilinear(m(x, negative_slope=slope, out_format="cb8", _folded=True), "split", _next=nxt)
             elif nxt is not None and m.out_channels % 16 == 0:
-                x = m(x, negative_slope=slope, out_format="split", _next=nxt, _folded=True)
+                x = m(x, negative_slope=slope, out_format="split_mx" if nxt.wants_mx() else "split", _next=nxt, _folded=True)
             elif nxt is not None:
                 raise NotImplementedError("ConvStack: inner layers need out_channels % 16 == 0")
             else:
@@ -775,7 +788,7 @@ class SuperresolutionHybrid8XDC(nn.Module):
         mx = b0.precision == "f16mx"
         if b0.precision in ("f16x3", "f16mx"):
             # f16mx: block0's conv1 epilogue leaves fp8 records in the lo plane and block1's up-sampling conv runs its cross products on them
-            b0.out_format, nxt = ("split_mx" if mx and _MX_UPCONV else "split"), b1
+            b0.out_format, nxt = ("split_mx" if b1.wants_mx() else "split"), b1
         else:
             b0.out_format, nxt = "cb8", None
         x, rgb = b0(x, rgb, ws3, _prepared=prep0, _next=nxt, _folded=True, _x_absmax=x_absmax, **block_kwargs)

@@ -64,7 +64,12 @@ def test_precision_policy(monkeypatch):
         set_sr_precision(G.superresolution, "fp8")
     n = SynthesisBlockNoUp(64, 64, w_dim=512, resolution=32, img_channels=3, is_last=False, conv_clamp=None)
     n.precision = "f16mx"
-    assert n._prec() == 1                       # no fp8 path in the block without up-sampling: computes as f16x3
+    assert n._prec() == 2 and n.wants_mx()      # round 4: SynthesisBlockNoUp has the fp8 path too (conv0 on R3D_FMT_SPLIT_MX inputs, conv1)
+    from real3dportrait_amd.superresolution import Conv2d
+    c3, c1 = Conv2d(64, 128, 3, 1, padding=1), Conv2d(64, 128, 1, 1, padding=0)
+    assert c3.precision == "f16x3" and not c3.wants_mx()
+    set_sr_precision(torch.nn.Sequential(c3, c1), "f16mx")
+    assert c3.wants_mx() and not c1.wants_mx()  # the 1x1 conv has no fp8 path
     monkeypatch.setenv("R3D_SR_PRECISION", "f16mx")
     assert SynthesisBlock(32, 64, w_dim=512, resolution=32, img_channels=3, is_last=False, conv_clamp=None).precision == "f16mx"
     ClipRenderer(G, z, None, z, z, precision="throughput")
