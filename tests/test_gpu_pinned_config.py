@@ -258,12 +258,15 @@ def test_sr_block_heavy_tail(torch_cuda, precision, k, where):
     assert max(ex, ei) <= _TIER[precision] and max(fx, fi) <= _TIER_FAR[(precision, k)], (precision, where, k, ex, fx, ei, fi)
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("k", SPIKES)
 @pytest.mark.parametrize("where", ["input", "weight_rows"])
-def test_conv_stack_heavy_tail(torch_cuda, k, where):
-    """Three chained plain convs (bg_encoder's plan, sr_with_ref.py:27-33; SPLIT hand-offs, f16x3 -- the stacks have no fp8 path) with a
-    2^k sigma spike in the input / in every weight row of every layer, vs float64.  A weight spike of a plain conv (no demodulation) makes
-    a hot output pixel pattern in that channel: the next layer sees heavy-tailed activations."""
+def test_conv_stack_heavy_tail(torch_cuda, k, where, precision):
+    """Three chained plain convs (bg_encoder's plan, sr_with_ref.py:27-33; SPLIT hand-offs; under 'f16mx' the two 3x3 convs with a SPLIT_MX
+    input run their cross products on the fp8 MFMA, the first one -- fp32 input, Cin = 3 -- stays f16x3) with a 2^k sigma spike in the input /
+    in every weight row of every layer, vs float64.  A weight spike of a plain conv (no demodulation) makes a hot output pixel pattern in
+    that channel: the next layer sees heavy-tailed activations.  In f16mx the second and third conv read operands one and two propagated
+    bounds away from the measured input: the case DESIGN 4.2c states the tier for."""
     torch = torch_cuda
     from real3dportrait_amd import synth
     from real3dportrait_amd.superresolution import Conv2d, ConvStack
@@ -276,6 +279,7 @@ def test_conv_stack_heavy_tail(torch_cuda, k, where):
             co_i = np.arange(co)
             w[co_i, (co_i * 5) % ci, co_i % 3, (co_i // 3) % 3] *= s
         c = Conv2d(ci, co, ks, 1, padding=ks // 2)
+        c.precision = precision
         with torch.no_grad():
             c.weight.copy_(torch.from_numpy(w)); c.bias.copy_(torch.from_numpy(b))
         mods.append(c)
@@ -295,9 +299,14 @@ def test_conv_stack_heavy_tail(torch_cuda, k, where):
     e = err.max() / ref.max()
     far = _far_mask((40, 36), [(17, 20)], 4) if where == "input" else np.ones((40, 36), bool)
     f = err[:, far].max() / ref[:, far].max()
-    print("conv stack heavy tail %s 2^%d: %.2e (far %.2e) of max|ref|" % (where, k, e, f))
+    print("conv stack heavy tail [%s] %s 2^%d: %.2e (far %.2e) of max|ref|" % (precision, where, k, e, f))
     assert torch.isfinite(y).all()
-    assert e <= 2e-5 and f <= 1e-4, (where, k, e, f)
+    if precision == "f16x3":
+        assert e <= 2e-5 and f <= 1e-4, (where, k, e, f)
+    else:
+        # measured: err / max|ref| <= 4.5e-5 everywhere; far-field 2.3e-4 at a spike of 2^10 sigma, 3.6e-4 at 2^14 (the third conv's operand is
+        # two propagated bounds -- ~10 binades -- away from the measured input on top of the spike)
+        assert e <= SR_TOL and f <= {6: SR_TOL, 10: 3e-4, 14: 1e-3}[k], (where, k, e, f)
 
 
 @pytest.mark.parametrize("k", SPIKES)
