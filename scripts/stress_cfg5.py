@@ -4,6 +4,17 @@ defines it -- the same two SynthesisBlocks are applied at 2x spatial size (256^2
 Checks item 0 against the CPU oracle (render) and reports throughput."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if "--check" not in sys.argv:
+    # the measured flow is bench.py's cfg5_stress (same launches as the `cfg5_stress` entry of the bench line): target of the rocprofv3 passes
+    import json
+    import torch
+    import bench
+    from real3dportrait_amd import _lib
+    out = bench.cfg5_stress(torch, torch.device("cuda:0"), _lib.load(), os.environ.get("R3D_SR_PRECISION", "f16mx"))
+    print(json.dumps(out))
+    sys.exit(0)
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from real3dportrait_amd import ImportanceRenderer, OSGDecoder, RaySampler, SynthesisBlock, synth
 from real3dportrait_amd.superresolution import chain_fold, const_bound
