@@ -35,6 +35,14 @@ def test_bench_weak_scaling_line_under_torchrun():
     assert abs(d["value"] - 6 / (d["ms_per_step"] * 6e-3)) / d["value"] < 1e-3
     assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] < 1 and d["repeats"]["n"] == 5
     assert d["value"] > 100
+    # roofline.traffic is re-measured in the run (two rocprofv3 --pmc child passes) whenever the tool is there; else the committed figure, labelled
+    import shutil
+    r = d["roofline"]
+    assert r["traffic"] and r["traffic_source"] and r["algorithmic_bytes_per_launch"] > 1e8
+    if shutil.which("rocprofv3"):
+        assert "child passes of this run" in r["traffic_source"], r["traffic_source"]
+        assert 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.6, (r["traffic"], r["algorithmic_bytes_per_launch"])
+    assert "f16mx" in d["dtype"] and r["precision"] == "f16mx"          # the precision of `value` is selected by name and spelled out
 
 
 def test_bench_clip_mode_uneven_tail_under_torchrun():
