@@ -62,6 +62,12 @@ __device__ __forceinline__ void split1_folded(float v, _Float16& hi, _Float16& l
 // from a measurement), which is what the block's range fold provides (see SuperresolutionHybrid8XDC.forward).
 // In memory the fp8 records take the place of the fp16 lo plane with the SAME addressing: "lo" chunk 2G holds xh8 (wl8) of the 16
 // channels 16G..16G+15, chunk 2G+1 holds xl8 (wh8) -- so every DMA of the f16x3 kernels is unchanged.
+// Byte order inside a 16-byte record (round 4): dword d = 2 h + p holds channels 8 p + 4 h .. + 3 (p = which 8-channel chunk of the group,
+// h = which half of that chunk), activations and weights alike (the K index of a dot product may be permuted freely).  The producers' lanes
+// hold 4 channels = (chunk, half), and the two chunks of a group come from consecutive iterations of their loops: with this order a lane
+// writes 8 contiguous bytes and a lane pair a whole record per store -- the straight order (dword 2 p + h) made every record two 8-byte
+// read-modify-writes (block1.conv0 wrote 153 MB for 134 MB, profiles/r04/pmc_summary.txt).
+__device__ __host__ __forceinline__ int mx_rec_chan(int dword) { return 8 * (dword & 1) + 4 * (dword >> 1); }     // first channel of a record dword
 #ifndef R3D_TAPS_CT
 #define R3D_TAPS_CT 3            // experiment switch (bisect): bit 0 = compile-time tap offsets in the f16 part, bit 1 = in the fp8 part
 #endif
@@ -131,8 +137,9 @@ __global__ void sr_prepack_mx_kernel(const float* __restrict__ w, int CiReal, in
     unsigned* pl = reinterpret_cast<unsigned*>(&wl8); unsigned* ph = reinterpret_cast<unsigned*>(&wh8);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        pl[q] = pack4_fp8(lo[4 * q] * kMxWl, lo[4 * q + 1] * kMxWl, lo[4 * q + 2] * kMxWl, lo[4 * q + 3] * kMxWl);
-        ph[q] = pack4_fp8(hi[4 * q] * kMxWh, hi[4 * q + 1] * kMxWh, hi[4 * q + 2] * kMxWh, hi[4 * q + 3] * kMxWh);
+        const int c = mx_rec_chan(q);
+        pl[q] = pack4_fp8(lo[c] * kMxWl, lo[c + 1] * kMxWl, lo[c + 2] * kMxWl, lo[c + 3] * kMxWl);
+        ph[q] = pack4_fp8(hi[c] * kMxWh, hi[c + 1] * kMxWh, hi[c + 2] * kMxWh, hi[c + 3] * kMxWh);
     }
     const size_t base = ((size_t)tap * (Ci / 8) + 2 * grp) * 2 * Cout + co;      // [tap][chunk][hi|lo][cout]
     out[base] = *reinterpret_cast<uint4*>(&h0);
@@ -279,6 +286,9 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
         __syncthreads();
     }
     float vmax = 0.f;
+    unsigned rec_h[NT], rec_l[NT];                        // y_split_mx: the even chunk's record dwords wait for the odd chunk's (one 8-byte store)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { rec_h[nt] = 0u; rec_l[nt] = 0u; }
     float rgbp[NT][3];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { rgbp[nt][0] = 0.f; rgbp[nt][1] = 0.f; rgbp[nt][2] = 0.f; }
@@ -362,9 +372,12 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
                         const unsigned xh8 = pack4_fp8((float)hi[0] * kMxXh, (float)hi[1] * kMxXh, (float)hi[2] * kMxXh, (float)hi[3] * kMxXh);
                         const unsigned xl8 = pack4_fp8(lf[0] * kMxXl, lf[1] * kMxXl, lf[2] * kMxXl, lf[3] * kMxXl);
                         const unsigned c8 = (unsigned)(m0 + cu) >> 3;
-                        unsigned* rec = reinterpret_cast<unsigned*>(Ys + oplane + (size_t)((c8 & ~1u) * cs + p0[nt]));
-                        rec[2 * (c8 & 1u) + h] = xh8;
-                        rec[(size_t)4 * cs + 2 * (c8 & 1u) + h] = xl8;
+                        if (!(c8 & 1u)) { rec_h[nt] = xh8; rec_l[nt] = xl8; }          // (g even; g + 1 is the group's other chunk, same mt, same pixels)
+                        else {
+                            uint2* rec = reinterpret_cast<uint2*>(Ys + oplane + (size_t)((c8 & ~1u) * cs + p0[nt])) + h;      // dwords 2 h, 2 h + 1
+                            rec[0] = make_uint2(rec_h[nt], xh8);
+                            rec[2 * (size_t)cs] = make_uint2(rec_l[nt], xl8);
+                        }
                     } else {
                         dst[2 * oplane] = *reinterpret_cast<uint2*>(&lo);
                     }
@@ -968,7 +981,7 @@ __global__ void sr_prepack_up_mx_kernel(const float* __restrict__ w, int Cin, in
         float f[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float v = w[((size_t)cout * Cin + st * 16 + 4 * q + j) * 9 + t] * ws;
+            const float v = w[((size_t)cout * Cin + st * 16 + mx_rec_chan(q) + j) * 9 + t] * ws;
             _Float16 a, b; split1(v, a, b);
             f[j] = hc ? (float)a * kMxWh : (v - (float)a) * kMxWl;
         }
@@ -1185,6 +1198,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void upconv_fir_f16x3_ker
     for (int g = 0; g < 4; ++g)
         asm volatile("" :: "v"(dv4[g].x), "v"(dv4[g].w), "v"(bv4[g].x), "v"(bv4[g].w), "v"(nv4[g].x), "v"(nv4[g].w));
     __syncthreads();                                                // the main loop's LDS reads are done
+    unsigned mxk_h[1024 / NTHR][2], mxk_l[1024 / NTHR][2];
+#pragma unroll
+    for (int k = 0; k < 1024 / NTHR; ++k) { mxk_h[k][0] = mxk_h[k][1] = 0u; mxk_l[k][0] = mxk_l[k][1] = 0u; }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         float4* hls = hls0 + (g & 1) * 2048;
@@ -1260,13 +1276,17 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void upconv_fir_f16x3_ker
                         const f2 fla = va - fha, flb = vb - fhb;
                         const unsigned xh8 = pack4_fp8(fha.x * kMxXh, fha.y * kMxXh, fhb.x * kMxXh, fhb.y * kMxXh);
                         const unsigned xl8 = pack4_fp8(fla.x * kMxXl, fla.y * kMxXl, flb.x * kMxXl, flb.y * kMxXl);
+                        if (!(g & 1)) { mxk_h[k][dy] = xh8; mxk_l[k][dy] = xl8; }      // the group's even chunk: its record dwords wait for slice g + 1
                         if (live && oy < OH && ox < OW) {
                             const size_t pix = (size_t)oy * OW + ox;
                             reinterpret_cast<uint2*>(d + pix)[half] = hw;
-                            // fp8 records of the 16-channel group (cg * 2 + (g >> 1)): even lo chunk = xh8, odd lo chunk = xl8
-                            uint4* rec = a.y + (size_t)n * a.y_stride_n + oplane + (size_t)((co0 >> 3) + (g & ~1)) * OH * OW + pix;    // lo plane
-                            reinterpret_cast<unsigned*>(rec)[2 * (g & 1) + half] = xh8;
-                            reinterpret_cast<unsigned*>(rec + (size_t)OH * OW)[2 * (g & 1) + half] = xl8;
+                            if (g & 1) {
+                                // fp8 records of the 16-channel group (cg * 2 + (g >> 1)): even lo chunk = xh8, odd lo chunk = xl8; this lane's dwords
+                                // 2 half, 2 half + 1 (mx_rec_chan): the lane pair writes the whole 16-byte record
+                                uint4* rec = a.y + (size_t)n * a.y_stride_n + oplane + (size_t)((co0 >> 3) + (g & ~1)) * OH * OW + pix;    // lo plane
+                                reinterpret_cast<uint2*>(rec)[half] = make_uint2(mxk_h[k][dy], xh8);
+                                reinterpret_cast<uint2*>(rec + (size_t)OH * OW)[half] = make_uint2(mxk_l[k][dy], xl8);
+                            }
                         }
                     } else {
                         const uint2 lw = make_uint2(*reinterpret_cast<const unsigned*>(&loa), *reinterpret_cast<const unsigned*>(&lob));
@@ -1465,9 +1485,11 @@ __global__ void blend_cat_to_split_kernel(const float* __restrict__ a, int a_cb8
     uint4* d = dst + (size_t)n * 2 * plane + (size_t)cb * HW + p;
     d[0] = *reinterpret_cast<uint4*>(&hi);
     if (mx) {
-        uint2* rec = reinterpret_cast<uint2*>(dst + (size_t)n * 2 * plane + plane + (size_t)(cb & ~1) * HW + p) + (cb & 1);
-        rec[0] = make_uint2(pack4_fp8(hf[0] * kMxXh, hf[1] * kMxXh, hf[2] * kMxXh, hf[3] * kMxXh), pack4_fp8(hf[4] * kMxXh, hf[5] * kMxXh, hf[6] * kMxXh, hf[7] * kMxXh));
-        rec[2 * (size_t)HW] = make_uint2(pack4_fp8(lf[0] * kMxXl, lf[1] * kMxXl, lf[2] * kMxXl, lf[3] * kMxXl), pack4_fp8(lf[4] * kMxXl, lf[5] * kMxXl, lf[6] * kMxXl, lf[7] * kMxXl));
+        unsigned* rec = reinterpret_cast<unsigned*>(dst + (size_t)n * 2 * plane + plane + (size_t)(cb & ~1) * HW + p) + (cb & 1);      // dwords p and 2 + p
+        rec[0] = pack4_fp8(hf[0] * kMxXh, hf[1] * kMxXh, hf[2] * kMxXh, hf[3] * kMxXh);
+        rec[2] = pack4_fp8(hf[4] * kMxXh, hf[5] * kMxXh, hf[6] * kMxXh, hf[7] * kMxXh);
+        rec[4 * (size_t)HW] = pack4_fp8(lf[0] * kMxXl, lf[1] * kMxXl, lf[2] * kMxXl, lf[3] * kMxXl);
+        rec[4 * (size_t)HW + 2] = pack4_fp8(lf[4] * kMxXl, lf[5] * kMxXl, lf[6] * kMxXl, lf[7] * kMxXl);
     } else {
         d[plane] = *reinterpret_cast<uint4*>(&lo);
     }
