@@ -28,6 +28,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 PEAK_F16_MFMA_TFLOPS = 2500.0         # dense f16/bf16 MFMA peak (same guide)
 PEAK_HBM_TBPS = 8.0
+PEAK_ENGINE_CLOCK_GHZ = 2.4           # "Max clock 2400 MHz" (same guide): the clock the MFMA peaks above are quoted at
 
 # algorithmic conv FLOPs of one frame: 2*taps*Cin*Cout*pixels for the four conv launches
 def conv_flops_per_frame(r=128):
@@ -501,10 +502,16 @@ def main():
     # streams a bracket would also contain other frames' kernels, so the kernel's own duration is measured over the
     # same K frames issued on ONE stream right after the timed region (what rocprofv3 --stats sees with --streams 1).
     # The duration measured INSIDE the timed region (other frames' kernels share the GPU) is reported next to it.
-    lib.r3d_profile_configure((1 << 1) | (1 << 2)); lib.r3d_profile_reset()
+    lib.r3d_profile_configure((1 << 0) | (1 << 1) | (1 << 2)); lib.r3d_profile_reset()
     for i in range(K):
         clip.render_u8(rank * K + i, out=ring[i:i + 1])
     torch.cuda.synchronize()
+    # the shader clock the kernels ran at in that loop: one wave per launch reads s_memtime / s_memrealtime (r3d_profile_clock)
+    clock_ghz = {}
+    for fam, pid in (("render_kernel", 0), ("conv", 1), ("upconv_fir", 2)):
+        g = ctypes.c_double(0)
+        _lib.check(lib.r3d_profile_clock(pid, ctypes.byref(g), None), "profile_clock")
+        clock_ghz[fam] = round(g.value, 3) if g.value > 0 else None
     lib.r3d_profile_configure(0)
     ms, cnt = ctypes.c_double(0), ctypes.c_int(0)
     _lib.check(lib.r3d_profile_read(1, ctypes.byref(ms), ctypes.byref(cnt)), "profile_read")
@@ -554,6 +561,13 @@ def main():
                 "algorithmic_gflop_per_launch": round(dom_flops / launches / 1e9, 3),
                 "mfma_products_per_mac": products,
                 "executed_tflops": round(achieved_tf * products, 1), "pipe_frac": round(achieved_tf * products / peak, 4),
+                # `peak` is the dense MFMA rate at the 2.4 GHz peak engine clock; the clock the power management held while THIS kernel ran is
+                # measured (s_memtime / s_memrealtime of one wave per launch, same one-stream loop as avg_launch_ms), and the fraction of the
+                # matrix rate at that clock is reported beside `frac`, never instead of it
+                "shader_clock_ghz": clock_ghz.get("conv"), "peak_clock_ghz": PEAK_ENGINE_CLOCK_GHZ,
+                "frac_at_measured_clock": round(achieved_tf / (peak * clock_ghz["conv"] / PEAK_ENGINE_CLOCK_GHZ), 4) if clock_ghz.get("conv") else None,
+                "pipe_frac_at_measured_clock": round(achieved_tf * products / (peak * clock_ghz["conv"] / PEAK_ENGINE_CLOCK_GHZ), 4) if clock_ghz.get("conv") else None,
+                "shader_clock_ghz_other_kernels": {k: v for k, v in clock_ghz.items() if k != "conv"},
                 "precision": prec}
     if up_tf is not None:   # second kernel family, reported beside the dominant one (its time includes the fused FIR/activation)
         roofline["upconv_fir_f16x3_kernel"] = {"launches_per_frame": 2, "avg_launch_ms": round(ums.value / max(1, ucnt.value), 4),

@@ -336,6 +336,12 @@ enum r3d_prof_id {
 int r3d_profile_configure(uint32_t mask);
 int r3d_profile_reset(void);
 int r3d_profile_read(int id, double* total_ms, int* launches);
+/* The shader clock the family's sampled kernels ran at since the last reset, in GHz (0 if none was sampled): one wave per launch of
+ * render_kernel (RENDER), the plain 3x3 f16x3/f16mx conv (CONV) and the fused up-sampling conv (UPCONV) reads s_memtime and
+ * s_memrealtime at its start and end -- cycles / ticks x hipDeviceAttributeWallClockRate.  The peaks bench.py prices against assume the
+ * 2.4 GHz peak engine clock; under an MFMA-dense kernel the power management holds less.  `cycles` (optional): the summed s_memtime
+ * cycles of the sampled waves.  Synchronises the device.  Sample with ONE stream (the start stamps are per family, not per launch). */
+int r3d_profile_clock(int id, double* ghz, unsigned long long* cycles);
 
 #ifdef __cplusplus
 }

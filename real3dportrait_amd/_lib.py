@@ -58,6 +58,7 @@ SIGNATURES = {
     "r3d_profile_configure": (c_int, [ctypes.c_uint32]),
     "r3d_profile_reset": (c_int, []),
     "r3d_profile_read": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_int)]),
+    "r3d_profile_clock": (c_int, [c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_ulonglong)]),
     "r3d_event_create": (c_int, [ctypes.POINTER(c_void_p)]),
     "r3d_event_record": (c_int, [P, P]),
     "r3d_event_elapsed_ms": (c_int, [P, P, ctypes.POINTER(c_float)]),

@@ -39,6 +39,12 @@ static uint32_t g_prof_mask = 0;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev[R3D_PROF_COUNT];
 static size_t g_prof_used[R3D_PROF_COUNT] = {0};
 static constexpr size_t kProfPool = 1024;       // event pairs pre-created per enabled family
+static unsigned long long* g_prof_clk = nullptr;   // device: [R3D_PROF_COUNT][4] (cycles, ticks, start cycles, start ticks), see prof_clock_slot
+
+unsigned long long* prof_clock_slot(int id)
+{
+    return (g_prof_clk && (g_prof_mask & (1u << id))) ? g_prof_clk + 4 * id : nullptr;
+}
 
 void prof_begin(int id, hipStream_t st)
 {
@@ -185,6 +191,10 @@ extern "C" int r3d_profile_configure(uint32_t mask)
                 if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { set_error("profile_configure: hipEventCreate failed"); return R3D_ERR_LAUNCH; }
                 g_prof_ev[i].push_back(std::make_pair(a, b));
             }
+    if (mask && !g_prof_clk) {
+        if (hipMalloc(&g_prof_clk, sizeof(unsigned long long) * 4 * R3D_PROF_COUNT) != hipSuccess ||
+            hipMemset(g_prof_clk, 0, sizeof(unsigned long long) * 4 * R3D_PROF_COUNT) != hipSuccess) { g_prof_clk = nullptr; set_error("profile_configure: clock slots"); return R3D_ERR_LAUNCH; }
+    }
     g_prof_mask = mask;
     return R3D_OK;
 }
@@ -192,6 +202,21 @@ extern "C" int r3d_profile_reset(void)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     for (int i = 0; i < R3D_PROF_COUNT; ++i) g_prof_used[i] = 0;
+    if (g_prof_clk && (hipDeviceSynchronize() != hipSuccess || hipMemset(g_prof_clk, 0, sizeof(unsigned long long) * 4 * R3D_PROF_COUNT) != hipSuccess)) { set_error("profile_reset: clock slots"); return R3D_ERR_LAUNCH; }
+    return R3D_OK;
+}
+extern "C" int r3d_profile_clock(int id, double* ghz, unsigned long long* cycles)
+{
+    if (id < 0 || id >= R3D_PROF_COUNT || !ghz) { set_error("profile_clock: bad argument"); return R3D_ERR_INVALID_ARG; }
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    *ghz = 0.0; if (cycles) *cycles = 0;
+    if (!g_prof_clk) return R3D_OK;
+    unsigned long long h[4];
+    int dev = 0, khz = 0;
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, g_prof_clk + 4 * id, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess) { set_error("profile_clock: query failed"); return R3D_ERR_LAUNCH; }
+    if (h[1] && khz > 0) *ghz = (double)h[0] / (double)h[1] * (double)khz * 1e-6;
+    if (cycles) *cycles = h[0];
     return R3D_OK;
 }
 extern "C" int r3d_profile_read(int id, double* total_ms, int* launches)

@@ -18,6 +18,24 @@ struct ProfScope {
     ProfScope(int id_, hipStream_t st_) : id(id_), st(st_) { prof_begin(id, st); }
     ~ProfScope() { prof_end(id, st); }
 };
+// The shader clock a profiled kernel actually runs at (r3d_profile_clock): when the family's bit is set its launches get a 4-word slot, and
+// ONE wave of each launch (wave 0 of a block in the middle of the grid) stores (s_memtime, s_memrealtime) when it starts and adds the two
+// deltas to words 0 / 1 when it ends -- cycles / ticks x the constant wall-clock rate = the frequency the power management held during the
+// kernel.  nullptr (family not profiled): the kernel pays one uniform branch.  Launches of one family on several streams at once share the
+// slot's start words: sample with one stream.
+unsigned long long* prof_clock_slot(int id);
+__device__ __forceinline__ void clk_begin(unsigned long long* c) { if (c) { c[2] = clock64(); c[3] = wall_clock64(); } }
+__device__ __forceinline__ void clk_end(unsigned long long* c) { if (c) { atomicAdd(c, clock64() - c[2]); atomicAdd(c + 1, wall_clock64() - c[3]); } }
+// Args::clk of a kernel whose FIRST parameter is an Args struct, read from the kernarg segment at the point of use (only the sampled wave
+// executes the load; nothing stays live across the kernel -- a by-value `a.clk` cost the register-tight kernels a spill)
+template <class Args>
+__device__ __forceinline__ unsigned long long* kernarg_clk()
+{
+    typedef const __attribute__((address_space(4))) Args* KA;
+    KA ap = (KA)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ap));
+    return ap->clk;
+}
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

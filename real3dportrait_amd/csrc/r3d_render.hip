@@ -932,6 +932,7 @@ struct RenderArgs {
     const float* noise_c; const float* u_f; unsigned long long seed;
     const DecFold* fold;                            // written by decoder_fold_kernel (same stream, before this kernel)
     float* rgb; float* depth; float* wsum; int rgb_cm;      // rgb_cm: rgb is [N,32,M] (channel-major) instead of [N,M,32]; depth may be NULL
+    unsigned long long* clk;                        // prof_clock_slot(R3D_PROF_RENDER) or null
 };
 
 // Ray order: XCD x (= blockIdx % 8, the observed dispatch rule -- speed only) renders the column strip
@@ -1018,6 +1019,7 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
     float run_min = INFINITY, run_max = -INFINITY;
     R3D_STAMP_DECL;
     int st_rays_ = 0; (void)st_rays_;
+    if (blockIdx.x == (gridDim.x >> 1) && threadIdx.x == 0) clk_begin(kernarg_clk<RenderArgs>());
 
     RayIter it;
     it.init(a, R, wave);
@@ -1351,6 +1353,7 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
         R3D_STAMP(6);
     }
     R3D_STAMP_FLUSH(10, st_rays_);
+    if (blockIdx.x == (gridDim.x >> 1) && threadIdx.x == 0) clk_end(kernarg_clk<RenderArgs>());
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
         run_min = fminf(run_min, __shfl_xor(run_min, d));
@@ -1575,6 +1578,7 @@ extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
     a.gstate = gstate; a.nlimit_blocks = (nrays + kLimitsBlock - 1) / kLimitsBlock; a.Nc = Nc; a.Nf = Nf; a.scale = 2.0f / box_warp; a.white_back = white_back;
     a.noise_c = noise_c; a.u_f = u_f; a.seed = seed;
     a.rgb = rgb; a.depth = depth; a.wsum = wsum; a.rgb_cm = rgb_channel_major ? 1 : 0;
+    a.clk = prof_clock_slot(R3D_PROF_RENDER);
 
     // (R computed above: square image -> XCD strip order; otherwise linear order)
     const int waves_needed = nrays;

@@ -244,6 +244,7 @@ struct Conv2Args {
     const float* wrgb; size_t wrgb_stride_n; float* rgb_partial; size_t rgbp_stride_n;   // toRGB partials [Cout/128][3][OH*OW] or null
     int Cin, Cout, CoutReal, H, W, nphase;    // Cout: padded to 128 (weight layout); CoutReal: channels that exist in the outputs
     int act; float act_slope, act_gain, clamp; // act: leaky-relu(slope) * gain after the bias; clamp < 0: off
+    unsigned long long* clk;                  // prof_clock_slot(R3D_PROF_CONV) or null (conv3x3_dma_block samples it)
     int order;                                // conv3x3_dma_block: 0 = (tile, cout tile) = (blockIdx.x, blockIdx.y); 1 / 2 = the cout tiles of a pixel tile adjacent in dispatch order on one XCD
     ConvPhase ph[4];
 };
@@ -736,6 +737,7 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
 
     // prologue: patch(0) and the first weight sub-stage
     R3D_STAMP_DECL;
+    if (blockIdx.x == (gridDim.x >> 1) && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) clk_begin(kernarg_clk<Conv2Args>());
     dma_weights2(0, wbuf);
     dma_patch(0, pbuf);
     R3D_STAMP(4);
@@ -847,11 +849,13 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
     __syncthreads();
     R3D_STAMP(5);
     conv_epilogue<FULL_EPI, WN, NT>(a, ph, n, acc, i0, j0, m0, reinterpret_cast<float*>(lds));
+    if (blockIdx.x == (gridDim.x >> 1) && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) clk_end(kernarg_clk<Conv2Args>());
     R3D_STAMP(6);
 #ifdef R3D_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     R3D_STAMP(7);
     if ((threadIdx.x & 63) == 0) { for (int i_ = 4; i_ < 8; ++i_) atomicAdd(&r3d::g_stamps[8 + i_], st_acc_[i_]); atomicAdd(&r3d::g_stamps[30], 1ull); }
+    R3D_STAMP_CLOCKS(26);
 #endif
 }
 
@@ -929,6 +933,7 @@ struct UpArgs {
     uint4* y; size_t y_stride_n;                // SPLIT output [hi|lo][Cout/8][2H][2W], scaled by next_scale
     int Cin, Cout, H, W, tiles_x, ntiles, tiles_per_xcd;
     float clamp;
+    unsigned long long* clk;                    // prof_clock_slot(R3D_PROF_UPCONV) or null
 };
 
 __global__ void sr_prepack_up_kernel(const float* __restrict__ w, int Cin, int Cout, const float* __restrict__ winv, uint4* __restrict__ out)
@@ -1013,6 +1018,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void upconv_fir_f16x3_ker
     const int tile = xcd * a.tiles_per_xcd + tl;
     if (tile >= a.ntiles) return;
     const int n = blockIdx.y;
+    if (blockIdx.x == (gridDim.x >> 1) && n == 0 && threadIdx.x == 0) clk_begin(kernarg_clk<UpArgs>());
     const int ty = tile / a.tiles_x, tx = tile - ty * a.tiles_x;
     const int i0 = ty * U_TILE, j0 = tx * U_TILE;                   // first input row / col of the tile; grid point g <-> i0 - 1 + g
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1301,6 +1307,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void upconv_fir_f16x3_ker
         }
     }
     R3D_STAMP(2);
+    if (blockIdx.x == (gridDim.x >> 1) && blockIdx.y == 0 && threadIdx.x == 0) clk_end(kernarg_clk<UpArgs>());
 #ifdef R3D_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     R3D_STAMP(3);
@@ -1602,7 +1609,7 @@ static unsigned lds_pad() { static const unsigned v = getenv("R3D_SR_LDS_PAD") ?
 
 static void launch_conv2(Conv2Args& a, int tiles, int N, hipStream_t st, bool mx = false)
 {
-
+    a.clk = prof_clock_slot(R3D_PROF_CONV);
     dim3 grid(tiles, a.Cout / BLOCK_M, N * a.nphase);
     static const int rows8 = getenv("R3D_CONV_ROWS8") ? atoi(getenv("R3D_CONV_ROWS8")) : 1;   // A/B switch: 0 = always 16x16 tiles
     if (rows8 && (rows8 == 1 || (rows8 == 2 && !a.rgb_partial) || (rows8 == 3 && a.rgb_partial)) && !mx && a.nphase == 1 && a.ph[0].ntaps == 9 && (size_t)tiles * grid.y * grid.z <= 256) {
@@ -1671,6 +1678,7 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
         u.ntiles = u.tiles_x * ((Hin + U_TILE - 1) / U_TILE);
         u.tiles_per_xcd = (u.ntiles + 7) / 8;
         u.clamp = clamp;
+        u.clk = prof_clock_slot(R3D_PROF_UPCONV);
         ProfScope ps(R3D_PROF_UPCONV, st);
         const dim3 ugrid(8 * u.tiles_per_xcd * (Cout / 32), N);
         // (NW = 8 -- one N tile per wave, 4 waves per SIMD -- was built for block0.conv0, the all-epilogue launch, and measured NEUTRAL in

@@ -12,7 +12,9 @@ with torch.no_grad():
             l = getattr(blk, name); w, b, aw, ab = p[name]
             l.weight.copy_(T(w)); l.bias.copy_(T(b)); l.affine.weight.copy_(T(aw)); l.affine.bias.copy_(T(ab))
 x = T(synth.hash_unitvar(7, (1, 32, 128, 128), stream=1)); rgb = x[:, :3].contiguous(); ws = torch.ones(1, 14, 512, device="cuda")
-for _ in range(2): sr(rgb, x, ws, noise_mode="none")
+for _ in range(2): out = sr(rgb, x, ws, noise_mode="none")
+import hashlib
+print("digest", hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest()[:16])
 torch.cuda.synchronize(); t = time.perf_counter()
 for _ in range(reps): sr(rgb, x, ws, noise_mode="none")
 torch.cuda.synchronize(); total = (time.perf_counter() - t) / reps * 1e3
