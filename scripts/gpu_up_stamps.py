@@ -37,7 +37,5 @@ for (cin, cout, res, seed) in ((32, 256, 128, 100), (256, 128, 256, 200)):
     import ctypes as _c
     hip = _c.CDLL("libamdhip64.so"); wr = _c.c_int(0); hip.hipDeviceGetAttribute(_c.byref(wr), 10017, 0)   # hipDeviceAttributeWallClockRate (kHz)
     wr_khz = wr.value if wr.value > 0 else 100000
-    ci = _c.c_int(0); hip.hipDeviceGetAttribute(_c.byref(ci), 10000, 0)   # hipDeviceAttributeClockInstructionRate: the rate clock64() is SPECIFIED in
-    if seed == 100: print("  (hipDeviceAttributeClockInstructionRate %d kHz, hipDeviceAttributeWallClockRate %d kHz)" % (ci.value, wr_khz))
     for nm, sl in (("up-conv", 28), ("conv1", 26)):
         if buf[sl + 1]: print("  %s waves ran at %.3f GHz (s_memtime / s_memrealtime, wall clock %d kHz)" % (nm, buf[sl] / buf[sl + 1] * wr_khz / 1e6, wr_khz))
