@@ -1094,49 +1094,102 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void upconv_fir_f16x3_ker
     };
     dma_stage(0, lds);
     R3D_STAMP(0);
+    i8v pa68, pa17, pb68[NTL], pb17[NTL];                           // MXIN: operand set P4 of the previous stage (see the main loop)
     for (int st = 0; st < nst; ++st) {
+#ifdef R3D_STAMPS
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); R3D_STAMP(1);      // stamps build: split the stage's cycles into compute (1) | own DMA wait (4) | barrier (5)
+#endif
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); // this stage's DMAs (issued one stage ago) have landed; this wave's LDS reads too (see conv3x3_dma_block)
+        R3D_STAMP(4);
         __builtin_amdgcn_s_barrier();                               // ... everybody's; and the other buffer's readers are done
+        R3D_STAMP(5);
         asm volatile("" ::: "memory");
         const uint4* cur = lds + (st & 1) * U_STAGE;
         if (st + 1 < nst) dma_stage(st + 1, lds + ((st + 1) & 1) * U_STAGE);
         if constexpr (MXIN) {
-            // hi * hi on the f16 pipe, window by window (the B window is read once for its 4 / 2 / 2 / 1 taps)
+            // hi * hi on the f16 pipe, window by window (a B window is read once for its 4 / 2 / 2 / 1 taps); then the cross products: one K = 64 fp8
+            // MFMA per tap pair and N tile -- taps (0, 2), (3, 5) and the centre tap meet the SAME B records (windows (0,0) / (0,1) of the lane halves).
+            // Two waves per SIMD do not hide an LDS round trip per MFMA (hipcc's own schedule was "2 reads, wait, 1 MFMA" a dozen times per stage:
+            // 3.1 k cycles for 1.2 k of MFMA), so the stage is four operand sets, each read while the previous set's MFMAs run:
+            //   R(P1) | M(P4 of the PREVIOUS stage: operands in registers since before the barrier) | R(P2) | M(P1) | R(P3) | M(P2) | R(P4) | M(P3)
+            //   P1 = windows 0, 1 (taps 0 1 3 4 | 2 5), P2 = windows 2, 3 (taps 6 7 | 8), P3 = pairs (0,2) (3,5) (4,-), P4 = pairs (6,8) (1,7).
+            // Per accumulator the MFMA order is the unpipelined one (f16 taps in window order, then its fp8 pairs): bit-identical results.
+            auto ld8 = [&](const uint4* p0, const uint4* p1) {
+                const uint4 q0 = *p0, q1 = *p1;
+                return (i8v){(int)q0.x, (int)q0.y, (int)q0.z, (int)q0.w, (int)q1.x, (int)q1.y, (int)q1.z, (int)q1.w};
+            };
+            auto ldh = [&](const uint4* p0) { uint4 q = *p0; return *reinterpret_cast<h8*>(&q); };
+            const uint4* curA = cur + aoff;
+            const int cb = (st & 1) * U_STAGE;
+            // ---- R(P1)
+            h8 B1[2][NTL], A1[6];
 #pragma unroll
-            for (int win = 0; win < 4; ++win) {
-                const int sy = win >> 1, sx = win & 1;
-                const int toff = -(sy * U_PW + sx);
-                h8 bh[NTL];
+            for (int nt = 0; nt < NTL; ++nt) { B1[0][nt] = ldh(cur + boff[nt]); B1[1][nt] = ldh(cur + boff[nt] - 1); }
+            {
+                constexpr int T1[6] = {0, 1, 3, 4, 2, 5};
 #pragma unroll
-                for (int nt = 0; nt < NTL; ++nt) { uint4 r0 = cur[boff[nt] + toff]; bh[nt] = *reinterpret_cast<h8*>(&r0); }
-#pragma unroll
-                for (int ky = 2 * sy; ky <= (sy ? 2 : 1); ++ky)
-#pragma unroll
-                    for (int kx = 2 * sx; kx <= (sx ? 2 : 1); ++kx) {
-                        const int t = ky * 3 + kx, p = (ky & 1) * 2 + (kx & 1);
-                        uint4 q0 = cur[t * 128 + aoff];
-                        const h8 ah = *reinterpret_cast<h8*>(&q0);
-#pragma unroll
-                        for (int nt = 0; nt < NTL; ++nt) acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[nt], acc[p][nt], 0, 0, 0);
-                    }
+                for (int k = 0; k < 6; ++k) A1[k] = ldh(curA + T1[k] * 128);
             }
-            // the cross products: one K = 64 fp8 MFMA per tap pair and N tile
-            auto mx_pair = [&](const int p, const int a0, const int a1, const int b_off, const int* bsel) {      // a0 / a1: absolute LDS slots of [wl8] / [wh8]
-                const uint4 q0 = lds[a0], q1 = lds[a1];
-                const i8v a8 = (i8v){(int)q0.x, (int)q0.y, (int)q0.z, (int)q0.w, (int)q1.x, (int)q1.y, (int)q1.z, (int)q1.w};
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- M(P4) of the previous stage
+            if (st > 0) {
 #pragma unroll
                 for (int nt = 0; nt < NTL; ++nt) {
-                    const uint4 r0 = cur[bsel[nt] + b_off], r1 = cur[bsel[nt] + b_off + U_PPLANE];
-                    const i8v b8 = (i8v){(int)r0.x, (int)r0.y, (int)r0.z, (int)r0.w, (int)r1.x, (int)r1.y, (int)r1.z, (int)r1.w};
-                    acc[p][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, acc[p][nt], 0, 0, 0, kMxScaleA, 0, kMxScaleB);
+                    acc[0][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pa68, pb68[nt], acc[0][nt], 0, 0, 0, kMxScaleA, 0, kMxScaleB);
+                    acc[1][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pa17, pb17[nt], acc[1][nt], 0, 0, 0, kMxScaleA, 0, kMxScaleB);
                 }
-            };
-            const int cb = (st & 1) * U_STAGE;
-            mx_pair(0, cb + a8d2 + 0 * 128, cb + a8d2 + 0 * 128 + 64, 0, b8c);        // taps (0, 2): windows (0,0) / (0,1)
-            mx_pair(0, cb + a8d2 + 6 * 128, cb + a8d2 + 6 * 128 + 64, -U_PW, b8c);    // taps (6, 8): windows (1,0) / (1,1)
-            mx_pair(1, cb + a8d6 + 1 * 128, cb + a8d6 + 1 * 128 + 64, 0, b8r);        // taps (1, 7): windows (0,0) / (1,0)
-            mx_pair(2, cb + a8d2 + 3 * 128, cb + a8d2 + 3 * 128 + 64, 0, b8c);        // taps (3, 5): windows (0,0) / (0,1)
-            mx_pair(3, h ? U_ZERO : cb + a8c, h ? U_ZERO + 1 : cb + a8c + 64, 0, b8c); // tap 4 alone: zero A record for the K half h = 1 (whatever B it meets)
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- R(P2)
+            h8 B2[2][NTL], A2[3];
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt) { B2[0][nt] = ldh(cur + boff[nt] - U_PW); B2[1][nt] = ldh(cur + boff[nt] - U_PW - 1); }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) A2[k] = ldh(curA + (6 + k) * 128);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- M(P1): window 0 -> taps 0 1 3 4 = phases 0 1 2 3; window 1 -> taps 2 5 = phases 0 2
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int nt = 0; nt < NTL; ++nt) acc[k][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1[k], B1[0][nt], acc[k][nt], 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int nt = 0; nt < NTL; ++nt) acc[2 * k][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A1[4 + k], B1[1][nt], acc[2 * k][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- R(P3)
+            const i8v a02 = ld8(lds + cb + a8d2 + 0 * 128, lds + cb + a8d2 + 0 * 128 + 64);
+            const i8v a35 = ld8(lds + cb + a8d2 + 3 * 128, lds + cb + a8d2 + 3 * 128 + 64);
+            const i8v a4 = ld8(lds + (h ? U_ZERO : cb + a8c), lds + (h ? U_ZERO + 1 : cb + a8c + 64));   // tap 4 alone: zero A record for the K half h = 1 (whatever B it meets)
+            i8v b3[NTL];
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt) b3[nt] = ld8(cur + b8c[nt], cur + b8c[nt] + U_PPLANE);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- M(P2): window 2 -> taps 6 7 = phases 0 1; window 3 -> tap 8 = phase 0
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int nt = 0; nt < NTL; ++nt) acc[k][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A2[k], B2[0][nt], acc[k][nt], 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt) acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A2[2], B2[1][nt], acc[0][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- R(P4): taps (6, 8) = windows (1,0) / (1,1); taps (1, 7) = windows (0,0) / (1,0)
+            pa68 = ld8(lds + cb + a8d2 + 6 * 128, lds + cb + a8d2 + 6 * 128 + 64);
+            pa17 = ld8(lds + cb + a8d6 + 1 * 128, lds + cb + a8d6 + 1 * 128 + 64);
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt) {
+                pb68[nt] = ld8(cur + b8c[nt] - U_PW, cur + b8c[nt] - U_PW + U_PPLANE);
+                pb17[nt] = ld8(cur + b8r[nt], cur + b8r[nt] + U_PPLANE);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- M(P3)
+#pragma unroll
+            for (int nt = 0; nt < NTL; ++nt) {
+                acc[0][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a02, b3[nt], acc[0][nt], 0, 0, 0, kMxScaleA, 0, kMxScaleB);
+                acc[2][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a35, b3[nt], acc[2][nt], 0, 0, 0, kMxScaleA, 0, kMxScaleB);
+                acc[3][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a4, b3[nt], acc[3][nt], 0, 0, 0, kMxScaleA, 0, kMxScaleB);
+            }
+            __builtin_amdgcn_sched_barrier(0);
             continue;
         }
 #pragma unroll
@@ -1164,6 +1217,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void upconv_fir_f16x3_ker
                         acc[p][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[nt], acc[p][nt], 0, 0, 0);
                     }
                 }
+        }
+    }
+    if constexpr (MXIN) {                                           // M(P4) of the last stage
+#pragma unroll
+        for (int nt = 0; nt < NTL; ++nt) {
+            acc[0][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pa68, pb68[nt], acc[0][nt], 0, 0, 0, kMxScaleA, 0, kMxScaleB);
+            acc[1][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pa17, pb17[nt], acc[1][nt], 0, 0, 0, kMxScaleA, 0, kMxScaleB);
         }
     }
 
@@ -1311,7 +1371,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void upconv_fir_f16x3_ker
 #ifdef R3D_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     R3D_STAMP(3);
-    R3D_STAMP_FLUSH(4, 1);
+    R3D_STAMP_FLUSH(6, 1);
 #endif
 }
 R3D_STAMP_READER(r3d_debug_stamps_sr)

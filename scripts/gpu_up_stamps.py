@@ -24,11 +24,11 @@ for (cin, cout, res, seed) in ((32, 256, 128, 100), (256, 128, 256, 200)):
     for _ in range(reps): blk(x, img, ws, noise_mode="none")
     torch.cuda.synchronize(); assert lib.r3d_debug_stamps_sr(buf) == 0
     waves = buf[31]
-    names = ["prologue", "main loop", "FIR epilogue", "store drain"]
-    tot = sum(buf[i] for i in range(4))
+    names = ["prologue", "main loop: compute", "FIR epilogue", "store drain", "main loop: own DMA wait", "main loop: barrier"]
+    tot = sum(buf[i] for i in range(6))
     print("up-conv %d -> %d at %d^2 (%s): %d waves per launch, %.0f cycles per wave" % (cin, cout, res, prec, waves // reps, tot / max(1, waves)))
     for i, n in enumerate(names):
-        print("  %-14s %8.0f cycles  %5.1f %%" % (n, buf[i] / max(1, waves), 100.0 * buf[i] / max(1, tot)))
+        print("  %-24s %8.0f cycles  %5.1f %%" % (n, buf[i] / max(1, waves), 100.0 * buf[i] / max(1, tot)))
     cw = buf[30]; ctot = sum(buf[12 + i] for i in range(4))
     print("  conv1 %d -> %d at %d^2: %d waves per launch, %.0f cycles per wave" % (cout, cout, 2 * res, cw // reps, ctot / max(1, cw)))
     for i, n in enumerate(["prologue", "main loop", "epilogue", "store drain"]):
