@@ -72,4 +72,5 @@ tail -c 600 $O/bench_n1.json; echo; head -8 $O/kernel_stats_streams1.csv | cut -
 ( cd $R/real3dportrait_amd/csrc && true )
 R3D_LIB=$R/real3dportrait_amd/lib/libr3d_hip_stamps.so python $R/scripts/gpu_ray_stamps.py > $O/ray_phase_stamps.txt 2>&1; cat $O/ray_phase_stamps.txt
 R3D_LIB=$R/real3dportrait_amd/lib/libr3d_hip_stamps.so python $R/scripts/gpu_up_stamps.py f16mx > $O/sr_phase_stamps.txt 2>&1; cat $O/sr_phase_stamps.txt
+bash $R/scripts/gpu_power_probe.sh > $O/power_probe.txt 2>&1; cat $O/power_probe.txt
 R3D_SR_PRECISION=f16mx bash $R/scripts/gpu_torso_trace.sh > $O/torso_trace.log 2>&1; cp $R/gpurun_out/torso_trace/torso_kernel_stats.txt $O/ 2>/dev/null; head -12 $O/torso_kernel_stats.txt

@@ -33,3 +33,5 @@ tot = sum(buf[i] for i in range(10))
 print("R=%d %d+%d: %.3f ms per call (instrumented), %d rays, %.0f cycles per ray" % (R, Nc, Nf, ev0.elapsed_time(ev1) / reps, rays // reps, tot / rays))
 for i, n in enumerate(names):
     print("  %-22s %8.0f cycles  %5.1f %%" % (n, buf[i] / rays, 100.0 * buf[i] / tot))
+if buf[29]:
+    print("  the waves ran at %.3f GHz (s_memtime cycles / s_memrealtime ticks x 100 MHz)" % (buf[28] / buf[29] * 0.1))
