@@ -43,6 +43,37 @@ def test_bench_weak_scaling_line_under_torchrun():
         assert "child passes of this run" in r["traffic_source"], r["traffic_source"]
         assert 0.9 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.6, (r["traffic"], r["algorithmic_bytes_per_launch"])
     assert "f16mx" in d["dtype"] and r["precision"] == "f16mx"          # the precision of `value` is selected by name and spelled out
+    # the clock the dominant kernel ran at is measured in the run (one wave per launch: s_memtime / s_memrealtime) and the fraction at that clock is
+    # reported beside `frac`, never instead of it
+    assert r["peak_clock_ghz"] == 2.4 and 0.8 < r["shader_clock_ghz"] <= 2.45, r["shader_clock_ghz"]
+    assert abs(r["frac_at_measured_clock"] - r["frac"] * r["peak_clock_ghz"] / r["shader_clock_ghz"]) < 2e-3 and r["frac_at_measured_clock"] < 1
+    assert set(r["shader_clock_ghz_other_kernels"]) == {"render_kernel", "upconv_fir"} and all(0.8 < v < 2.45 for v in r["shader_clock_ghz_other_kernels"].values())
+
+
+def test_profile_clock_is_zero_until_a_profiled_launch_and_plausible_after():
+    import ctypes
+    import numpy as np
+    import torch
+    from real3dportrait_amd import _lib, synth
+    from real3dportrait_amd.superresolution import Conv2d
+    lib = _lib.load()
+    g, cyc = ctypes.c_double(-1.0), ctypes.c_ulonglong(1)
+    lib.r3d_profile_configure(0); lib.r3d_profile_reset()
+    assert lib.r3d_profile_clock(1, ctypes.byref(g), ctypes.byref(cyc)) == 0 and g.value == 0.0 and cyc.value == 0
+    assert lib.r3d_profile_clock(99, ctypes.byref(g), None) != 0                      # bad family id: error code, no crash
+    c = Conv2d(128, 128, 3, 1, padding=1).cuda()
+    x = torch.from_numpy(synth.hash_unitvar(3, (1, 128, 256, 256), stream=1)).cuda()
+    y0 = c(x, out_format="cb8").clone()                                                # not profiled: nothing sampled
+    torch.cuda.synchronize()
+    assert lib.r3d_profile_clock(1, ctypes.byref(g), None) == 0 and g.value == 0.0
+    lib.r3d_profile_configure(1 << 1); lib.r3d_profile_reset()
+    for _ in range(20):
+        y1 = c(x, out_format="cb8")
+    torch.cuda.synchronize()
+    assert lib.r3d_profile_clock(1, ctypes.byref(g), ctypes.byref(cyc)) == 0
+    lib.r3d_profile_configure(0)
+    assert 0.5 < g.value < 2.6 and cyc.value > 20 * 10000, (g.value, cyc.value)          # GHz of the sampled waves; 20 launches x >= 10 k cycles each
+    assert torch.equal(y0, y1)                                                         # sampling does not touch the result
 
 
 def test_bench_clip_mode_uneven_tail_under_torchrun():
