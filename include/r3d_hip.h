@@ -278,7 +278,8 @@ int r3d_blend_cat_to_split(const float* a, int a_format, int Ca, const float* b,
 
 /* torch.nn.UpsamplingBilinear2d(scale_factor=2) (align_corners=True), the resampling step inside to_plane_cnn
  * (modules/real3d/segformer.py:691-700), between two r3d_conv_forward layers: x fp32 channel-blocked [N,C/8,H,W,8] ->
- * y at 2H x 2W in R3D_FMT_CB8 or R3D_FMT_SPLIT (scaled by next_scale, NULL = 1).  C % 8 == 0. */
+ * y at 2H x 2W in R3D_FMT_CB8, R3D_FMT_SPLIT or R3D_FMT_SPLIT_MX (scaled by next_scale, NULL = 1; SPLIT_MX -- the consumer runs the f16mx
+ * main loop -- needs C % 16 == 0).  C % 8 == 0. */
 int r3d_upsample2x_bilinear(const float* x_cb8, int N, int C, int H, int W, void* y, int y_format,
                             const float* next_scale, size_t next_scale_stride, r3d_stream_t stream);
 

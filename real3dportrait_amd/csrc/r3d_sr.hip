@@ -841,7 +841,8 @@ extern "C" int r3d_upsample2x_bilinear(const float* x_cb8, int N, int C, int H, 
 {
     using namespace r3d;
     if (!x_cb8 || !y || N <= 0 || C <= 0 || (C & 7) || H <= 0 || W <= 0) { set_error("upsample2x_bilinear: bad argument (C %d must be a multiple of 8)", C); return R3D_ERR_INVALID_ARG; }
-    if (y_format != R3D_FMT_CB8 && y_format != R3D_FMT_SPLIT) { set_error("upsample2x_bilinear: y_format %d must be CB8 or SPLIT", y_format); return R3D_ERR_INVALID_ARG; }
+    if (y_format != R3D_FMT_CB8 && y_format != R3D_FMT_SPLIT && y_format != R3D_FMT_SPLIT_MX) { set_error("upsample2x_bilinear: y_format %d must be CB8, SPLIT or SPLIT_MX", y_format); return R3D_ERR_INVALID_ARG; }
+    if (y_format == R3D_FMT_SPLIT_MX && (C & 15)) { set_error("upsample2x_bilinear: SPLIT_MX needs C %% 16 == 0 (C %d)", C); return R3D_ERR_INVALID_ARG; }
     return upsample2x_bilinear_f16x3(x_cb8, N, C, H, W, y, y_format, next_scale, next_scale_stride, (hipStream_t)stream);
 }
 

@@ -611,7 +611,7 @@ typedef int i8v __attribute__((ext_vector_type(8)));
 template <bool FULL_EPI, bool MX = false, int TH = F_TILE_H>
 __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const ConvPhase& ph, int n, uint4* lds)
 {
-    static_assert(TH == 16 || (TH == 8 && !MX), "tile rows");
+    static_assert(TH == 16 || TH == 8, "tile rows");
     constexpr int WN = 4, NT = TH / 8;
     constexpr int PATCH_PIX = (TH + 2) * F_PATCH_W;                  // 324 | 180
     constexpr int PSEGS = (4 * PATCH_PIX + 63) / 64;                 // 21 | 12 DMA segments of 64 slots
@@ -876,10 +876,11 @@ __global__ __launch_bounds__(128 * WN, OCC) void conv_mfma_f16x3_kernel(Conv2Arg
 
 // the same conv on 8x16-pixel tiles (conv3x3_dma_block TH = 8), for launches that would fill less than half of the chip's block slots
 static constexpr int F3S_LDS_UINT4 = 2 * 768 + 2 * W2_BUF;           // 57.3 KB
+template <bool MX = false>
 __global__ __launch_bounds__(512, 4) void conv_mfma_f16x3_rows8_kernel(Conv2Args a)
 {
     __shared__ uint4 lds[F3S_LDS_UINT4];
-    conv3x3_dma_block<true, false, 8>(a, a.ph[0], blockIdx.z, lds);
+    conv3x3_dma_block<true, MX, 8>(a, a.ph[0], blockIdx.z, lds);
 }
 
 // 1x1 conv with the full epilogue (nn.Conv2d(k=1) layers of the torso/background fusion stack)
@@ -1576,7 +1577,7 @@ int blend_cat_to_split_f16x3(const float* a, int a_format, int Ca, const float* 
 // (modules/real3d/segformer.py:691-700): fp32 channel-blocked in -> SPLIT (or fp32 channel-blocked) out at 2H x 2W.
 // Source index = dst * (in - 1) / (out - 1), lambda in fp32, as ATen's upsample_bilinear2d (area_pixel_compute_scale).
 __global__ void upsample2x_bilinear_kernel(const float* __restrict__ x, uint4* __restrict__ y_split, float* __restrict__ y_cb8,
-                                           const float* __restrict__ next_scale, size_t next_scale_stride_n, int C, int H, int W)
+                                           const float* __restrict__ next_scale, size_t next_scale_stride_n, int C, int H, int W, int mx)
 {
     const int n = blockIdx.z, cb = blockIdx.y;
     const int OH = 2 * H, OW = 2 * W;
@@ -1607,15 +1608,26 @@ __global__ void upsample2x_bilinear_kernel(const float* __restrict__ x, uint4* _
     }
     if (y_split) {
         h8 hi, lo;
+        float hf[8], lf[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
             const float sc = next_scale ? next_scale[n * next_scale_stride_n + cb * 8 + c] : 1.f;
-            _Float16 a, b; split1(v[c] * sc, a, b); hi[c] = a; lo[c] = b;
+            const float t = as_rounded(v[c] * sc);                 // (= split1, with the fp32 residual kept for the fp8 records)
+            const float cl = fminf(fmaxf(t, -65504.f), 65504.f);
+            hi[c] = (_Float16)cl; hf[c] = (float)hi[c]; lf[c] = t - hf[c]; lo[c] = (_Float16)lf[c];
         }
-        const size_t plane = (size_t)(C / 8) * OH * OW;
-        uint4* d = y_split + (size_t)n * 2 * plane + (size_t)cb * OH * OW + p;
+        const size_t plane = (size_t)(C / 8) * OH * OW, HW = (size_t)OH * OW;
+        uint4* d = y_split + (size_t)n * 2 * plane + (size_t)cb * HW + p;
         d[0] = *reinterpret_cast<uint4*>(&hi);
-        d[plane] = *reinterpret_cast<uint4*>(&lo);
+        if (mx) {                                                   // R3D_FMT_SPLIT_MX: this chunk's dwords (cb & 1) and 2 + (cb & 1) of the group's two records (blend_cat_to_split_kernel)
+            unsigned* rec = reinterpret_cast<unsigned*>(y_split + (size_t)n * 2 * plane + plane + (size_t)(cb & ~1) * HW + p) + (cb & 1);
+            rec[0] = pack4_fp8(hf[0] * kMxXh, hf[1] * kMxXh, hf[2] * kMxXh, hf[3] * kMxXh);
+            rec[2] = pack4_fp8(hf[4] * kMxXh, hf[5] * kMxXh, hf[6] * kMxXh, hf[7] * kMxXh);
+            rec[4 * HW] = pack4_fp8(lf[0] * kMxXl, lf[1] * kMxXl, lf[2] * kMxXl, lf[3] * kMxXl);
+            rec[4 * HW + 2] = pack4_fp8(lf[4] * kMxXl, lf[5] * kMxXl, lf[6] * kMxXl, lf[7] * kMxXl);
+        } else {
+            d[plane] = *reinterpret_cast<uint4*>(&lo);
+        }
     }
 }
 
@@ -1624,8 +1636,9 @@ int upsample2x_bilinear_f16x3(const float* x_cb8, int N, int C, int H, int W, vo
 {
     ProfScope ps(R3D_PROF_LAYOUT, st);
     hipLaunchKernelGGL(upsample2x_bilinear_kernel, dim3((4 * H * W + 255) / 256, C / 8, N), dim3(256), 0, st, x_cb8,
-                       y_format == R3D_FMT_SPLIT ? reinterpret_cast<uint4*>(y) : nullptr,
-                       y_format == R3D_FMT_CB8 ? reinterpret_cast<float*>(y) : nullptr, next_scale, next_scale_stride, C, H, W);
+                       (y_format == R3D_FMT_SPLIT || y_format == R3D_FMT_SPLIT_MX) ? reinterpret_cast<uint4*>(y) : nullptr,
+                       y_format == R3D_FMT_CB8 ? reinterpret_cast<float*>(y) : nullptr, next_scale, next_scale_stride, C, H, W,
+                       y_format == R3D_FMT_SPLIT_MX ? 1 : 0);
     return check_launch("upsample2x_bilinear");
 }
 
@@ -1672,11 +1685,12 @@ static void launch_conv2(Conv2Args& a, int tiles, int N, hipStream_t st, bool mx
     a.clk = prof_clock_slot(R3D_PROF_CONV);
     dim3 grid(tiles, a.Cout / BLOCK_M, N * a.nphase);
     static const int rows8 = getenv("R3D_CONV_ROWS8") ? atoi(getenv("R3D_CONV_ROWS8")) : 1;   // A/B switch: 0 = always 16x16 tiles
-    if (rows8 && (rows8 == 1 || (rows8 == 2 && !a.rgb_partial) || (rows8 == 3 && a.rgb_partial)) && !mx && a.nphase == 1 && a.ph[0].ntaps == 9 && (size_t)tiles * grid.y * grid.z <= 256) {
+    if (rows8 && (rows8 == 1 || (rows8 == 2 && !a.rgb_partial) || (rows8 == 3 && a.rgb_partial)) && a.nphase == 1 && a.ph[0].ntaps == 9 && (size_t)tiles * grid.y * grid.z <= 256) {
         // under-filled launch (<= half of the 512 block slots): 8x16-pixel tiles, twice the blocks (bit-identical results)
         const int t8 = ((a.ph[0].outW + F_TILE_W - 1) / F_TILE_W) * ((a.ph[0].outH + 7) / 8);
         a.order = (t8 & 7) == 0 ? 2 : 0;
-        hipLaunchKernelGGL(conv_mfma_f16x3_rows8_kernel, dim3(t8, grid.y, grid.z), dim3(512), 0, st, a);
+        if (mx) hipLaunchKernelGGL(conv_mfma_f16x3_rows8_kernel<true>, dim3(t8, grid.y, grid.z), dim3(512), 0, st, a);     // (round 4: to_plane_cnn's 128^2 layers on MX)
+        else hipLaunchKernelGGL(conv_mfma_f16x3_rows8_kernel<false>, dim3(t8, grid.y, grid.z), dim3(512), 0, st, a);
         return;
     }
     static const int shape = getenv("R3D_CONV_SHAPE") ? atoi(getenv("R3D_CONV_SHAPE")) : 0;   // tuning switch, default 0

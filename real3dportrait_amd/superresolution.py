@@ -103,6 +103,9 @@ def set_sr_precision(module, precision):
 MAX_DEPTH = 3      # a stored fp16 operand may be at most this many conv layers away from a measured / known max|x|
 
 
+MX_MAX_DEPTH = 2     # f16mx main loops only within this many layers of a measured bound (ConvStack.forward)
+
+
 def bound_of(x, meter, layers=1):
     """(bound, depth) of an fp32 activation that is about to enter a chain of `layers` conv layers folded together.  The propagated
     bound loosens ~5 binades per layer and the fp16 window has ~16, so a tag (`_r3d_bound`, `_r3d_depth` = layers since the last
@@ -493,14 +496,14 @@ class Conv2d(nn.Module):
 
 def upsample2x_bilinear(x, out_format="split", _next=None):
     """torch.nn.UpsamplingBilinear2d(scale_factor=2.) (align_corners=True) on a channel-blocked fp32 activation
-    (r3d_upsample2x_bilinear); output 'split' (input of the conv `_next`, already folded) or 'cb8'."""
+    (r3d_upsample2x_bilinear); output 'split' / 'split_mx' (input of the conv `_next`, already folded) or 'cb8'."""
     lib = _lib.load()
     assert getattr(x, "_r3d_fmt", None) == "cb8", "upsample2x_bilinear takes the 'cb8' output of a Conv2d"
     bx, dx = getattr(x, "_r3d_bound", None), int(getattr(x, "_r3d_depth", 0))
     x = x.contiguous()
     N, C8, H, W, _ = x.shape
     next_scale, next_stride = None, 0
-    if out_format == "split":
+    if out_format in ("split", "split_mx"):
         assert _next is not None
         next_scale, next_stride = _next.in_scale()
         y = torch.empty(N, 2, C8, 2 * H, 2 * W, 8, device=x.device, dtype=torch.float16)
@@ -509,7 +512,7 @@ def upsample2x_bilinear(x, out_format="split", _next=None):
     _lib.check(lib.r3d_upsample2x_bilinear(_lib.ptr(x), N, C8 * 8, H, W, _lib.ptr(y), SynthesisBlock._FMT[out_format],
                                            _lib.ptr(next_scale), next_stride, _lib.stream_ptr()), "upsample2x_bilinear")
     y._r3d_fmt = out_format
-    if out_format == "split":
+    if out_format in ("split", "split_mx"):
         y._r3d_for = _next
     elif bx is not None:
         _tag(y, bx, dx)            # a convex combination does not raise the bound
@@ -660,6 +663,7 @@ class ConvStack(nn.Sequential):
         _y_absmax: device float[N] slot the last conv measures max|y| into (zeroed by a preceding fold)."""
         plan = self._plan()
         x_fmt = getattr(x, "_r3d_fmt", "nchw")
+        dx = int(getattr(x, "_r3d_depth", 0))
         if x_fmt in ("split", "split_mx"):
             if getattr(x, "_r3d_for", None) is not plan[0][0]:
                 raise RuntimeError("SPLIT activation was scaled for a different consumer")
@@ -671,10 +675,15 @@ class ConvStack(nn.Sequential):
             self.fold_for_input(x.shape[0], x.device, [bx], depth=dx)
         for k, (m, slope, up) in enumerate(plan):
             nxt = plan[k + 1][0] if k + 1 < len(plan) else None
+            # The fp8 records carry ONE exponent per tensor (the fold's bound), and a bound propagated through the layers' L1 norms loosens by
+            # ~5 binades per layer: three layers from a measurement the typical operand sits 2^15 under its bound, xh8 = e4m3(hi * 2^-7) is a
+            # subnormal and the layer's cross products are noise (to_plane_cnn's last conv at full size: 3.4e-4 of max|ref| instead of 2.8e-5,
+            # tests/test_gpu_mx.py) -- so a layer whose operand is more than MX_MAX_DEPTH layers from a measured bound runs f16x3.
+            mx_next = nxt is not None and nxt.wants_mx() and m.out_channels % 16 == 0 and dx + k + 1 <= MX_MAX_DEPTH
             if up:
-                x = upsample2x_bilinear(m(x, negative_slope=slope, out_format="cb8", _folded=True), "split", _next=nxt)
+                x = upsample2x_bilinear(m(x, negative_slope=slope, out_format="cb8", _folded=True), "split_mx" if mx_next else "split", _next=nxt)
             elif nxt is not None and m.out_channels % 16 == 0:
-                x = m(x, negative_slope=slope, out_format="split_mx" if nxt.wants_mx() else "split", _next=nxt, _folded=True)
+                x = m(x, negative_slope=slope, out_format="split_mx" if mx_next else "split", _next=nxt, _folded=True)
             elif nxt is not None:
                 raise NotImplementedError("ConvStack: inner layers need out_channels % 16 == 0")
             else:

@@ -14,7 +14,7 @@ import test_gpu_warp_sr as tw
 
 pytestmark = pytest.mark.gpu
 
-WITH_TORCH = [tp.test_synthesis_golden, tp.test_fusion_stacks_golden, tp.test_sr_rgb_skip_is_linear,
+WITH_TORCH = [tp.test_synthesis_golden, tp.test_fusion_stacks_golden, tp.test_to_plane_cnn_golden, tp.test_sr_rgb_skip_is_linear,
               tp.test_sr_concurrent_streams_are_bit_identical, tp.test_multi_stream_pipeline_is_bit_identical,
               tp.test_ray_kernel_split_output_equals_conversion_launch, tp.test_synthesis_batch_of_two_equals_two_singles,
               tr.test_sr_cfg5_golden, tr.test_fusion_stacks_full_size_golden, tr.test_fused_u8_epilogue_equals_reference_formula,

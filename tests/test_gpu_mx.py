@@ -1,4 +1,4 @@
-"""GPU parity (`-m gpu`) of the 'f16mx' SR precision (the default since the end of round 3): f16x3 with the correction products of each
+"""GPU parity (`-m gpu`) of the 'f16mx' SR precision (the throughput tier, selected by name; the default at the end of round 3): f16x3 with the correction products of each
 block's 3x3 conv on the block-scaled fp8 MFMA.  Own, stated tolerance tier: the correction is accurate to fp8 rounding (~2^-16 of each
 product), so
 
@@ -109,3 +109,42 @@ def test_sr_block_range_sweep_f16mx(what, k):
     ei = (io.cpu().double() - ri).abs().max().item() / max(ri.abs().max().item(), 1e-300)
     assert torch.isfinite(xo).all() and torch.isfinite(io).all()
     assert ex <= 1e-4 and ei <= 1e-4, (what, k, ex, ei)
+
+
+def test_to_plane_stack_f16mx_full_size_batch_equals_singles_and_fp64():
+    """to_plane_cnn at its real size (256 ch, 128^2 -> 256^2) under f16mx: a single sample runs the under-filled layers on the 8-row MX tiles
+    (conv_mfma_f16x3_rows8_kernel<true>: 256 blocks), a batch of three on the 16x16 MX tiles --
+    the same K order per output, so the batch must equal its samples bit for bit; and both stay in the tier against torch fp64."""
+    import torch
+    from real3dportrait_amd import synth
+    from real3dportrait_amd.superresolution import Conv2d, ConvStack, set_sr_precision
+    seed, r = 11, 128
+    mods, ref_mods = [], []
+    for i, ((ci, co, k, lrelu), (w, b)) in enumerate(zip(synth.TO_PLANE_CNN, synth.synth_conv_stack(seed, synth.TO_PLANE_CNN, 500))):
+        if i == synth.TO_PLANE_CNN_UP_BEFORE:
+            mods.append(torch.nn.UpsamplingBilinear2d(scale_factor=2.)); ref_mods.append(torch.nn.UpsamplingBilinear2d(scale_factor=2.))
+        c = Conv2d(ci, co, k, 1, padding=1); rc = torch.nn.Conv2d(ci, co, k, 1, padding=1)
+        with torch.no_grad():
+            c.weight.copy_(torch.from_numpy(w)); c.bias.copy_(torch.from_numpy(b)); rc.weight.copy_(torch.from_numpy(w)); rc.bias.copy_(torch.from_numpy(b))
+        mods.append(c); ref_mods.append(rc)
+        if lrelu:
+            mods.append(torch.nn.LeakyReLU(0.01)); ref_mods.append(torch.nn.LeakyReLU(0.01))
+    cnn = ConvStack(*mods).cuda()
+    set_sr_precision(cnn, "f16mx")
+    assert all(m.wants_mx() for m in cnn.modules() if isinstance(m, Conv2d))
+    x = torch.from_numpy(synth.hash_unitvar(seed, (3, 256, r, r), stream=1)).cuda()
+    x[1] *= 0.25; x[2] *= 8.0                                                   # per-sample folds differ
+    yb = cnn(x).clone()
+    for n in range(3):
+        y1 = cnn(x[n:n + 1].contiguous())
+        assert torch.equal(y1[0], yb[n]), "sample %d: batch (16x16 MX tiles) != single (8-row MX tiles)" % n
+    ref = torch.nn.Sequential(*ref_mods).double()
+    with torch.no_grad():
+        yr = ref(x[:1].double().cpu())
+    e = float((yb[:1].double().cpu() - yr).abs().max() / yr.abs().max())
+    print("to_plane_cnn f16mx at 128^2 -> 256^2 vs fp64: %.2e of max|ref|" % e)
+    # 2.8e-5 measured.  (With the LAST conv on MX as well -- three layers from the measured input bound -- it was 3.4e-4: the records' single exponent
+    # sits 2^15 above the typical operand there, superresolution.MX_MAX_DEPTH.)
+    assert e <= MX_TOL, e
+    convs = [m for m in cnn.modules() if isinstance(m, Conv2d)]
+    assert len(convs) == 4
