@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 WITH_TORCH = [tp.test_synthesis_golden, tp.test_fusion_stacks_golden, tp.test_to_plane_cnn_golden, tp.test_sr_rgb_skip_is_linear,
               tp.test_sr_concurrent_streams_are_bit_identical, tp.test_multi_stream_pipeline_is_bit_identical,
               tp.test_ray_kernel_split_output_equals_conversion_launch, tp.test_synthesis_batch_of_two_equals_two_singles,
-              tr.test_sr_cfg5_golden, tr.test_fusion_stacks_full_size_golden, tr.test_fused_u8_epilogue_equals_reference_formula,
+              tr.test_sr_cfg5_golden, tr.test_fusion_stacks_full_size_golden, tr.test_to_plane_cnn_full_size_golden, tr.test_fused_u8_epilogue_equals_reference_formula,
               tr.test_synthesis_mask_invalid_rays_golden, tr.test_bounds_are_upper_bounds_and_stored_operands_fit_fp16]
 PLAIN = [tw.test_warp_sr_forward_v2_golden, tw.test_torso_frame_fused_input_equals_unfused_sequence,
          tw.test_warp_sr_forward_v2_batch_of_two_equals_two_singles]

@@ -9,6 +9,8 @@
 
 Tolerances: as in test_gpu_parity.py (SR <= 2e-4 * max(1, max|ref|)); range sweeps <= 2e-5 * max|ref| (fp32-rounding class).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -101,6 +103,7 @@ def test_fusion_stacks_full_size_golden(torch_cuda):
                      (rgb2.cpu().numpy()[:, :, ::4, ::4], "rgb2"), (cr(x1), "x1_crop"), (cr(x3), "x3_crop")):
         ref = g[key]
         assert got.shape == ref.shape, key
+        print("fusion stacks at 256^2 [%s] %-8s err %.2e of max(1, max|ref|)" % (os.environ.get("R3D_SR_PRECISION", "default"), key, np.abs(got - ref).max() / max(1.0, np.abs(ref).max())))
         assert np.abs(got - ref).max() <= SR_TOL * max(1.0, np.abs(ref).max()), key
 
 
