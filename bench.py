@@ -281,6 +281,32 @@ def build_torso_frame(torch, dev, G, seed=7, fused_input=True, precision=None):
     return frame, fl
 
 
+def sustained_mix_probe(conv_tflops, seconds=1.5):
+    """What the f16mx conv's MFMA mix (2 f16 + 1 block-scaled fp8 MFMA per 2 taps x 16 channels and tile) sustains on this board for `seconds` per
+    variant when only the matrix pipe -- and then its LDS feed -- is busy: constant register operands, random register operands, random operands from
+    LDS at the conv's read ratio.  No memory traffic, barrier or epilogue in any of them; the board clocks each to its power budget.  The dominant
+    kernel's algorithmic rate is reported as a fraction of the LDS-fed variant beside `roofline.frac`."""
+    import re, subprocess
+    exe = os.path.join(ROOT, "scripts", "probes", "bin", "power_ceiling_probe")
+    if not os.path.exists(exe):
+        return {"skipped": "scripts/probes/bin/power_ceiling_probe not built (__graft_entry__.build())"}
+    try:
+        txt = subprocess.run([exe, str(seconds)], capture_output=True, text=True, timeout=120).stdout
+    except Exception as e:      # noqa: BLE001
+        return {"skipped": "probe failed: %r" % (e,)}
+    res = {"what": "scripts/probes/power_ceiling_probe.hip, %.1f s per variant, 4 waves/SIMD x 64 accumulators (the conv's shape); algorithmic TFLOP/s of the "
+                   "f16mx MFMA mix, the clock its waves ran at and the socket power meanwhile" % seconds}
+    for line in txt.splitlines():
+        m = re.match(r"(R0|R1|L1):.*?([0-9.]+) ms/launch\s+([0-9.]+) algorithmic TFLOP/s = ([0-9.]+) of 2500 .*?waves at ([0-9.]+) GHz\s+socket\s+([0-9.]+) W", line)
+        if m:
+            res[{"R0": "registers_constant", "R1": "registers_random", "L1": "lds_fed_random"}[m.group(1)]] = {
+                "tflops": float(m.group(3)), "frac_of_f16_peak": float(m.group(4)), "wave_clock_ghz": float(m.group(5)), "socket_w": float(m.group(6))}
+    if conv_tflops and "lds_fed_random" in res and res["lds_fed_random"]["tflops"] > 0:
+        res["dominant_kernel_vs_lds_fed_mix"] = round(conv_tflops / res["lds_fed_random"]["tflops"], 3)
+        res["dominant_kernel_vs_register_random_mix"] = round(conv_tflops / res["registers_random"]["tflops"], 3) if "registers_random" in res else None
+    return res
+
+
 def power_probe(torch, step, sync, K, seconds=3.0):
     """Socket power and sclk as rocm-smi reports them while the headline frame loop runs (a sampler thread polls the CLI; the GPU work is not
     touched).  The frame loop of this path runs AT THE BOARD'S POWER CAP: frames/s is joules per frame, and the MFMA peaks -- quoted at the
@@ -811,6 +837,10 @@ def main():
     # ---- what the power management reports while the headline loop runs (extras; ~3 s of the same pipelined frames) ----------------------
     if rank == 0 and world == 1 and not args.no_extras:
         out["power"] = power_probe(torch, lambda i: step(i % K), (lambda: pipe.sync()) if pipe is not None else torch.cuda.synchronize, K)
+
+    # ---- the sustained rate of the dominant kernel's MFMA mix on THIS board with nothing else busy (scripts/probes/power_ceiling_probe.hip) ----
+    if rank == 0 and world == 1 and not args.no_extras:
+        out["mfma_mix_sustained"] = sustained_mix_probe(achieved_tf if prec == "f16mx" else None)
 
     # ---- BASELINE configs[2] on one GPU and configs[4] (stress) -- extras, rank 0 of a 1-GPU run ----------------------------------------
     if rank == 0 and world == 1 and not args.no_extras:
