@@ -48,7 +48,7 @@ __global__ __launch_bounds__(512, 4) void mix_kernel(float* out, int iters, unsi
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {                               // one conv sub-stage (2 taps x 16 channels) for the wave's 4 tiles: 8 f16 + 4 fp8 MFMAs
-            if (VAR == 1) {                                         // new bits in every operand register (24 xors per 512 MFMA cycles)
+            if (VAR == 1 || VAR >= 3) {                             // new bits in every operand register (24 xors per 512 MFMA cycles)
                 const unsigned k = rnd();
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { ah[j] = f16pair(ah[j] ^ (k * (2 * j + 1))); bh[j] = f16pair(bh[j] ^ (k * (2 * j + 3))); }
@@ -69,6 +69,27 @@ __global__ __launch_bounds__(512, 4) void mix_kernel(float* out, int iters, unsi
                     const i8v A8 = {(int)fp8quad(q0[0]), (int)fp8quad(q0[1]), (int)q0[2], (int)q0[3], (int)fp8quad(q1[0]), (int)fp8quad(q1[1]), (int)q1[2], (int)q1[3]};
                     const i8v B8 = {(int)fp8quad(p0[0]), (int)fp8quad(p0[1]), (int)p0[2], (int)p0[3], (int)fp8quad(p1[0]), (int)fp8quad(p1[1]), (int)p1[2], (int)p1[3]};
                     c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A8, B8, c[t], 0, 0, 0, 116, 0, 127);
+                }
+            } else if (VAR == 3) {                                  // the mix with the cross products on fp6 e2m3 (same K = 64, half the passes; operands: 24 of the 32 bytes)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    c[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const h8*)&ah, *(const h8*)&bh, c[t], 0, 0, 0);
+                    c[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const h8*)&bh, *(const h8*)&ah, c[t], 0, 0, 0);
+                    c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c[t], 2, 2, 0, 116, 0, 127);
+                }
+            } else if (VAR == 4) {                                  // f16 MFMAs only (4 per tile: the same matrix cycles as the mix)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    c[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const h8*)&ah, *(const h8*)&bh, c[t], 0, 0, 0);
+                    c[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const h8*)&bh, *(const h8*)&ah, c[t], 0, 0, 0);
+                    c[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const h8*)&ah, *(const h8*)&bh, c[t], 0, 0, 0);
+                    c[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const h8*)&bh, *(const h8*)&ah, c[t], 0, 0, 0);
+                }
+            } else if (VAR == 5) {                                  // fp8 K = 64 MFMAs only (2 per tile: the same matrix cycles)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8, b8, c[t], 0, 0, 0, 116, 0, 127);
+                    c[t] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(b8, a8, c[t], 0, 0, 0, 116, 0, 127);
                 }
             } else {
 #pragma unroll
@@ -139,5 +160,10 @@ int main(int argc, char** argv)
     run<0>("R0: f16mx MFMA mix, operands in registers, constant", d, sec);
     run<1>("R1: ... operands in registers, re-randomised every sub-stage", d, sec);
     run<2>("L1: ... operands from LDS (16 ds_read_b128 per 12 MFMAs), random", d, sec);
+    if (argc > 2) {                                                 // the instruction types on their own (TFLOP/s figures of these lines: read "matrix passes", see below)
+        run<3>("X6: the mix with the cross products on fp6 (registers, random)", d, sec);
+        run<4>("XF: f16 MFMAs only, 4 per tile and sub-stage (registers, random)", d, sec);
+        run<5>("X8: fp8 K=64 MFMAs only, 2 per tile and sub-stage (registers, random)", d, sec);
+    }
     return 0;
 }
