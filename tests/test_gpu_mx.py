@@ -148,3 +148,44 @@ def test_to_plane_stack_f16mx_full_size_batch_equals_singles_and_fp64():
     assert e <= MX_TOL, e
     convs = [m for m in cnn.modules() if isinstance(m, Conv2d)]
     assert len(convs) == 4
+
+
+@pytest.mark.parametrize("cout", [128, 96])
+def test_conv_up_conv_stack_f16mx_records_from_the_upsampling_step(cout):
+    """conv -> UpsamplingBilinear2d(2) -> conv under f16mx: the second conv's operand is one layer from the measured input bound, so the bilinear
+    step writes R3D_FMT_SPLIT_MX (fp8 records next to the hi plane) and the conv runs the MX main loop -- also with a padded cout tile (96 -> 128)."""
+    import torch
+    from real3dportrait_amd import synth
+    from real3dportrait_amd.superresolution import Conv2d, ConvStack, set_sr_precision, upsample2x_bilinear
+    plan = [(256, 256, 3, True), (256, cout, 3, False)]
+    mods, ref_mods = [], []
+    for i, ((ci, co, k, lrelu), (w, b)) in enumerate(zip(plan, synth.synth_conv_stack(5, plan, 700))):
+        if i == 1:
+            mods.append(torch.nn.UpsamplingBilinear2d(scale_factor=2.)); ref_mods.append(torch.nn.UpsamplingBilinear2d(scale_factor=2.))
+        c = Conv2d(ci, co, k, 1, padding=1); rc = torch.nn.Conv2d(ci, co, k, 1, padding=1)
+        with torch.no_grad():
+            c.weight.copy_(torch.from_numpy(w)); c.bias.copy_(torch.from_numpy(b)); rc.weight.copy_(torch.from_numpy(w)); rc.bias.copy_(torch.from_numpy(b))
+        mods.append(c); ref_mods.append(rc)
+        if lrelu:
+            mods.append(torch.nn.LeakyReLU(0.01)); ref_mods.append(torch.nn.LeakyReLU(0.01))
+    cnn = ConvStack(*mods).cuda()
+    set_sr_precision(cnn, "f16mx")
+    seen = []
+    import real3dportrait_amd.superresolution as srmod
+    orig = srmod.upsample2x_bilinear
+
+    def spy(x, out_format="split", _next=None):
+        seen.append(out_format)
+        return orig(x, out_format, _next=_next)
+    srmod.upsample2x_bilinear = spy
+    try:
+        x = torch.from_numpy(synth.hash_unitvar(3, (2, 256, 48, 40), stream=1)).cuda()
+        y = cnn(x)
+    finally:
+        srmod.upsample2x_bilinear = orig
+    assert seen == ["split_mx"], seen
+    with torch.no_grad():
+        yr = torch.nn.Sequential(*ref_mods).double()(x.double().cpu())
+    e = float((y.double().cpu() - yr).abs().max() / yr.abs().max())
+    print("conv -> up -> conv(%d) f16mx vs fp64: %.2e of max|ref|" % (cout, e))
+    assert e <= MX_TOL, e
