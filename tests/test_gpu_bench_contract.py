@@ -80,3 +80,23 @@ def test_bench_clip_mode_uneven_tail_under_torchrun():
     d = _run(["--gpus", "1", "--clip", "7", "--warmup", "2", "--no-extras", "--no-cpu-baseline"], torchrun=True)
     assert d["scaling"] == "strong" and d["config"]["frames_total"] == 7 and d["steps"] == 7
     assert d["value"] > 100
+
+
+def test_sustained_mix_probe_and_power_probe_report_plausible_numbers():
+    """bench.py's two board-level legs (extras): the f16mx MFMA mix sustained from registers / from LDS, and rocm-smi's power while frames render."""
+    import shutil
+    import time
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    r = bench.sustained_mix_probe(600.0, seconds=0.6)
+    assert "skipped" not in r, r                                          # __graft_entry__.build() builds the probe
+    for k in ("registers_constant", "registers_random", "lds_fed_random"):
+        v = r[k]
+        assert 100 < v["tflops"] < 1300 and 0.04 < v["frac_of_f16_peak"] < 0.52 and 0.8 < v["wave_clock_ghz"] < 2.45, (k, v)
+    assert r["registers_constant"]["tflops"] >= r["lds_fed_random"]["tflops"]          # data that never toggles is the cheapest to multiply
+    assert 0.3 < r["dominant_kernel_vs_lds_fed_mix"] < 1.5
+    if shutil.which("rocm-smi"):
+        x = torch.randn(4096, 4096, device="cuda")
+        p = bench.power_probe(torch, lambda i: x @ x, torch.cuda.synchronize, 8, seconds=1.5)
+        assert "skipped" in p or (50 < p["socket_power_w_mean"] < 1500 and 300 < p["sclk_mhz_mean"] < 2500 and p["samples"] >= 1), p
