@@ -76,6 +76,7 @@ class ChainOp(ctypes.Structure):
 
 CHAIN_SR_BLOCK, CHAIN_CONV, CHAIN_SR_BLOCK_TAIL, CHAIN_SRC_NONE, CHAIN_MAX_OPS, CHAIN_MAX_EXT, CHAIN_MAX_ZERO = 0, 1, 2, -1000, 12, 4, 4
 
+ABI_VERSION = 50          # r3d_version() of the library this table mirrors (include/r3d_hip.h)
 _lib = None
 
 
@@ -107,6 +108,9 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError if the ABI and this table drift apart
         fn.restype, fn.argtypes = res, args
+    if lib.r3d_version() != ABI_VERSION:      # a stale in-tree build (real3dportrait_amd/lib/ is not tracked): arguments would be shifted silently
+        raise RuntimeError("real3dportrait_amd: %s reports ABI %d, this package binds ABI %d -- rebuild it (`make -C %s`)"
+                           % (LIB_PATH, lib.r3d_version(), ABI_VERSION, CSRC))
     _lib = lib
     return lib
 

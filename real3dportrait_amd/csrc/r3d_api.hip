@@ -143,7 +143,7 @@ __global__ void person_occlusion_kernel(const float* __restrict__ alpha, const f
 
 using namespace r3d;
 
-extern "C" int r3d_version(void) { return 40; }   // 0.4.0: R3D_FMT_SPLIT_MX (f16mx on the up-sampling conv, SynthesisBlockNoUp and the plain 3x3 convs), r3d_blend_cat_to_split y_format
+extern "C" int r3d_version(void) { return 50; }   // 0.5.0: the activation records of R3D_FMT_SPLIT_MX are OCP e5m2 (0.4.0: e4m3 of hi * 2^-7); real3dportrait_amd/_lib.py checks the number
 
 extern "C" int r3d_resize_bilinear(const float* x, int planes, int H, int W, float* y, int OH, int OW, int antialias, r3d_stream_t stream)
 {

@@ -52,14 +52,21 @@ __device__ __forceinline__ void split1_folded(float v, _Float16& hi, _Float16& l
 
 // ---- "f16mx": the two 2^-11-sized correction products on the block-scaled fp8 MFMA (R3D_SR_F16MX) -------------------------------------
 // A product is x*w = xh*wh + (xh*wl + xl*wh) (+ xl*wl ~ 2^-22, dropped as in f16x3).  f16x3 spends two f16 MFMAs per K = 16 on the bracket;
-// here the bracket of TWO taps x 16 channels is ONE v_mfma_scale_f32_32x32x64_f8f6f4 (OCP e4m3, 2x the f16 rate):
-//     B lane (pixel, h):  32 bytes  [ xh8 (16 ch) | xl8 (16 ch) ]  of tap h        xh8 = fp8(hi * 2^-7),  xl8 = fp8(lo * 2^4)
-//     A lane (cout,  h):  32 bytes  [ wl8 (16 ch) | wh8 (16 ch) ]  of tap h        wl8 = fp8(wl * 2^8),   wh8 = fp8(wh * 2^-3)
-// (operand layout probed on the GPU: lane l holds row / column l % 32 and k = 32 * (l / 32) + byte, scripts/probes/mx_correction_probe.hip);
-// the E8M0 scale operands supply the common factor 2^-1.  The stored operands obey the range fold of r3d_sr_common.h (|hi| < 2^15,
-// |w| < 2^11), so every fp8 value is below 2^8 < 448; the correction is accurate to fp8 rounding (2^-4), i.e. ~2^-16 of the product:
-// between fp32 (2^-24) and TF32 (2^-11).  It needs the conv1 operand to sit within ~6 binades of its bound (a bound at most one layer
-// from a measurement), which is what the block's range fold provides (see SuperresolutionHybrid8XDC.forward).
+// here the bracket of TWO taps x 16 channels is ONE v_mfma_scale_f32_32x32x64_f8f6f4 (2x the f16 rate):
+//     B lane (pixel, h):  32 bytes  [ xh8 (16 ch) | xl8 (16 ch) ]  of tap h        xh8 = bf8(hi),         xl8 = bf8(lo * 2^11)       OCP e5m2
+//     A lane (cout,  h):  32 bytes  [ wl8 (16 ch) | wh8 (16 ch) ]  of tap h        wl8 = fp8(wl * 2^8),   wh8 = fp8(wh * 2^-3)       OCP e4m3
+// (operand layout probed on the GPU: lane l holds row / column l % 32 and k = 32 * (l / 32) + byte, scripts/probes/mx_correction_probe.hip;
+// the instruction takes the element format per operand: cbsz = 0 (e4m3) for A, blgp = 1 (e5m2) for B); the E8M0 scale operands supply the
+// common factor 2^-8.
+// Round 5: the ACTIVATION records are e5m2, stored at the top of its range.  Until round 4 they were e4m3 (xh8 = fp8(hi * 2^-7)), which has
+// 14 binades of normal range under the fold's bound: the records carry one exponent per tensor, and with the bound 2^17 or more above the
+// typical pixel (a 2^10 .. 2^14 sigma spike on top of the ~5 binades a propagated L1 bound is loose by) xh8 went subnormal and the typical
+// outputs fell to the TF32 class (far-field 1.6e-4 / 3.6e-4 of max|ref| in tests/test_gpu_pinned_config.py -- why f16mx could not be the
+// library default).  e5m2 holds hi < 2^15 directly (max 57 344) with 29 binades of NORMAL range below it -- a per-element exponent does what
+// per-(pixel, group) E8M0 scale bytes would have done, without a byte to transport or a scale operand to load -- at one mantissa bit less:
+// the correction is accurate to 2^-3 of a 2^-11-sized term instead of 2^-4, i.e. ~2^-15 of the product (numpy model of both formats over
+// bounds 2^3 .. 2^25 above the typical value: e4m3 1.0e-5 -> 3e-4 of max|ref| from 2^17 on, e5m2 1.7e-5 flat; profiles/r05/mx_format_model.txt).
+// The weight records stay e4m3: a weight row is normalised by its own maximum (2^kw[co]) at prepack time.
 // In memory the fp8 records take the place of the fp16 lo plane with the SAME addressing: "lo" chunk 2G holds xh8 (wl8) of the 16
 // channels 16G..16G+15, chunk 2G+1 holds xl8 (wh8) -- so every DMA of the f16x3 kernels is unchanged.
 // Byte order inside a 16-byte record (round 4): dword d = 2 h + p holds channels 8 p + 4 h .. + 3 (p = which 8-channel chunk of the group,
@@ -77,15 +84,37 @@ __device__ __host__ __forceinline__ int mx_rec_chan(int dword) { return 8 * (dwo
 #ifndef R3D_MX_DRAIN
 #define R3D_MX_DRAIN 0        // experiment switch: 1 = the MX conv waits for ALL its DMAs at every sub-stage (the spilling build's behaviour)
 #endif
-static constexpr int kMxScaleA = 127, kMxScaleB = 126;     // E8M0 bytes: 2^0 * 2^-1
-static constexpr float kMxXh = 0.0078125f /* 2^-7 */, kMxXl = 16.0f /* 2^4 */, kMxWl = 256.0f /* 2^8 */, kMxWh = 0.125f /* 2^-3 */;
+#ifndef R3D_MX_ACT_E4M3
+#define R3D_MX_ACT_E4M3 0     // experiment switch (A/B builds): 1 = the round-4 activation records, e4m3 of hi * 2^-7 / lo * 2^4
+#endif
+static constexpr float kMxWl = 256.0f /* 2^8 */, kMxWh = 0.125f /* 2^-3 */;
+#if R3D_MX_ACT_E4M3
+static constexpr int kMxFmtB = 0;                               // blgp: B operand (activation records) OCP e4m3
+static constexpr int kMxScaleA = 127, kMxScaleB = 126;          // E8M0 bytes: 2^0 * 2^-1
+static constexpr float kMxXh = 0.0078125f /* 2^-7 */, kMxXl = 16.0f /* 2^4 */;
+#else
+static constexpr int kMxFmtB = 1;                               // blgp: B operand (activation records) OCP e5m2
+static constexpr int kMxScaleA = 127, kMxScaleB = 119;          // E8M0 bytes: 2^0 * 2^-8
+static constexpr float kMxXh = 1.0f, kMxXl = 2048.0f /* 2^11 */;
+#endif
 
-__device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d)
+__device__ __forceinline__ unsigned pack4_fp8(float a, float b, float c, float d)      // OCP e4m3: the weight records
 {
     int v = 0;
     v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, v, false);
     v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
     return (unsigned)v;
+}
+__device__ __forceinline__ unsigned pack4_x8(float a, float b, float c, float d)       // the activation records (e5m2; e4m3 in the A/B build)
+{
+#if R3D_MX_ACT_E4M3
+    return pack4_fp8(a, b, c, d);
+#else
+    int v = 0;
+    v = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, v, false);
+    v = __builtin_amdgcn_cvt_pk_bf8_f32(c, d, v, true);
+    return (unsigned)v;
+#endif
 }
 
 // ---- per-cout statistics of a weight tensor [CoutReal][row_len]: tail = {2^-kw[co], sum|w[co]|} (ConvTail), padded couts -> {1, 0}.
@@ -370,8 +399,8 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
                     if (a.y_split_mx) {
                         // fp8 records in place of the lo words (see "f16mx" at the top): lo chunk 2G <- xh8, 2G+1 <- xl8 of the 16 channels of
                         // group G; this lane's 4 couts are bytes [8 (chunk & 1) + 4 h, +4) of both records
-                        const unsigned xh8 = pack4_fp8((float)hi[0] * kMxXh, (float)hi[1] * kMxXh, (float)hi[2] * kMxXh, (float)hi[3] * kMxXh);
-                        const unsigned xl8 = pack4_fp8(lf[0] * kMxXl, lf[1] * kMxXl, lf[2] * kMxXl, lf[3] * kMxXl);
+                        const unsigned xh8 = pack4_x8((float)hi[0] * kMxXh, (float)hi[1] * kMxXh, (float)hi[2] * kMxXh, (float)hi[3] * kMxXh);
+                        const unsigned xl8 = pack4_x8(lf[0] * kMxXl, lf[1] * kMxXl, lf[2] * kMxXl, lf[3] * kMxXl);
                         const unsigned c8 = (unsigned)(m0 + cu) >> 3;
                         if (!(c8 & 1u)) { rec_h[nt] = xh8; rec_l[nt] = xl8; }          // (g even; g + 1 is the group's other chunk, same mt, same pixels)
                         else {
@@ -837,7 +866,7 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
                     const i8v b8 = (i8v){(int)r0.x, (int)r0.y, (int)r0.z, (int)r0.w, (int)r1.x, (int)r1.y, (int)r1.z, (int)r1.w};
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[mt], b8, acc[mt][nt], 0, 0, 0, kMxScaleA, 0, kMxScaleB);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a8[mt], b8, acc[mt][nt], 0, kMxFmtB, 0, kMxScaleA, 0, kMxScaleB);
                     }
                 }
 #if !R3D_MX_FREE_SCHED
@@ -1136,8 +1165,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void upconv_fir_f16x3_ker
             if (st > 0) {
 #pragma unroll
                 for (int nt = 0; nt < NTL; ++nt) {
-                    acc[0][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pa68, pb68[nt], acc[0][nt], 0, 0, 0, kMxScaleA, 0, kMxScaleB);
-                    acc[1][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pa17, pb17[nt], acc[1][nt], 0, 0, 0, kMxScaleA, 0, kMxScaleB);
+                    acc[0][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pa68, pb68[nt], acc[0][nt], 0, kMxFmtB, 0, kMxScaleA, 0, kMxScaleB);
+                    acc[1][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pa17, pb17[nt], acc[1][nt], 0, kMxFmtB, 0, kMxScaleA, 0, kMxScaleB);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -1186,9 +1215,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void upconv_fir_f16x3_ker
             // ---- M(P3)
 #pragma unroll
             for (int nt = 0; nt < NTL; ++nt) {
-                acc[0][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a02, b3[nt], acc[0][nt], 0, 0, 0, kMxScaleA, 0, kMxScaleB);
-                acc[2][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a35, b3[nt], acc[2][nt], 0, 0, 0, kMxScaleA, 0, kMxScaleB);
-                acc[3][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a4, b3[nt], acc[3][nt], 0, 0, 0, kMxScaleA, 0, kMxScaleB);
+                acc[0][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a02, b3[nt], acc[0][nt], 0, kMxFmtB, 0, kMxScaleA, 0, kMxScaleB);
+                acc[2][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a35, b3[nt], acc[2][nt], 0, kMxFmtB, 0, kMxScaleA, 0, kMxScaleB);
+                acc[3][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a4, b3[nt], acc[3][nt], 0, kMxFmtB, 0, kMxScaleA, 0, kMxScaleB);
             }
             __builtin_amdgcn_sched_barrier(0);
             continue;
@@ -1223,8 +1252,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void upconv_fir_f16x3_ker
     if constexpr (MXIN) {                                           // M(P4) of the last stage
 #pragma unroll
         for (int nt = 0; nt < NTL; ++nt) {
-            acc[0][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pa68, pb68[nt], acc[0][nt], 0, 0, 0, kMxScaleA, 0, kMxScaleB);
-            acc[1][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pa17, pb17[nt], acc[1][nt], 0, 0, 0, kMxScaleA, 0, kMxScaleB);
+            acc[0][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pa68, pb68[nt], acc[0][nt], 0, kMxFmtB, 0, kMxScaleA, 0, kMxScaleB);
+            acc[1][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(pa17, pb17[nt], acc[1][nt], 0, kMxFmtB, 0, kMxScaleA, 0, kMxScaleB);
         }
     }
 
@@ -1341,8 +1370,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void upconv_fir_f16x3_ker
                     if constexpr (MX) {
                         const f2 fha = __builtin_convertvector(hia, f2), fhb = __builtin_convertvector(hib, f2);
                         const f2 fla = va - fha, flb = vb - fhb;
-                        const unsigned xh8 = pack4_fp8(fha.x * kMxXh, fha.y * kMxXh, fhb.x * kMxXh, fhb.y * kMxXh);
-                        const unsigned xl8 = pack4_fp8(fla.x * kMxXl, fla.y * kMxXl, flb.x * kMxXl, flb.y * kMxXl);
+                        const unsigned xh8 = pack4_x8(fha.x * kMxXh, fha.y * kMxXh, fhb.x * kMxXh, fhb.y * kMxXh);
+                        const unsigned xl8 = pack4_x8(fla.x * kMxXl, fla.y * kMxXl, flb.x * kMxXl, flb.y * kMxXl);
                         if (!(g & 1)) { mxk_h[k][dy] = xh8; mxk_l[k][dy] = xl8; }      // the group's even chunk: its record dwords wait for slice g + 1
                         if (live && oy < OH && ox < OW) {
                             const size_t pix = (size_t)oy * OW + ox;
@@ -1554,10 +1583,10 @@ __global__ void blend_cat_to_split_kernel(const float* __restrict__ a, int a_cb8
     d[0] = *reinterpret_cast<uint4*>(&hi);
     if (mx) {
         unsigned* rec = reinterpret_cast<unsigned*>(dst + (size_t)n * 2 * plane + plane + (size_t)(cb & ~1) * HW + p) + (cb & 1);      // dwords p and 2 + p
-        rec[0] = pack4_fp8(hf[0] * kMxXh, hf[1] * kMxXh, hf[2] * kMxXh, hf[3] * kMxXh);
-        rec[2] = pack4_fp8(hf[4] * kMxXh, hf[5] * kMxXh, hf[6] * kMxXh, hf[7] * kMxXh);
-        rec[4 * (size_t)HW] = pack4_fp8(lf[0] * kMxXl, lf[1] * kMxXl, lf[2] * kMxXl, lf[3] * kMxXl);
-        rec[4 * (size_t)HW + 2] = pack4_fp8(lf[4] * kMxXl, lf[5] * kMxXl, lf[6] * kMxXl, lf[7] * kMxXl);
+        rec[0] = pack4_x8(hf[0] * kMxXh, hf[1] * kMxXh, hf[2] * kMxXh, hf[3] * kMxXh);
+        rec[2] = pack4_x8(hf[4] * kMxXh, hf[5] * kMxXh, hf[6] * kMxXh, hf[7] * kMxXh);
+        rec[4 * (size_t)HW] = pack4_x8(lf[0] * kMxXl, lf[1] * kMxXl, lf[2] * kMxXl, lf[3] * kMxXl);
+        rec[4 * (size_t)HW + 2] = pack4_x8(lf[4] * kMxXl, lf[5] * kMxXl, lf[6] * kMxXl, lf[7] * kMxXl);
     } else {
         d[plane] = *reinterpret_cast<uint4*>(&lo);
     }
@@ -1621,10 +1650,10 @@ __global__ void upsample2x_bilinear_kernel(const float* __restrict__ x, uint4* _
         d[0] = *reinterpret_cast<uint4*>(&hi);
         if (mx) {                                                   // R3D_FMT_SPLIT_MX: this chunk's dwords (cb & 1) and 2 + (cb & 1) of the group's two records (blend_cat_to_split_kernel)
             unsigned* rec = reinterpret_cast<unsigned*>(y_split + (size_t)n * 2 * plane + plane + (size_t)(cb & ~1) * HW + p) + (cb & 1);
-            rec[0] = pack4_fp8(hf[0] * kMxXh, hf[1] * kMxXh, hf[2] * kMxXh, hf[3] * kMxXh);
-            rec[2] = pack4_fp8(hf[4] * kMxXh, hf[5] * kMxXh, hf[6] * kMxXh, hf[7] * kMxXh);
-            rec[4 * HW] = pack4_fp8(lf[0] * kMxXl, lf[1] * kMxXl, lf[2] * kMxXl, lf[3] * kMxXl);
-            rec[4 * HW + 2] = pack4_fp8(lf[4] * kMxXl, lf[5] * kMxXl, lf[6] * kMxXl, lf[7] * kMxXl);
+            rec[0] = pack4_x8(hf[0] * kMxXh, hf[1] * kMxXh, hf[2] * kMxXh, hf[3] * kMxXh);
+            rec[2] = pack4_x8(hf[4] * kMxXh, hf[5] * kMxXh, hf[6] * kMxXh, hf[7] * kMxXh);
+            rec[4 * HW] = pack4_x8(lf[0] * kMxXl, lf[1] * kMxXl, lf[2] * kMxXl, lf[3] * kMxXl);
+            rec[4 * HW + 2] = pack4_x8(lf[4] * kMxXl, lf[5] * kMxXl, lf[6] * kMxXl, lf[7] * kMxXl);
         } else {
             d[plane] = *reinterpret_cast<uint4*>(&lo);
         }
@@ -1697,7 +1726,7 @@ static void launch_conv2(Conv2Args& a, int tiles, int N, hipStream_t st, bool mx
     static const int order = getenv("R3D_CONV_ORDER") ? atoi(getenv("R3D_CONV_ORDER")) : 2;   // tuning switch (0: plain (x, y) order)
     a.order = (tiles & 7) == 0 ? order : 0;
     const int kind = a.nphase > 1 ? 2 : (a.ph[0].ntaps == 9 ? 0 : 1);      // 0: 3x3 conv, 1: 1x1 conv, 2: transposed-conv phases
-    if (shape == 1) {           // 4 waves x (64 couts x 128 px), 2 blocks/CU
+    if (shape == 1 && !mx) {    // 4 waves x (64 couts x 128 px), 2 blocks/CU (the switch has no MX instantiation: an R3D_FMT_SPLIT_MX input keeps the default shape)
         if (kind == 0) hipLaunchKernelGGL((conv_mfma_f16x3_kernel<2, 4, 2>), grid, dim3(256), 0, st, a);
         else if (kind == 1) hipLaunchKernelGGL((conv1x1_mfma_f16x3_kernel<2, 4, 2>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((tconv_mfma_f16x3_kernel<2, 4, 2>), grid, dim3(256), 0, st, a);

@@ -193,10 +193,14 @@ def selftest(llvm_bin):
                 raise SystemExit("pk_opsel_fix selftest: hazardous or unparsable form after the rewrite: " + l)
         for refused in ("v_pk_mul_f32 v[2:3], v[4:5], v[6:7] op_sel:[1,1] op_sel_hi:[0,0]", "v_pk_fma_f32 v[2:3], v[4:5], v[6:7], v[8:9] op_sel:[0,0,1] op_sel_hi:[1,1,0]",
                         "v_pk_mov_b32 v[2:3], v[4:5], v[6:7] op_sel:[0,1]"):
+            allow = os.environ.pop("R3D_PK_ALLOW_DWORD_SWAP", None)      # the refusal is what is checked here: the escape hatch stays usable from make
             try:
                 fix_line("\t" + refused, {"pk": 0, "swapped": 0, "dword_swapped": 0})
             except RuntimeError:
                 continue
+            finally:
+                if allow is not None:
+                    os.environ["R3D_PK_ALLOW_DWORD_SWAP"] = allow
             raise SystemExit("pk_opsel_fix selftest: a form without a validated rewrite was not refused: " + refused)
     print("pk_opsel_fix selftest: %d forms round-tripped through the gfx950 assembler, %d rewritten, refusals ok" % (len(SELFTEST_FORMS), stats["swapped"]))
 

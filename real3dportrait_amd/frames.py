@@ -156,9 +156,9 @@ class ClipRenderer:
     render + SR, clamp, uint8 HWC conversion on device."""
 
     def __init__(self, generator, cano_planes, residuals, cameras, ws, base_seed=0, precision=None):
-        """precision: SR precision to set on the generator's blocks -- None = leave them as they are (library default 'f16x3'),
-        'throughput' = superresolution.THROUGHPUT_SR_PRECISION ('f16mx', unless R3D_SR_PRECISION names another: what bench.py asks for),
-        or a precision name."""
+        """precision: SR precision to set on the generator's blocks -- None = leave them as they are (library default 'f16mx'),
+        'throughput' = superresolution.THROUGHPUT_SR_PRECISION (the default 'f16mx', unless R3D_SR_PRECISION names another),
+        or a precision name ('f16x3' = the fp32-class tier, 'f32')."""
         import os
         from . import _lib
         from .superresolution import THROUGHPUT_SR_PRECISION, set_sr_precision

@@ -80,11 +80,16 @@ def const_bound(value, N, device):
     return t
 
 
-# Precision policy (round 4; ADVICE r3 / VERDICT r3 weak 2).  A module built by anybody -- a user, patch_model() on a reference model --
-# computes in the fp32-class tier 'f16x3' (the reference runs these layers in fp32).  The throughput drivers (frames.ClipRenderer, bench.py)
-# ask for THROUGHPUT_SR_PRECISION by name; R3D_SR_PRECISION overrides both for a process.  DESIGN 4.2c states the tiers.
-DEFAULT_SR_PRECISION = "f16x3"
-THROUGHPUT_SR_PRECISION = "f16mx"
+# Precision policy (round 5).  A module built by anybody -- a user, patch_model() on a reference model, frames.ClipRenderer,
+# bench.py -- computes in 'f16mx': fp32 operands as fp16 hi + lo, hi*hi on the f16 MFMA, the two cross products on the block-scaled 8-bit
+# MFMA, fp32 accumulate.  It earned the default when its activation records became OCP e5m2 (r3d_sr_f16x3.hip "f16mx"): every reference
+# golden, the benchmarked frame and the heavy-tail sweeps (spikes of 2^6 .. 2^14 sigma, near and far field) sit at 1.3e-5 .. 6.3e-5 of max|ref|
+# against the 2e-4 SURVEY 8(d) states; until round 4 (e4m3 records with one exponent per tensor) the far field left the tolerance at 2^14 sigma.
+# 'f16x3' (every product as 3 fp16 MFMA terms: <= 1.3e-6, the fp32-class tier) and 'f32' (exact fp32 MFMA) are selected by name;
+# R3D_SR_PRECISION overrides the default for a process.  DESIGN 4.2c states the tiers.
+DEFAULT_SR_PRECISION = "f16mx"
+THROUGHPUT_SR_PRECISION = "f16mx"          # what ClipRenderer(precision='throughput') asks for: the default since round 5
+FP32_CLASS_SR_PRECISION = "f16x3"
 _MX_UPCONV = os.environ.get("R3D_MX_UPCONV", "1") != "0"      # A/B switch: 0 = f16mx keeps block1's up-sampling conv on the 3-term fp16 split
 
 
@@ -103,7 +108,11 @@ def set_sr_precision(module, precision):
 MAX_DEPTH = 3      # a stored fp16 operand may be at most this many conv layers away from a measured / known max|x|
 
 
-MX_MAX_DEPTH = 2     # f16mx main loops only within this many layers of a measured bound (ConvStack.forward)
+# f16mx main loops only within this many layers of a measured bound (ConvStack.forward).  Round 4: 2 -- the e4m3 records carried one exponent
+# per tensor and went subnormal three propagated bounds (~15 binades) from a measurement.  Round 5: the e5m2 records have the fp16 hi plane's own
+# exponent range, so an MX operand is usable wherever a SPLIT operand is (MAX_DEPTH), including the hand-offs between a stack and a block
+# (fuse_fg_bg_convs -> block1: depth 3); measured at depth 3: to_plane_cnn 2.9e-5 (2.2e-5 at depth 2), torso frame 4.0e-5 of max|ref|.
+MX_MAX_DEPTH = int(os.environ.get("R3D_MX_MAX_DEPTH", str(MAX_DEPTH)))
 
 
 def bound_of(x, meter, layers=1):
@@ -216,10 +225,10 @@ class SynthesisBlock(nn.Module):
         self.conv_clamp = conv_clamp
         self.out_format = "nchw"       # 'nchw' (reference layout) | 'cb8' | 'split' (f16x3 hand-off, needs _next)
         self.return_x = True           # False: skip materialising x (last block of SuperresolutionHybrid8XDC)
-        # 'f16x3' (library default): fp32-accurate 3-term split on the f16 matrix pipe (<= 1.3e-6 over the operand sweeps);
-        # 'f16mx' (what frames.ClipRenderer / bench.py select by name): the same split with the cross products of the block's convs on the
-        #          block-scaled fp8 MFMA (error ~2^-16 of each product: <= 5e-5 of max|ref| on every reference golden, heavy-tailed operands
-        #          in tests/test_gpu_pinned_config.py; 2 instead of 3 matrix passes per MAC; SynthesisBlockNoUp computes as 'f16x3');
+        # 'f16mx' (library default): fp32 operands as fp16 hi + lo with the cross products of the block's convs on the block-scaled 8-bit MFMA
+        #          (e5m2 activation x e4m3 weight records, error ~2^-15 of each product: <= 6.3e-5 of max|ref| on every reference golden and
+        #          heavy-tail sweep, tests/test_gpu_pinned_config.py; 2 instead of 3 matrix passes per MAC);
+        # 'f16x3': fp32-accurate 3-term split on the f16 matrix pipe (<= 1.3e-6 over the operand sweeps);
         # 'f32': exact fp32 MFMA.
         # Override per module (`.precision`, set_sr_precision()) or for the process with R3D_SR_PRECISION.
         self.precision = os.environ.get("R3D_SR_PRECISION", DEFAULT_SR_PRECISION)
@@ -345,8 +354,11 @@ class SynthesisBlock(nn.Module):
         if out_fmt == "none":
             x_out = None
         elif out_fmt in ("split", "split_mx"):
-            assert _next is not None, "out_format='split' needs the consumer (its folded in-multiplier)"
-            assert out_fmt == "split" or (prec == 2 and _next.wants_mx()), "split_mx is the hand-off to an f16mx consumer"
+            if _next is None:
+                raise RuntimeError("out_format=%r needs the consumer (`_next`: its folded in-multiplier)" % out_fmt)
+            if out_fmt == "split_mx" and not (prec == 2 and _next.wants_mx()):
+                # mixed per-module precision: only an f16mx block writes the fp8 records, and only an f16mx consumer reads them
+                out_fmt = "split"
             next_scale, next_stride = _next.in_scale()
             x_out = torch.empty(N, 2, Cout // 8, OH, OW, 8, device=dev, dtype=torch.float16)
         elif out_fmt == "cb8":
@@ -400,8 +412,8 @@ class Conv2d(nn.Module):
         self._bias32 = None
         self._meter = _BoundMeter()
         self._depth_in = 0
-        # 'f16x3' (library default, fp32-class) | 'f16mx': a 3x3 conv whose SPLIT input carries fp8 records (R3D_FMT_SPLIT_MX) runs its
-        # cross products on the block-scaled fp8 MFMA; the PRODUCER of the input asks `wants_mx()` and writes the records.  'f32' = 'f16x3'
+        # 'f16mx' (library default): a 3x3 conv whose SPLIT input carries 8-bit records (R3D_FMT_SPLIT_MX) runs its cross products on the
+        # block-scaled 8-bit MFMA; the PRODUCER of the input asks `wants_mx()` and writes the records | 'f16x3' (fp32-class).  'f32' = 'f16x3'
         # here (the plain convs have no exact-f32 kernel).  R3D_SR_PRECISION / set_sr_precision() as for the SR blocks.
         self.precision = os.environ.get("R3D_SR_PRECISION", DEFAULT_SR_PRECISION)
 

@@ -183,8 +183,8 @@ def _reference_hparams(model):
 def patch_model(model, fuse_warp_sr=True, precision=None):
     """Swap the hot-path operators of a constructed reference model for the HIP ones (in place).  INFERENCE ONLY: the HIP modules
     detach their inputs and build no autograd graph (the reference runs this path under torch.no_grad(), real3d_infer.py:435,479).
-    precision: SR precision of the installed blocks (None = the library default 'f16x3', fp32-class like the reference's fp32 layers;
-    'f16mx' = the throughput tier bench.py measures; superresolution.py "Precision policy").
+    precision: SR precision of the installed blocks (None = the library default 'f16mx': inside the 2e-4 of SURVEY 8(d) on every golden and heavy-tail sweep,
+    what bench.py measures; 'f16x3' = the fp32-class tier, 1.3e-6; superresolution.py "Precision policy").
 
     * model.ray_sampler  -> RaySampler            (created at img2plane_baseline.py:106 / triplane.py:38)
     * model.renderer     -> ImportanceRenderer    (img2plane_baseline.py:104-105 / triplane.py:36-37)

@@ -1,17 +1,17 @@
-"""GPU parity (`-m gpu`) of the 'f16mx' SR precision (the throughput tier, selected by name; the default at the end of round 3): f16x3 with the correction products of each
-block's 3x3 conv on the block-scaled fp8 MFMA.  Own, stated tolerance tier: the correction is accurate to fp8 rounding (~2^-16 of each
-product), so
+"""GPU parity (`-m gpu`) of the 'f16mx' SR precision (the library default since round 5): f16x3 with the correction products of each 3x3 conv on
+the block-scaled 8-bit MFMA (e5m2 activation records x e4m3 weight records).  Own, stated tolerance tier, tighter than the 2e-4 of SURVEY 8(d):
+the correction is accurate to e5m2 rounding (~2^-15 of each product), so
 
-    SR outputs   <= 5e-5 * max(1, max|ref|)        (f16x3 / f32 tier: 2e-4 with ~4e-6 measured; TF32 would be ~2e-4 measured)
-    final image  <= 1e-3 abs after the clamp       (unchanged)
+    SR outputs   <= 5e-5 * max(1, max|ref|)        (measured 1.6e-5 .. 3.6e-5; f16x3 ~4e-6; TF32 would be ~2e-4)
+    final image  <= 2e-4 (SR_TOL) after the clamp
 
 against the same reference goldens, plus the dynamic-range sweep (inputs / weights / styles / biases scaled by 2^k, k in [-20, 14])
-at <= 1e-4 * max|ref| vs torch fp64."""
+at <= 1e-4 * max|ref| vs torch fp64.  The heavy-tail sweeps (tests/test_gpu_pinned_config.py) hold both precisions to SR_TOL near and far."""
 import numpy as np
 import pytest
 
 from conftest import load_golden
-from test_gpu_parity import RGB_TOL, DEPTH_TOL, T, load_block
+from test_gpu_parity import RGB_TOL, DEPTH_TOL, SR_TOL, T, load_block
 from test_gpu_range_and_sizes import SWEEP, _block_fp64, _generator
 
 pytestmark = pytest.mark.gpu
@@ -73,8 +73,9 @@ def test_synthesis_golden_f16mx():
     out = G.synthesis(torch.ones(1, 14, 512, device="cuda"), T(torch, g["cam"]), use_cached_backbone=True, noise_mode="none")
     img = out["image"].cpu().numpy()
     assert np.abs(out["image_raw"].cpu().numpy() - g["image_raw"]).max() <= RGB_TOL
-    assert np.abs(img[:, :, ::4, ::4] - g["image_strided"]).max() <= 1e-3
-    assert np.abs(img[:, :, :96, :96] - g["image_corner"]).max() <= 1e-3
+    e_str, e_cor = np.abs(img[:, :, ::4, ::4] - g["image_strided"]).max(), np.abs(img[:, :, :96, :96] - g["image_corner"]).max()
+    print("synthesis golden: final image err strided %.2e corner %.2e (tier %.0e x max(1, |ref|))" % (e_str, e_cor, SR_TOL))
+    assert e_str <= SR_TOL * max(1.0, np.abs(g["image_strided"]).max()) and e_cor <= SR_TOL * max(1.0, np.abs(g["image_corner"]).max())
 
 
 @pytest.mark.parametrize("what", ["input", "weights", "styles", "bias"])

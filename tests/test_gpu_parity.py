@@ -166,8 +166,10 @@ def test_fusion_stacks_golden(torch_cuda):
     y1 = stacks["fuse_head_torso_convs"](blend_cat(i["x_head"], x_torso, a, stacks["fuse_head_torso_convs"]))
     y2, _ = blk(y1, rgb1, i["ws"], noise_mode="none")
     y3 = stacks["fuse_fg_bg_convs"](blend_cat(y2, x_bg, occ, stacks["fuse_fg_bg_convs"]))
+    # (f16mx: the fused flow hands over 8-bit records where the unfused one feeds fp32 NCHW into an f16x3 first layer: the two differ by the tier)
+    tier = 2e-5 if stacks["fuse_fg_bg_convs"][2].precision == "f16x3" else 1e-4
     for got, ref in ((y1, x1), (y2, x2), (y3, x3)):
-        assert (got - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+        assert (got - ref).abs().max().item() <= tier * max(1.0, ref.abs().max().item())
 
 
 @pytest.mark.parametrize("N,Cin,Cout,k,H,W,slope", [(2, 3, 64, 3, 37, 21, 0.01), (1, 64, 256, 1, 16, 16, None),
@@ -280,9 +282,10 @@ def test_synthesis_golden(torch_cuda):
     assert np.abs(out["image_raw"].cpu().numpy() - g["image_raw"]).max() <= RGB_TOL
     assert np.abs(out["image_depth"].cpu().numpy() - g["image_depth"]).max() <= DEPTH_TOL
     assert np.abs(out["image_feature"].cpu().numpy()[:, ::4] - g["image_feature_strided"]).max() <= RGB_TOL
-    # SR amplifies its input error by the network gain; the image is clamped to [-1,1]
-    assert np.abs(img[:, :, ::4, ::4] - g["image_strided"]).max() <= 1e-3
-    assert np.abs(img[:, :, :96, :96] - g["image_corner"]).max() <= 1e-3
+    # the end-to-end golden at the tolerance SURVEY 8(d) states for the SR (measured ~4e-6 f16x3, ~3e-5 f16mx)
+    e_str, e_cor = np.abs(img[:, :, ::4, ::4] - g["image_strided"]).max(), np.abs(img[:, :, :96, :96] - g["image_corner"]).max()
+    print("synthesis golden: final image err strided %.2e corner %.2e (tier %.0e x max(1, |ref|))" % (e_str, e_cor, SR_TOL))
+    assert e_str <= SR_TOL * max(1.0, np.abs(g["image_strided"]).max()) and e_cor <= SR_TOL * max(1.0, np.abs(g["image_corner"]).max())
 
 
 # ------------------------------------------------------------------------------------------------

@@ -190,13 +190,14 @@ def test_render_cfg5_full_size_subset_vs_oracle(torch_cuda, oracle):
 # (b) heavy tails
 # ------------------------------------------------------------------------------------------------
 SPIKES = [6, 10, 14]
-# Asserted tiers.  `max` figure (err / max|ref|, the tolerance SURVEY 8d states): f16x3 2e-5, f16mx 2e-4 for every spike.  `far` figure:
-# f16x3 2e-5 for every spike (measured <= 2.3e-6: the exact power-of-two fold keeps 22+ bits at max / rms = 2^14); f16mx 2e-4 up to
-# max / rms = 2^10 (measured 2.0e-5 at 2^6, 1.6e-4 at 2^10) and 1e-3 at 2^14 (measured 3.6e-4): its fp8 correction terms carry ONE
-# per-tensor exponent, so with the bound 2^14 above the typical value they run out of fp8 range (xh8 = fp8(hi * 2^-7) goes subnormal) and
-# the typical outputs degrade toward the TF32 class (5e-4) -- the reason 'f16mx' is selected by name and is not the library default.
+# Asserted tiers.  `max` figure (err / max|ref|, the tolerance SURVEY 8d states): f16x3 2e-5, f16mx 2e-4 for every spike.  `far` figure
+# (outputs no spike reaches): f16x3 2e-5 (measured <= 2.3e-6: the exact power-of-two fold keeps 22+ bits at max / rms = 2^14); f16mx 2e-4 for
+# EVERY spike since round 5: its activation records are OCP e5m2 (a per-element exponent, 29 binades of normal range under the fold's bound),
+# so the typical outputs no longer depend on how far the tensor's bound sits above them.  Until round 4 the records were e4m3 with one exponent
+# per tensor and went subnormal from max / rms = 2^10 on (far 1.6e-4 at 2^10, 3.6e-4 at 2^14: asserted 1e-3 then, and the reason 'f16mx' was
+# not the library default); profiles/r05/mx_format_model.txt is the numpy model of both formats, `make EXTRA=-DR3D_MX_ACT_E4M3=1` the A/B build.
 _TIER = {"f16x3": 2e-5, "f16mx": SR_TOL}
-_TIER_FAR = {("f16x3", 6): 2e-5, ("f16x3", 10): 2e-5, ("f16x3", 14): 2e-5, ("f16mx", 6): SR_TOL, ("f16mx", 10): SR_TOL, ("f16mx", 14): 1e-3}
+_TIER_FAR = {("f16x3", 6): 2e-5, ("f16x3", 10): 2e-5, ("f16x3", 14): 2e-5, ("f16mx", 6): SR_TOL, ("f16mx", 10): SR_TOL, ("f16mx", 14): SR_TOL}
 
 
 def _far_mask(shape_hw, centers, radius):
@@ -304,9 +305,9 @@ def test_conv_stack_heavy_tail(torch_cuda, k, where, precision):
     if precision == "f16x3":
         assert e <= 2e-5 and f <= 1e-4, (where, k, e, f)
     else:
-        # measured: err / max|ref| <= 4.5e-5 everywhere; far-field 2.3e-4 at a spike of 2^10 sigma, 3.6e-4 at 2^14 (the third conv's operand is
-        # two propagated bounds -- ~10 binades -- away from the measured input on top of the spike)
-        assert e <= SR_TOL and f <= {6: SR_TOL, 10: 3e-4, 14: 1e-3}[k], (where, k, e, f)
+        # e5m2 activation records (round 5): the far-field no longer depends on the spike (round 4, e4m3 with one exponent per tensor: 2.3e-4 at a
+        # spike of 2^10 sigma, 3.6e-4 at 2^14 -- the third conv's operand is two propagated bounds, ~10 binades, from the measured input on top of it)
+        assert e <= SR_TOL and f <= SR_TOL, (where, k, e, f)
 
 
 @pytest.mark.parametrize("k", SPIKES)
