@@ -371,8 +371,13 @@ __device__ __forceinline__ void split8_bounded(const float (&x)[8], h8& hi, h8& 
 {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const _Float16 a = (_Float16)x[j];
-        hi[j] = a; lo[j] = (_Float16)(x[j] - (float)a);
+        // as_rounded(): without it hipcc fuses the producer's multiply into both conversions -- hi = v_fma_mixlo_f16(x, m, 0),
+        // lo = v_fma_mixlo_f16(x, m, -hi) -- which reads well (the residual of the exact product) and measures 26x WORSE: the mix form does not
+        // keep the fp16 subnormals lo lives in (|lo| ~ 2^-12 |x|).  Round 5, the build without packed-f32 (the packed multiply used to stand between
+        // the two): run_model vs fp64 9.7e-6 instead of 3.7e-7, profiles/r05/nopk_price.txt; tests/test_abi.py lints the form out of every kernel.
+        const float v = as_rounded(x[j]);
+        const _Float16 a = (_Float16)v;
+        hi[j] = a; lo[j] = (_Float16)(v - (float)a);
     }
 }
 
@@ -1068,11 +1073,18 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
         f32x4 colc[2][NTC];
         float sigc[NTC];
         {
-            // depth of the sample this lane gathers for (lane gs of the per-sample mapping: q = 0, s = gs)
-            float tgs[NTC];
+            // the depths go to the ray's LDS record first (the march reads them there anyway): the pass fetches the depth of the sample a lane
+            // gathers for (lane gs of the per-sample mapping: q = 0, s = gs) per tile, as the fine pass does, instead of holding NTC shuffled
+            // copies + the NTC originals in registers across the pass (round 5: six registers of the REF shape's 247)
+            if (q == 0) {
 #pragma unroll
-            for (int nt = 0; nt < NTC; ++nt) tgs[nt] = __shfl(tc[nt], gs);
-            auto dof = [&](int t) { return tgs[t]; };
+                for (int nt = 0; nt < NTC; ++nt) {
+                    const int k = 16 * nt + s;
+                    if (k < Nc) L.t[k] = tc[nt];
+                }
+            }
+            wave_lds_sync();
+            auto dof = [&](int t) { const int k = 16 * t + gs; return k < Nc ? L.t[k] : start; };
             decode_pass<NTC, GPF, TRI>(F, dec, P, A.H, A.W, A.D, lane, ox, oy, oz, dx, dy, dz, A.scale, xs3, dof, colc[0], colc[1], sigc);
         }
         constexpr bool parked = PARK;                  // (an instantiation with NTF > 0 is only launched with Nf > 0)
@@ -1084,7 +1096,7 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
 #pragma unroll
             for (int nt = 0; nt < NTC; ++nt) {
                 const int k = 16 * nt + s;
-                if (k < Nc) { L.t[k] = tc[nt]; L.sg[k] = sigc[nt]; }
+                if (k < Nc) L.sg[k] = sigc[nt];
             }
         }
         wave_lds_sync();

@@ -164,20 +164,20 @@ def test_pipelined_frames_equal_sequential_soak(torch_cuda, precision):
     assert bad == 0, "%d of %d pipelined frames differ from the sequential render" % (bad, passes * n)
 
 
-def test_build_without_packed_f32_agrees():
-    """the product depends on a text pass over compiler output (csrc/tools/pk_opsel_fix.py).  Its A/B partner is the same source
-    compiled with the packed-f32 target feature OFF (`make NOPK=1`, built by __graft_entry__.build_test_helpers(): no v_pk_*_f32 in its code objects,
-    nothing for the rewriter to do).  The two compilations contract different mul + add pairs (fp-contract=fast around the SLP vectoriser), so the
-    comparison is a tight tolerance -- fp32 ray-kernel outputs within 1e-5, uint8 frames within one count in < 0.2 % of the bytes, the torso frame's
-    fp32 image within 3e-4 of its maximum (nine f16mx convolutions deep) -- where a wrong
+def test_build_with_packed_f32_agrees():
+    """The product is compiled without packed-f32 instructions (round 5: they buy nothing next to MFMAs and one of their forms is hazardous on gfx950,
+    DESIGN 4.1a).  Its A/B partner is the same source WITH them, every translation unit through the op_sel rewriter (`make PK=1`, built by
+    __graft_entry__.build_test_helpers(); the product build of rounds 3-4).  The two compilations contract different mul + add pairs
+    (fp-contract=fast around the SLP vectoriser), so the comparison is a tight tolerance -- fp32 ray-kernel outputs within 1e-5, uint8 frames within
+    one count in < 0.2 % of the bytes, the torso frame's fp32 image within 3e-4 of its maximum (nine f16mx convolutions deep) -- where a wrong
     operand in a quarter of the lanes is off by the operand's magnitude: head frames (both SR precisions), four ray-kernel shapes, the torso frame."""
     import subprocess
     import sys
-    nopk = os.path.join(ROOT, "tests", "_build", "libr3d_hip_nopk.so")
-    assert os.path.exists(nopk), "tests/_build/libr3d_hip_nopk.so is missing: __graft_entry__.build() builds it"
-    listing = open(os.path.join(ROOT, "tests", "_build", "obj_nopk", "r3d_render.fix.s")).read()
-    assert "v_pk_fma_f32" not in listing and "v_pk_mul_f32" not in listing and "v_pk_add_f32" not in listing      # it really is the build without them
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gpu_build_ab.py"), "default", "tests/_build/libr3d_hip_nopk.so"],
+    pk = os.path.join(ROOT, "tests", "_build", "libr3d_hip_pk.so")
+    assert os.path.exists(pk), "tests/_build/libr3d_hip_pk.so is missing: __graft_entry__.build() builds it"
+    listing = open(os.path.join(ROOT, "tests", "_build", "obj_pk", "r3d_render.fix.s")).read()
+    assert "v_pk_fma_f32" in listing and "v_pk_mul_f32" in listing                      # it really is the build with them
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "gpu_build_ab.py"), "default", "tests/_build/libr3d_hip_pk.so"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     print(r.stdout)
     assert r.returncode == 0 and "\nAGREE" in r.stdout, (r.stdout[-3000:], r.stderr[-1500:])
