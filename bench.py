@@ -155,6 +155,9 @@ def cpu_baseline_reference():
             "measured": measured}
 
 
+VALU_INSTS = {}
+
+
 def measure_traffic(prec):
     """HBM bytes per launch of the conv kernels, measured NOW: two `rocprofv3 --pmc` child runs of this script (FETCH_SIZE and WRITE_SIZE
     need separate passes, MI355X_MICROARCH.md "rocprofv3 PMC slots"; --pmc only, no trace domain), 6 frames on one stream each.
@@ -171,7 +174,7 @@ def measure_traffic(prec):
     tmp = tempfile.mkdtemp(prefix="r3d_traffic_", dir="/tmp")
     vals = collections.defaultdict(dict)
     try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
             cmd = [tool, "--pmc", ctr, "--output-format", "csv", "-d", os.path.join(tmp, ctr), "-o", "p", "--", sys.executable,
                    os.path.abspath(__file__), "--traffic-child", "--sr-precision", prec, "--steps", "6"]
             # (the child is a plain single-process run: no rendezvous variables of a torch.distributed launcher may leak into it)
@@ -192,7 +195,9 @@ def measure_traffic(prec):
         return None, "traffic measurement failed (%s)" % type(e).__name__
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    out = {k: int((2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024) for k, v in vals.items() if len(v) == 2}
+    out = {k: int((2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024) for k, v in vals.items() if "FETCH_SIZE" in v and "WRITE_SIZE" in v}
+    global VALU_INSTS
+    VALU_INSTS = {k: v["SQ_INSTS_VALU"] for k, v in vals.items() if "SQ_INSTS_VALU" in v}      # wave-level VALU instructions per launch (third pass)
     return out, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this run (6 frames, one stream): 2 x FETCH_SIZE + WRITE_SIZE per launch"
 
 
@@ -724,6 +729,20 @@ def main():
         S = 128 * 128 * 96
         out["render_kernel"] = {"ms": bd["render"], "algorithmic_GBps": round((S * 1536 + 128 * 128 * 137) / (bd["render"] * 1e-3) / 1e9, 1),
                                 "mlp_TFLOPs": round(S * 8320 / (bd["render"] * 1e-3) / 1e12, 2)}
+        # what the ray kernel is bound by: `algorithmic_GBps` counts every tap a sample touches and is served by L1 / L2 -- not a
+        # roofline.  The two real ones: (i) the VALU issue port -- wave-level VALU instructions of one launch (SQ_INSTS_VALU, a --pmc child pass of
+        # this run) / 1 024 SIMDs x 4 cycles per wave64 instruction at the clock the kernel ran at; (ii) HBM on the COMPULSORY bytes of a frame:
+        # planes 3 x 256^2 x 32 x 4 B read once + the feature / depth / weight images and the SPLIT copy written once.
+        rk = out["render_kernel"]
+        compulsory = 3 * 256 * 256 * 32 * 4 + 128 * 128 * (32 * 4 + 4 + 4 + 1) + 128 * 128 * 32 * 4
+        rk["compulsory_bytes"] = compulsory
+        rk["frac_of_hbm_on_compulsory_bytes"] = round(compulsory / (bd["render"] * 1e-3) / 8e12, 4)
+        vi = [v for k, v in VALU_INSTS.items() if k.startswith("render_kernel")]
+        if vi and clock_ghz.get("render_kernel"):
+            floor_ms = vi[0] / 1024.0 * 4.0 / (clock_ghz["render_kernel"] * 1e9) * 1e3
+            rk.update({"valu_wave_insts_per_launch": int(vi[0]), "shader_clock_ghz": clock_ghz["render_kernel"],
+                       "valu_issue_floor_ms": round(floor_ms, 4), "frac_of_valu_issue_bound": round(floor_ms / bd["render"], 4),
+                       "bound": "VALU issue (2 waves per SIMD; the rest is gather latency and the transcendental / MFMA dependency chains of a tile)"})
         # literal "512x512 neural render, 48 depth samples": R=512 rays, no SR
         cano, residuals, cams = scene
         opts = dict(G.rendering_kwargs)
