@@ -422,7 +422,8 @@ def cfg5_stress(torch, dev, lib, precision="f16mx"):
         fimg = feat.permute(0, 2, 1).reshape(N, 32, R, R).contiguous()
         prep0, prep1 = b0.prepare(ws, dev), b1.prepare(ws, dev)
         b0._depth_in, b1._depth_in = 0, 2
-        mx = b0.precision == "f16mx"           # as SuperresolutionHybrid8XDC.forward: block0 measures max|x0|, block1's conv1 operand is re-folded from it
+        from real3dportrait_amd import superresolution as _srm
+        mx = b0.precision == "f16mx" and _srm._MX_TAIL_FOLD      # as SuperresolutionHybrid8XDC.forward (R3D_MX_TAIL_FOLD=1: block0 measures max|x0|, block1's conv1 operand is re-folded from it)
         chain_fold([b0.chain_op(-1), b1.chain_op(0)], N, [const_bound(1.01, N, dev)], zero=[mx_slot] if mx else ())
         x, rgb = b0(fimg, fimg[:, :3].contiguous(), ws, noise_mode="none", _prepared=prep0, _next=b1, _folded=True, _x_absmax=mx_slot if mx else None)
         if mx:
@@ -777,19 +778,21 @@ def main():
                 G_api.renderer.seed = frame_seed(clip.base_seed, t)
                 G_api._last_planes = (cano + residuals[t % len(residuals)]).view(1, 96, 256, 256)
                 return G_api.synthesis(ws_api, cams[t:t + 1], use_cached_backbone=True, noise_mode="none")
-            for i in range(4):
+            for i in range(12):                          # (first calls of a precision: weight prepack, style vectors, workspaces)
                 ret = api_frame(i)
             torch.cuda.synchronize()
             assert tuple(ret["image"].shape) == (1, 3, 512, 512) and tuple(ret["image_raw"].shape) == (1, 3, 128, 128) \
                 and tuple(ret["image_depth"].shape) == (1, 1, 128, 128) and tuple(ret["image_feature"].shape) == (1, 29, 128, 128)
             api_u8 = ((ret["image"][0].permute(1, 2, 0) + 1) / 2 * 255).int().clamp(0, 255).to(torch.uint8)
             api_equal = bool(torch.equal(api_u8, ref_u8)) if api_prec == prec else None
-            nb = 40
-            t1 = time.perf_counter()
-            for i in range(nb):
-                ret = api_frame(i)
-            torch.cuda.synchronize()
-            api[api_prec] = ((time.perf_counter() - t1) / nb, api_equal)
+            nb, best_api = 40, 1e9
+            for rep in range(2):                         # best of 2 passes of 40 frames
+                t1 = time.perf_counter()
+                for i in range(nb):
+                    ret = api_frame(i)
+                torch.cuda.synchronize()
+                best_api = min(best_api, (time.perf_counter() - t1) / nb)
+            api[api_prec] = (best_api, api_equal)
         t_api, api_equal = api[prec]
         out["value_synthesis_api"] = {
             "what": "TriPlaneGenerator.synthesis() per frame on ONE stream through patch_model()'d operators: `cano + secc` add (torch), layout, rays, "

@@ -90,6 +90,10 @@ def const_bound(value, N, device):
 DEFAULT_SR_PRECISION = "f16mx"
 THROUGHPUT_SR_PRECISION = "f16mx"          # what ClipRenderer(precision='throughput') asks for: the default since round 5
 FP32_CLASS_SR_PRECISION = "f16x3"
+# A/B switch: 1 = the head network re-folds block1's conv1 operand every frame from max|block0 output| measured in block0's epilogue (rounds 3-4: the
+# e4m3 records needed the operand within one layer of a measurement).  Round 5: the e5m2 records have the fp16 hi plane's exponent range, the
+# propagated bound of the main fold serves f16mx as it always served f16x3 -- one launch (~10 us on one stream) and one atomic per frame less.
+_MX_TAIL_FOLD = os.environ.get("R3D_MX_TAIL_FOLD", "0") == "1"
 _MX_UPCONV = os.environ.get("R3D_MX_UPCONV", "1") != "0"      # A/B switch: 0 = f16mx keeps block1's up-sampling conv on the 3-term fp16 split
 
 
@@ -752,13 +756,13 @@ class SuperresolutionHybrid8XDC(nn.Module):
         b1.precision = b0.precision
         prep0 = b0.prepare(ws3, dev, ws_key=ws)
         prep1 = b1.prepare(ws3, dev, ws_key=ws)
-        mx = b0.precision == "f16mx"
+        mx = b0.precision == "f16mx" and _MX_TAIL_FOLD
         x_absmax = None
         if b0.precision in ("f16x3", "f16mx"):
             # one fold launch for both blocks; block0's conv1 epilogue then emits its output already multiplied by block1.conv0's
             # folded styles and split into fp16 hi/lo planes, so block1 stages its input with plain copies
             b0._depth_in, b1._depth_in = dx, dx + 2
-            if mx:      # block1's conv1 operand must sit within one layer of a measurement: block0 measures max|x0| in its epilogue
+            if mx:      # R3D_MX_TAIL_FOLD=1: block1's conv1 operand within one layer of a measurement: block0 measures max|x0| in its epilogue
                 if self._mx_slot is None or self._mx_slot.shape[0] != N or self._mx_slot.device != dev:
                     self._mx_slot = torch.zeros(N, device=dev, dtype=torch.float32)
                 x_absmax = self._mx_slot
@@ -804,9 +808,9 @@ class SuperresolutionHybrid8XDC(nn.Module):
             bx, dx = None, 0
             if b0.precision in ("f16x3", "f16mx"):
                 x = _keep_tags(x)
-                bx, dx = bound_of(x, self._meter, layers=4 if b0.precision != "f16mx" else MAX_DEPTH + 1)
+                bx, dx = bound_of(x, self._meter, layers=4)
         ws3, prep0, prep1, x_absmax = self._prepare_and_fold(ws, N, dev, bx, dx)
-        mx = b0.precision == "f16mx"
+        mx = x_absmax is not None              # (f16mx with R3D_MX_TAIL_FOLD=1)
         if b0.precision in ("f16x3", "f16mx"):
             # f16mx: block0's conv1 epilogue leaves fp8 records in the lo plane and block1's up-sampling conv runs its cross products on them
             b0.out_format, nxt = ("split_mx" if b1.wants_mx() else "split"), b1
