@@ -193,6 +193,65 @@ def _forward_v2(self, S, rgb, x, ws, ref_torso_rgb, ref_bg_rgb, weights_img, seg
     return rgb_out, ret
 
 
+def infer_forward_stage1(self, rgb, x, ws, ref_torso_rgb, ref_bg_rgb, weights_img, segmap, kp_s, kp_d, **block_kwargs):
+    """sr_with_ref.py:164-188 (the reference's two-stage entry, unused by real3d_infer.py): block0 + the warp network's first stage; returns
+    the dict the second stage continues from (keys as the reference: the torso model's own + 'ref_bg_rgb_256', 'weights_256', 'x', 'ws',
+    'rgb').  Runs the HIP operators one by one (each folds its own range): the fused per-frame path is `forward`."""
+    aa = self.sr_antialias
+    weights_img = weights_img.detach()
+    ws3 = ws[:, -1:, :].repeat(1, 3, 1)                                                                  # :167
+    if x.shape[-1] != self.input_resolution:                                                            # :169-173
+        sz = (self.input_resolution, self.input_resolution)
+        x, rgb = resize_bilinear(x, sz, aa), resize_bilinear(rgb, sz, aa)
+    rgb_256 = resize_bilinear(rgb, (256, 256), aa)                                                      # :175-178
+    weights_256 = resize_bilinear(weights_img, (256, 256), aa)
+    ref_torso_rgb_256 = resize_bilinear(ref_torso_rgb, (256, 256), aa)
+    ref_bg_rgb_256 = resize_bilinear(ref_bg_rgb, (256, 256), aa)
+    kw = dict(block_kwargs)
+    kw.setdefault("noise_mode", "none")
+    b0 = self.block0
+    saved = (b0.out_format, b0.return_x)
+    try:
+        b0.out_format, b0.return_x = "nchw", True
+        x, rgb = b0(x, rgb, ws3, **kw)                                                                  # :180
+    finally:
+        b0.out_format, b0.return_x = saved
+    ret = self.torso_model.infer_forward_stage1(ref_torso_rgb_256, segmap, kp_s, kp_d, rgb_256.detach(), cal_loss=True)      # :182
+    ret["ref_bg_rgb_256"], ret["weights_256"], ret["x"], ret["ws"], ret["rgb"] = ref_bg_rgb_256, weights_256, x, ws3, rgb
+    return ret
+
+
+def infer_forward_stage2(self, facev2v_ret, **block_kwargs):
+    """sr_with_ref.py:190-218: the warp network's second stage, the alpha / occlusion blends, fuse_fg_bg_convs, block1 -> (rgb, ret).
+    (This entry blends x and x_torso directly -- no fuse_head_torso_convs / head_torso_block -- and thresholds the head mask at 0.5.)"""
+    hp = self._r3d_state.hparams
+    x, ws3, rgb = facev2v_ret["x"], facev2v_ret["ws"], facev2v_ret["rgb"]
+    ref_bg_rgb_256, weights_256 = facev2v_ret["ref_bg_rgb_256"], facev2v_ret["weights_256"]
+    rgb_torso = self.torso_model.infer_forward_stage2(facev2v_ret)                                      # :196
+    x_torso = self.torso_encoder(facev2v_ret["deformed_torso_hid"])                                     # :197
+    x_bg = self.bg_encoder(ref_bg_rgb_256)                                                              # :198
+    kw = dict(block_kwargs)
+    kw.setdefault("noise_mode", "none")
+    b1 = self.block1
+    saved = (b1.out_format, b1.return_x)
+    try:
+        b1.out_format, b1.return_x = "nchw", True
+        if hp.get("weight_fuse", True):
+            rgb = blend(rgb, rgb_torso, weights_256)                                                    # :201
+            x = blend(x, x_torso, weights_256)                                                          # :202
+            torso_occ = resize_bilinear(facev2v_ret["occlusion_2"], (256, 256), self.sr_antialias)     # :206
+            pocc = person_occlusion(weights_256, torso_occ, 0.5)                                        # :204-207
+            rgb = blend(rgb, ref_bg_rgb_256, pocc)                                                      # :209
+            x = self.fuse_fg_bg_convs(blend_cat(x, x_bg, pocc, self.fuse_fg_bg_convs))                  # :210-211
+            x, rgb = b1(x, rgb, ws3, **kw)                                                              # :212
+        else:
+            raise NotImplementedError("weight_fuse=False: block1 is called with img=None there (sr_with_ref.py:214-216), which the HIP "
+                                      "SynthesisBlock does not build")
+    finally:
+        b1.out_format, b1.return_x = saved
+    return rgb, facev2v_ret
+
+
 class SuperresolutionHybrid8XDC_Warp(torch.nn.Module):
     """Mirror of the reference class (sr_with_ref.py:16-63) for the shipped configuration (weight_fuse, fuse mode 'v2'): same
     attribute names and state_dict keys for everything except `torso_model`, which is PASSED IN (the reference's face-vid2vid
@@ -227,6 +286,8 @@ class SuperresolutionHybrid8XDC_Warp(torch.nn.Module):
         self._r3d_state = WarpSRState(hp)
 
     forward = forward_v2
+    infer_forward_stage1 = infer_forward_stage1
+    infer_forward_stage2 = infer_forward_stage2
 
     def split_input_spec(self, ws, N, dev):
         return warp_split_input_spec(self, ws, N, dev)

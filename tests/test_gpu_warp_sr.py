@@ -39,6 +39,35 @@ def test_warp_sr_forward_v2_golden():
     assert not torch.equal(out2, outs[0])
 
 
+def test_warp_sr_two_stage_entry_golden():
+    """The reference's two-stage entry (sr_with_ref.py:164-218: infer_forward_stage1 -> infer_forward_stage2, unused by real3d_infer.py) on the
+    mirror class against the reference's own outputs (tests/golden/warp_sr_two_stage_a.npz): block0's x, the dict's keys, the final image."""
+    import torch
+    import warp_mock
+    from real3dportrait_amd.sr_with_ref import SuperresolutionHybrid8XDC_Warp
+    g = load_golden("warp_sr_two_stage_a")
+    sr = SuperresolutionHybrid8XDC_Warp(32, 512, 0, True, torso_model=warp_mock.MockTorso()).cuda()
+    warp_mock.load_warp_params(sr, lambda blk, p: load_block(torch, blk, p), to=lambda a: T(torch, a))
+    i = {k: T(torch, v) for k, v in warp_mock.warp_inputs().items()}
+    ret = sr.infer_forward_stage1(i["x"][:, :3].contiguous(), i["x"], i["ws"], i["ref_torso_rgb"], i["ref_bg_rgb"], i["weights_img"], None, None, None,
+                                  noise_mode="none")
+    assert sorted(k for k in ret if not k.startswith("_")) == [str(k) for k in g["keys"]]
+    x0 = ret["x"].cpu().numpy()
+    assert x0.shape == (1, 256, 256, 256)
+    assert np.abs(x0[:, ::8, ::8, ::8] - g["x0_strided"]).max() <= SR_TOL * max(1.0, np.abs(g["x0_strided"]).max())
+    out, ret2 = sr.infer_forward_stage2(ret, noise_mode="none")
+    assert ret2 is ret
+    out = out.cpu().numpy()
+    tol = SR_TOL * max(1.0, np.abs(g["strided"]).max())
+    assert out.shape == (1, 3, 512, 512)
+    e = max(np.abs(out[:, :, ::4, ::4] - g["strided"]).max(), np.abs(out[:, :, :96, :96] - g["corner"]).max(), np.abs(out[:, :, -64:, -64:] - g["tail"]).max())
+    print("two-stage entry [%s]: final image err %.2e (tier %.1e)" % (sr.block0.precision, e, tol))
+    assert e <= tol
+    assert abs(float(np.abs(out).mean()) - float(g["absmean"])) <= 1e-4
+    # the hand-off formats the fused forward sets per call are untouched by the two-stage entry
+    assert sr.block0.out_format == "nchw" and sr.block1.out_format == "nchw" and sr.block1.return_x is True
+
+
 def test_resize_blend_kernels_vs_torch():
     """r3d_resize_bilinear vs F.interpolate(bilinear, align_corners=False, antialias) for the three shapes of sr_with_ref.py:77-82,110
     and odd sizes; r3d_blend / r3d_person_occlusion vs the torch expressions."""

@@ -26,6 +26,17 @@ class MockTorso(torch.nn.Module):
         occ = torch.from_numpy(synth.synth_noise(self.seed, (N, 1, 64, 64), stream=33)).to(dev)
         return rgb_torso, {"deformed_torso_hid": hid, "occlusion_2": occ}
 
+    # the two-stage entry (WarpBasedTorsoModelMediaPipe.infer_forward_stage1 / _stage2, called by sr_with_ref.py:182,196): stage 1 returns the
+    # dict, stage 2 the torso image computed from what stage 1 left in it
+    def infer_forward_stage1(self, ref_torso_rgb_256, segmap, kp_s, kp_d, rgb_256, cal_loss=True):
+        N, dev = rgb_256.shape[0], rgb_256.device
+        rgb_torso, ret = self.forward(ref_torso_rgb_256, segmap, kp_s, kp_d, rgb_256, torch.ones(N, 1, 256, 256, device=dev) * 0.5)
+        ret["_rgb_torso"] = rgb_torso
+        return ret
+
+    def infer_forward_stage2(self, ret):
+        return ret["_rgb_torso"]
+
 
 def warp_inputs(seed=SEED, N=1):
     t = lambda shape, s, g=1.0: synth.hash_unitvar(seed, shape, stream=s) * np.float32(g)
