@@ -99,8 +99,16 @@ def forward_v2(self, rgb, x, ws, ref_torso_rgb, ref_bg_rgb, weights_img, segmap,
     """Signature and return value of SuperresolutionHybrid8XDC_Warp.forward (sr_with_ref.py:67): (rgb [N,3,512,512], facev2v_ret)."""
     S = self._r3d_state
     hp = S.hparams
+    if hp.get("weight_fuse", True) and hp.get("htbsr_head_weight_fuse_mode") == "v1" and getattr(self, "_r3d_reference_forward", None) is None:
+        # fuse mode v1 (sr_with_ref.py:92-104; not the shipped configuration): the direct alpha blend of x and x_torso -- the flow of the two-stage
+        # entry with the hparams' head threshold.  Operator by operator (each folds its own range), not fused.
+        return _forward_v1(self, rgb, x, ws, ref_torso_rgb, ref_bg_rgb, weights_img, segmap, kp_s, kp_d, target_torso_mask, block_kwargs)
     if not hp.get("weight_fuse", True) or hp.get("htbsr_head_weight_fuse_mode") != "v2":
-        raise NotImplementedError("fused HIP forward covers weight_fuse=True, htbsr_head_weight_fuse_mode='v2' (the shipped torso model)")
+        ref_forward = getattr(self, "_r3d_reference_forward", None)
+        if ref_forward is not None:        # a patch_model()'d reference module: its own forward over the patched sub-modules
+            return ref_forward(rgb, x, ws, ref_torso_rgb, ref_bg_rgb, weights_img, segmap, kp_s, kp_d, target_torso_mask=target_torso_mask, **block_kwargs)
+        raise NotImplementedError("the HIP forward covers weight_fuse=True with htbsr_head_weight_fuse_mode 'v2' (fused: the shipped torso model) and 'v1' "
+                                  "(operator by operator); 'v3' adds a learned mask post-processing (head_torso_alpha_predictor) that is not built")
     if self.block0.precision == "f32":
         # the exact-f32 kernels have no channel-blocked hand-off / epilogue measurements: run the reference's own forward over the
         # patched sub-modules (patch_model keeps it), or refuse for the mirror class that has none
@@ -118,6 +126,47 @@ def forward_v2(self, rgb, x, ws, ref_torso_rgb, ref_bg_rgb, weights_img, segmap,
     finally:
         for m, fmt, rx in saved:
             m.out_format, m.return_x = fmt, rx
+
+
+def _forward_v1(self, rgb, x, ws, ref_torso_rgb, ref_bg_rgb, weights_img, segmap, kp_s, kp_d, target_torso_mask, block_kwargs):
+    hp = self._r3d_state.hparams
+    aa = self.sr_antialias
+    weights_img = weights_img.detach()
+    N = rgb.shape[0]
+    ws3 = ws[:, -1:, :].expand(N, 3, -1).contiguous()                                                   # :69
+    if x.shape[-1] != self.input_resolution:
+        sz = (self.input_resolution, self.input_resolution)
+        x, rgb = resize_bilinear(x, sz, aa), resize_bilinear(rgb, sz, aa)
+    rgb_256 = resize_bilinear(rgb, (256, 256), aa)
+    weights_256 = resize_bilinear(weights_img, (256, 256), aa)
+    ref_torso_rgb_256 = resize_bilinear(ref_torso_rgb, (256, 256), aa)
+    ref_bg_rgb_256 = resize_bilinear(ref_bg_rgb, (256, 256), aa)
+    kw = dict(block_kwargs)
+    kw.setdefault("noise_mode", "none")
+    b0, b1 = self.block0, self.block1
+    saved = [(m, m.out_format, m.return_x) for m in (b0, b1)]
+    try:
+        b0.out_format, b0.return_x, b1.out_format, b1.return_x = "nchw", True, "nchw", True
+        x, rgb = b0(x, rgb, ws3, **kw)                                                                  # :83
+        if hp.get("torso_model_version", "v1") == "v1":
+            rgb_torso, ret = self.torso_model.forward(ref_torso_rgb_256, segmap, kp_s, kp_d, rgb_256.detach(), cal_loss=True,
+                                                      target_torso_mask=target_torso_mask)
+        else:
+            rgb_torso, ret = self.torso_model.forward(ref_torso_rgb_256, segmap, kp_s, kp_d, rgb_256.detach(), weights_256.detach(),
+                                                      cal_loss=True, target_torso_mask=target_torso_mask)
+        x_torso = self.torso_encoder(ret["deformed_torso_hid"])                                         # :88
+        x_bg = self.bg_encoder(ref_bg_rgb_256)                                                          # :90
+        rgb = blend(rgb, rgb_torso, weights_256)                                                        # :94
+        x = blend(x, x_torso, weights_256)                                                              # :95
+        torso_occ = resize_bilinear(ret["occlusion_2"], (256, 256), aa)                                 # :99
+        pocc = person_occlusion(weights_256, torso_occ, hp["htbsr_head_threshold"])                     # :96-100
+        rgb = blend(rgb, ref_bg_rgb_256, pocc)                                                          # :101
+        x = self.fuse_fg_bg_convs(blend_cat(x, x_bg, pocc, self.fuse_fg_bg_convs))                      # :102-103
+        _, rgb = b1(x, rgb, ws3, **kw)                                                                  # :104
+    finally:
+        for m, fmt, rx in saved:
+            m.out_format, m.return_x = fmt, rx
+    return rgb, ret
 
 
 def _forward_v2(self, S, rgb, x, ws, ref_torso_rgb, ref_bg_rgb, weights_img, segmap, kp_s, kp_d, target_torso_mask, block_kwargs):

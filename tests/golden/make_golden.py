@@ -467,6 +467,33 @@ def warp_sr_two_stage_case(name):
     print(name, out.shape, float(np.abs(out).mean()))
 
 
+def warp_sr_v1_case(name):
+    """SuperresolutionHybrid8XDC_Warp.forward with htbsr_head_weight_fuse_mode = 'v1' (sr_with_ref.py:92-104: the direct alpha blend of x and x_torso;
+    not a shipped configuration): same parameters, inputs and stand-in torso network as warp_sr_case."""
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import ref_stubs
+    import warp_mock
+    ref_stubs.install()
+    from utils.commons.hparams import set_hparams, hparams
+    set_hparams(os.path.join(REF, "egs/os_avatar/real3d_orig/secc_img2plane_torso_orig.yaml"), print_hparams=False)
+    hparams["htbsr_head_weight_fuse_mode"] = "v1"
+    from modules.real3d.super_resolution.sr_with_ref import SuperresolutionHybrid8XDC_Warp
+    sr = SuperresolutionHybrid8XDC_Warp(channels=32, img_resolution=512, sr_num_fp16_res=0, sr_antialias=True, channel_base=32768,
+                                        channel_max=512, fused_modconv_default="inference_only").eval()
+    sr.torso_model = warp_mock.MockTorso()
+    warp_mock.load_warp_params(sr, load_block)
+    i = {k: torch.from_numpy(v) for k, v in warp_mock.warp_inputs().items()}
+    with torch.no_grad():
+        out, ret = sr(i["x"][:, :3].contiguous(), i["x"], i["ws"], i["ref_torso_rgb"], i["ref_bg_rgb"], i["weights_img"], None, None, None,
+                      noise_mode="none")
+    hparams["htbsr_head_weight_fuse_mode"] = "v2"
+    out = out.numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=warp_mock.SEED, threshold=np.float64(hparams["htbsr_head_threshold"]),
+                        strided=out[:, :, ::4, ::4], corner=out[:, :, :96, :96], tail=out[:, :, -64:, -64:],
+                        absmean=np.float64(np.abs(out).mean()))
+    print(name, out.shape, float(np.abs(out).mean()))
+
+
 def render_r512_case(name, Nf):
     """BASELINE configs[1] read literally: a 512x512 NEURAL render (R = 512) with 48 (+48) depth samples on full-size planes.  The
     reference renders all 262 144 rays; the fixture keeps the rays of every 8th row and column (the global couplings -- min / max of
@@ -526,7 +553,7 @@ def sr_resize_case(name):
 
 def main():
     which = sys.argv[1:] or ["render", "run_model", "sr_small", "sr_full", "synthesis", "fusion", "toplane", "sr_cfg5", "fusion_full",
-                             "toplane_full", "synthesis_mask", "warp_sr", "warp_sr_two_stage", "render_r512", "sr_resize"]
+                             "toplane_full", "synthesis_mask", "warp_sr", "warp_sr_two_stage", "warp_sr_v1", "render_r512", "sr_resize"]
     if "render_r512" in which:
         render_r512_case("render_g_r512_48p0", 0)
         render_r512_case("render_h_r512_48p48_sr", 48)
@@ -536,6 +563,8 @@ def main():
         warp_sr_case("warp_sr_a")
     if "warp_sr_two_stage" in which:
         warp_sr_two_stage_case("warp_sr_two_stage_a")
+    if "warp_sr_v1" in which:
+        warp_sr_v1_case("warp_sr_v1_a")
     if "sr_cfg5" in which:
         sr_cfg5_case("sr_cfg5_a")
     if "fusion_full" in which:

@@ -19,7 +19,7 @@ WITH_TORCH = [tp.test_synthesis_golden, tp.test_fusion_stacks_golden, tp.test_to
               tp.test_ray_kernel_split_output_equals_conversion_launch, tp.test_synthesis_batch_of_two_equals_two_singles,
               tr.test_sr_cfg5_golden, tr.test_fusion_stacks_full_size_golden, tr.test_to_plane_cnn_full_size_golden, tr.test_fused_u8_epilogue_equals_reference_formula,
               tr.test_synthesis_mask_invalid_rays_golden, tr.test_bounds_are_upper_bounds_and_stored_operands_fit_fp16]
-PLAIN = [tw.test_warp_sr_forward_v2_golden, tw.test_warp_sr_two_stage_entry_golden, tw.test_torso_frame_fused_input_equals_unfused_sequence,
+PLAIN = [tw.test_warp_sr_forward_v2_golden, tw.test_warp_sr_two_stage_entry_golden, tw.test_warp_sr_forward_fuse_mode_v1_golden, tw.test_torso_frame_fused_input_equals_unfused_sequence,
          tw.test_warp_sr_forward_v2_batch_of_two_equals_two_singles]
 
 

@@ -68,6 +68,29 @@ def test_warp_sr_two_stage_entry_golden():
     assert sr.block0.out_format == "nchw" and sr.block1.out_format == "nchw" and sr.block1.return_x is True
 
 
+def test_warp_sr_forward_fuse_mode_v1_golden():
+    """htbsr_head_weight_fuse_mode = 'v1' (sr_with_ref.py:92-104, not a shipped configuration) on the mirror class, operator by operator, against
+    the reference's forward under the same hparams (tests/golden/warp_sr_v1_a.npz); 'v3' stays a descriptive NotImplementedError."""
+    import torch
+    import warp_mock
+    from real3dportrait_amd.sr_with_ref import SuperresolutionHybrid8XDC_Warp
+    g = load_golden("warp_sr_v1_a")
+    sr = SuperresolutionHybrid8XDC_Warp(32, 512, 0, True, torso_model=warp_mock.MockTorso(),
+                                        hparams={"htbsr_head_threshold": float(g["threshold"]), "htbsr_head_weight_fuse_mode": "v1"}).cuda()
+    warp_mock.load_warp_params(sr, lambda blk, p: load_block(torch, blk, p), to=lambda a: T(torch, a))
+    i = {k: T(torch, v) for k, v in warp_mock.warp_inputs().items()}
+    args = (i["x"][:, :3].contiguous(), i["x"], i["ws"], i["ref_torso_rgb"], i["ref_bg_rgb"], i["weights_img"], None, None, None)
+    out, ret = sr(*args, noise_mode="none")
+    out = out.cpu().numpy()
+    tol = SR_TOL * max(1.0, np.abs(g["strided"]).max())
+    e = max(np.abs(out[:, :, ::4, ::4] - g["strided"]).max(), np.abs(out[:, :, :96, :96] - g["corner"]).max(), np.abs(out[:, :, -64:, -64:] - g["tail"]).max())
+    print("fuse mode v1 [%s]: final image err %.2e (tier %.1e)" % (sr.block0.precision, e, tol))
+    assert out.shape == (1, 3, 512, 512) and e <= tol and abs(float(np.abs(out).mean()) - float(g["absmean"])) <= 1e-4
+    sr._r3d_state.hparams["htbsr_head_weight_fuse_mode"] = "v3"
+    with pytest.raises(NotImplementedError):
+        sr(*args, noise_mode="none")
+
+
 def test_resize_blend_kernels_vs_torch():
     """r3d_resize_bilinear vs F.interpolate(bilinear, align_corners=False, antialias) for the three shapes of sr_with_ref.py:77-82,110
     and odd sizes; r3d_blend / r3d_person_occlusion vs the torch expressions."""

@@ -281,6 +281,8 @@ def test_full_size_goldens_are_present_and_consistent():
     assert 0.2 < float(g["masked_frac"]) < 0.6 and g["image_raw"].shape == (1, 3, 128, 128)
     g = load_golden("warp_sr_a")
     assert g["strided"].shape == (1, 3, 128, 128) and float(g["threshold"]) == 0.9
+    g = load_golden("warp_sr_v1_a")                 # fuse mode v1 of the same forward (round 5)
+    assert g["strided"].shape == (1, 3, 128, 128) and float(g["threshold"]) == 0.9
     g = load_golden("warp_sr_two_stage_a")          # the reference's two-stage entry of the same module (round 5)
     assert g["strided"].shape == (1, 3, 128, 128) and g["x0_strided"].shape == (1, 32, 32, 32)
     assert {"deformed_torso_hid", "occlusion_2", "ref_bg_rgb_256", "weights_256", "x", "ws", "rgb"} <= set(str(k) for k in g["keys"])

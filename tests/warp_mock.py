@@ -52,9 +52,12 @@ def load_warp_params(sr, load_block, seed=SEED, to=lambda a: torch.from_numpy(np
     sr_with_ref.py:24-63), for the reference module and for ours alike."""
     load_block(sr.block0, synth.synth_sr_block(seed, 32, 256, 512, 100))
     load_block(sr.block1, synth.synth_sr_block(seed, 256, 128, 512, 200))
-    load_block(sr.head_torso_block, synth.synth_sr_block(seed, 256, 256, 512, 400))
+    if hasattr(sr, "head_torso_block"):            # (the reference builds it and fuse_head_torso_convs for fuse modes v2 / v3 only, sr_with_ref.py:36-55)
+        load_block(sr.head_torso_block, synth.synth_sr_block(seed, 256, 256, 512, 400))
     with torch.no_grad():
         for i, (name, plan) in enumerate(synth.FUSION_STACKS.items()):
+            if not hasattr(sr, name):
+                continue
             convs = [m for m in getattr(sr, name) if hasattr(m, "weight")]
             for m, (w, b) in zip(convs, synth.synth_conv_stack(seed, plan, 300 + 20 * i)):
                 m.weight.copy_(to(w)); m.bias.copy_(to(b))
