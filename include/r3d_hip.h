@@ -151,10 +151,11 @@ size_t r3d_run_model_workspace_bytes(void);
  *   by the consumer conv's style vector -- as input it must have been scaled with this block's conv0 styles; as
  *   output it is scaled with `next_scale` ([N][Cout] floats, stride next_scale_stride: the next block's conv0 styles,
  *   i.e. the start of that block's styles buffer).
- *   R3D_FMT_SPLIT_MX (R3D_SR_F16MX, up = 1 blocks): R3D_FMT_SPLIT whose lo plane holds, byte for byte in its place, the fp8 correction
- *   records of the f16mx precision (lo chunk 2G: xh8 = e4m3(hi * 2^-7) of channels 16G..16G+15, lo chunk 2G+1: xl8 = e4m3(lo * 2^4)).
+ *   R3D_FMT_SPLIT_MX (R3D_SR_F16MX): R3D_FMT_SPLIT whose lo plane holds, byte for byte in its place, the 8-bit correction
+ *   records of the f16mx precision: lo chunk 2G: xh8 = e5m2(hi) of channels 16G..16G+15, lo chunk 2G+1: xl8 = e5m2(lo * 2^11) (OCP e5m2 since ABI
+ *   0.5.0 -- a per-element exponent with the fp16 hi plane's range; 0.4.0: e4m3 of hi * 2^-7 / lo * 2^4, one exponent per tensor).
  *   As x_out_format the block's conv1 epilogue writes them; as x_format the block's up-sampling conv runs its cross products on the
- *   block-scaled fp8 MFMA (2 instead of 3 matrix passes per MAC).  A producer / consumer pair must agree (same next_scale as SPLIT).
+ *   block-scaled 8-bit MFMA (2 instead of 3 matrix passes per MAC).  A producer / consumer pair must agree (same next_scale as SPLIT).
  *   clamp < 0 disables conv_clamp (the fp32 configuration Real3D uses, img2plane_baseline.py:102-104).
  *   img_u8 (may be NULL; R3D_SR_F16X3 only): [N,OH,OW,3] uint8 -- the block is the last one of the network and the frame leaves
  *   as clamp(-1,1) -> ((x + 1) / 2 * 255).int() (triplane.py:136 + inference/real3d_infer.py:472,518-522), fused into the
@@ -167,14 +168,15 @@ size_t r3d_run_model_workspace_bytes(void);
  *            R3D_SR_F16X3 fp32-accurate on the f16 matrix pipe: every operand is split x = hi + lo (two fp16
  *                         terms, 2^-24 relative) and hi*hi + hi*lo + lo*hi is accumulated in fp32 by
  *                         v_mfma_f32_32x32x16_f16 (3 MFMAs at 16x the f32 rate; ~1e-7 relative per dot product).
- *            R3D_SR_F16MX (what the Python operators pass by default since round 3; up = 1 blocks): as F16X3, but in the block's plain 3x3 conv (conv1, 80 % of the block's FLOPs) the two
- *                         2^-11-sized correction products hi*lo + lo*hi of two taps x 16 channels are ONE block-scaled fp8 MFMA
- *                         (v_mfma_scale_f32_32x32x64_f8f6f4, OCP e4m3, 2x the f16 rate) instead of four f16 MFMAs: 1.5x fewer matrix
- *                         cycles.  The correction is then accurate to fp8 rounding, i.e. ~2^-16 of each product (between fp32's
- *                         2^-24 and TF32's 2^-11); parity tier: <= 5e-5 * max|ref| per block on the reference goldens, <= 1e-4 over
- *                         the 2^-20..2^14 operand sweeps vs fp64 (measured 3.3e-5) (tests/test_gpu_mx.py).  Needs the
- *                         block's conv1 operand within one layer of a measured bound (fold the block with R3D_CHAIN_SR_BLOCK_TAIL
- *                         from a measured max|x| when its input bound is a propagated one).
+ *            R3D_SR_F16MX (what the Python operators pass by default): as F16X3, but in the 3x3 convs whose input arrives as R3D_FMT_SPLIT_MX the two
+ *                         2^-11-sized correction products hi*lo + lo*hi of two taps x 16 channels are ONE block-scaled 8-bit MFMA
+ *                         (v_mfma_scale_f32_32x32x64_f8f6f4: activation records OCP e5m2, weight records OCP e4m3, 2x the f16 rate) instead of
+ *                         four f16 MFMAs: 1.5x fewer matrix cycles.  The correction is then accurate to e5m2 rounding, i.e. ~2^-15 of each
+ *                         product (between fp32's 2^-24 and TF32's 2^-11); parity: <= 5e-5 * max|ref| per block on the reference goldens,
+ *                         <= 6.3e-5 near and far field on the heavy-tail sweeps (spikes of 2^6 .. 2^14 sigma) against the 2e-4 tolerance of
+ *                         the path, <= 1e-4 over the 2^-20..2^14 operand sweeps vs fp64 (tests/test_gpu_mx.py, tests/test_gpu_pinned_config.py).
+ *                         The records have the hi plane's exponent range: no measured bound is needed beyond what R3D_SR_F16X3 needs
+ *                         (R3D_CHAIN_SR_BLOCK_TAIL stays available for chains deeper than three layers).
  *            The prepacked buffer is precision-specific (same size). */
 enum r3d_sr_precision { R3D_SR_F32 = 0, R3D_SR_F16X3 = 1, R3D_SR_F16MX = 2 };
 enum r3d_act_format { R3D_FMT_NONE = -1, R3D_FMT_NCHW = 0, R3D_FMT_CB8 = 1, R3D_FMT_SPLIT = 2, R3D_FMT_SPLIT_MX = 3 };
