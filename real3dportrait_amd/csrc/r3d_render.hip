@@ -31,6 +31,9 @@ static constexpr int kWavesPerBlock = 4;
 #ifndef R3D_RENDER_BIG_OCC_DEFAULT
 #define R3D_RENDER_BIG_OCC_DEFAULT 2
 #endif
+#ifndef R3D_RENDER_GPARK
+#define R3D_RENDER_GPARK 1       // experiment switch: 0 = the big shapes leave their coarse colours to the register allocator (round 4)
+#endif
 
 // -------------------------------------------------------------------------------------------------
 // layout kernel: NCHW [N*3][C][H*W] (+ optional add, optionally flipped along H / W per plane) -> [N*3][H*W][C]
@@ -830,7 +833,7 @@ struct TileGather {                               // one lane quad = one sample;
 template <int NT, int GPF, bool TRI, typename DepthFn>
 __device__ __forceinline__ void decode_pass(FeatLds& F, const DecoderLds& dec, const float4* __restrict__ P, int H, int W, int D, int lane,
                                             float ox, float oy, float oz, float dx, float dy, float dz, float scale, float xs3,
-                                            DepthFn depth_of, f32x4 (&col0)[NT], f32x4 (&col1)[NT], float (&sig)[NT])
+                                            DepthFn depth_of, f32x4 (&col0)[NT], f32x4 (&col1)[NT], float (&sig)[NT], f32x4* gp = nullptr)
 {
     const int gq = lane & 3, gs = lane >> 2, q = lane >> 4, s = lane & 15;
     // Staging slots: slot(sample, k-slot q) = 16 q + (sample ^ 2 q).  A ds_read_b128 is served in the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19,
@@ -892,7 +895,8 @@ __device__ __forceinline__ void decode_pass(FeatLds& F, const DecoderLds& dec, c
         __builtin_amdgcn_sched_barrier(0);
         if (more && !TRI) { g.template pin<0>(c2[0], c2[1]); g.template consume<2, 0>(); g.finish(F, (t + 1) & 1, wi, xs3); }
         if (more && TRI) gather_whole(t + 1);
-        col0[t] = c2[0]; col1[t] = c2[1];
+        if (gp) { gp[(2 * t) * 64] = c2[0]; gp[(2 * t + 1) * 64] = c2[1]; }      // (the big shapes: colours straight to the workspace parking, see render_kernel)
+        else { col0[t] = c2[0]; col1[t] = c2[1]; }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -941,6 +945,7 @@ struct RenderArgs {
     const DecFold* fold;                            // written by decoder_fold_kernel (same stream, before this kernel)
     float* rgb; float* depth; float* wsum; int rgb_cm;      // rgb_cm: rgb is [N,32,M] (channel-major) instead of [N,M,32]; depth may be NULL
     unsigned long long* clk;                        // prof_clock_slot(R3D_PROF_RENDER) or null
+    f32x4* park_g;                                  // shapes with more than 3 coarse tiles: [wave of the grid][2 (NTC + NTF)][64] f32x4 parking of a ray's colours (workspace)
 };
 
 // Ray order: XCD x (= blockIdx % 8, the observed dispatch rule -- speed only) renders the column strip
@@ -1002,6 +1007,10 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
     // and the fine pass (its own colours + the gather pipeline's load buffers) is where the register file runs out (REF shape: 256 VGPRs and
     // spills to scratch, whose loads share vmcnt with the gather).  6 KB per wave; only for shapes whose block stays under 80 KB of LDS.
     constexpr bool PARK = NTF > 0 && NTC <= 3;
+    // Round 5: the bigger shapes park ALL colours of a ray -- coarse and fine, tile by tile as the decode produces them -- in the workspace (2 (NTC +
+    // NTF) KB per wave, each 16 B per lane written once and read once per ray, served by L2) instead of leaving 96 live registers to the allocator
+    // (built without packed-f32 instructions <6,6> spilled 131 registers and BASELINE config 5's render took 15.0 instead of 12.5 ms).
+    constexpr bool GPARK = NTF > 0 && NTC > 3 && R3D_RENDER_GPARK;
     __shared__ __attribute__((aligned(16))) f32x4 park[PARK ? kWavesPerBlock : 1][PARK ? 2 * NTC : 1][64];
 
     stage_decoder(dec, a.w1, a.b1, a.w2, a.b2, a.fold);
@@ -1072,6 +1081,8 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
         // ---- coarse pass: gather + decode ----------------------------------------------------------------
         f32x4 colc[2][NTC];
         float sigc[NTC];
+        f32x4* gpark = nullptr;                         // GPARK: this wave's [2 (NTC + NTF)][64] f32x4 slots of the workspace
+        if constexpr (GPARK) gpark = A.park_g + ((size_t)(blockIdx.x * kWavesPerBlock + wave) * (2 * (NTC + NTF))) * 64 + lane;
         {
             // the depths go to the ray's LDS record first (the march reads them there anyway): the pass fetches the depth of the sample a lane
             // gathers for (lane gs of the per-sample mapping: q = 0, s = gs) per tile, as the fine pass does, instead of holding NTC shuffled
@@ -1085,13 +1096,14 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
             }
             wave_lds_sync();
             auto dof = [&](int t) { const int k = 16 * t + gs; return k < Nc ? L.t[k] : start; };
-            decode_pass<NTC, GPF, TRI>(F, dec, P, A.H, A.W, A.D, lane, ox, oy, oz, dx, dy, dz, A.scale, xs3, dof, colc[0], colc[1], sigc);
+            decode_pass<NTC, GPF, TRI>(F, dec, P, A.H, A.W, A.D, lane, ox, oy, oz, dx, dy, dz, A.scale, xs3, dof, colc[0], colc[1], sigc, gpark);
         }
         constexpr bool parked = PARK;                  // (an instantiation with NTF > 0 is only launched with Nf > 0)
         if (parked) {
 #pragma unroll
             for (int nt = 0; nt < NTC; ++nt) { park[PARK ? wave : 0][PARK ? 2 * nt : 0][lane] = colc[0][nt]; park[PARK ? wave : 0][PARK ? 2 * nt + 1 : 0][lane] = colc[1][nt]; }
         }
+
         if (q == 0) {
 #pragma unroll
             for (int nt = 0; nt < NTC; ++nt) {
@@ -1156,7 +1168,7 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
             float sigf[NTF > 0 ? NTF : 1];
             {
                 auto dof = [&](int t) { const int k = 16 * t + gs; return L.t[Nc + (k < Nf ? k : 0)]; };
-                decode_pass<(NTF > 0 ? NTF : 1), GPF, TRI>(F, dec, P, A.H, A.W, A.D, lane, ox, oy, oz, dx, dy, dz, A.scale, xs3, dof, colf[0], colf[1], sigf);
+                decode_pass<(NTF > 0 ? NTF : 1), GPF, TRI>(F, dec, P, A.H, A.W, A.D, lane, ox, oy, oz, dx, dy, dz, A.scale, xs3, dof, colf[0], colf[1], sigf, GPARK ? gpark + 2 * NTC * 64 : nullptr);
             }
             if (q == 0) {
 #pragma unroll
@@ -1296,6 +1308,7 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
             const float om = k < Nc ? L.om[k] : 0.0f;
             f32x4 cc0 = colc[0][nt], cc1 = colc[1][nt];
             if (parked) { cc0 = park[PARK ? wave : 0][PARK ? 2 * nt : 0][lane]; cc1 = park[PARK ? wave : 0][PARK ? 2 * nt + 1 : 0][lane]; }
+            if constexpr (GPARK) { cc0 = gpark[(2 * nt) * 64]; cc1 = gpark[(2 * nt + 1) * 64]; }
             acc[0] += cc0 * om;
             acc[1] += cc1 * om;
         }
@@ -1304,8 +1317,10 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
             for (int nt = 0; nt < NTF; ++nt) {
                 const int k = 16 * nt + s;
                 const float om = (fine_done && k < Nf) ? L.om[Nc + k] : 0.0f;
-                acc[0] += colf[0][nt] * om;
-                acc[1] += colf[1][nt] * om;
+                f32x4 cf0 = colf[0][nt], cf1 = colf[1][nt];
+                if constexpr (GPARK) { cf0 = gpark[(2 * (NTC + nt)) * 64]; cf1 = gpark[(2 * (NTC + nt) + 1) * 64]; }
+                acc[0] += cf0 * om;
+                acc[1] += cf1 * om;
             }
         }
 #pragma unroll
@@ -1439,6 +1454,7 @@ __global__ __launch_bounds__(256, 2) void run_model_kernel(const float4* __restr
 static inline size_t render_state_bytes(size_t nrays) { return ((kStateHeader + 3 * ((nrays + kLimitsBlock - 1) / kLimitsBlock)) * sizeof(int) + 63) & ~(size_t)63; }
 // decoder fold record (64 bytes) + room for the partials of plane_absmax_kernel (when the caller passes none)
 static constexpr size_t kFoldBytes = 64 + kAbsmaxBlocks * sizeof(float);
+static constexpr int kMaxGrid = 512;                     // blocks of a render launch (2 per CU)
 
 // launches (plane_absmax_kernel if needed +) decoder_fold_kernel; returns the device address of the DecFold record
 static const DecFold* launch_decoder_fold(const float* planes_nhwc, size_t plane_floats, const float* plane_absmax, int n_plane_absmax,
@@ -1540,9 +1556,10 @@ extern "C" int r3d_raygen(const float* c2w, const float* intrinsics, int N, int 
 
 extern "C" size_t r3d_render_workspace_bytes(int N, int M, int Nc, int Nf)
 {
-    (void)Nc; (void)Nf;
     const size_t nrays = (size_t)N * M;
-    return render_state_bytes(nrays) + 2 * nrays * sizeof(float) + 64 + kFoldBytes;
+    // + the colour parking of the shapes with more than 3 tiles per pass (Nc or Nf above 48: <4,4>, <6,6> and their tri-grid twins): 512 blocks x 4 waves x 2 * (6 + 6) tiles x 1 KB = 50 MB
+    const size_t park = (Nc > 48 || Nf > 48) ? (size_t)kMaxGrid * kWavesPerBlock * 24 * 64 * sizeof(f32x4) : 0;
+    return render_state_bytes(nrays) + 2 * nrays * sizeof(float) + 64 + kFoldBytes + park;
 }
 
 extern "C" size_t r3d_run_model_workspace_bytes(void) { return kFoldBytes; }
@@ -1578,6 +1595,7 @@ extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
     float* ray_start = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + render_state_bytes(nrays));
     float* ray_end = ray_start + nrays;
     void* fold_mem = reinterpret_cast<char*>(workspace) + ((render_state_bytes(nrays) + 2 * (size_t)nrays * sizeof(float) + 63) & ~(size_t)63);
+    f32x4* park_g = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(fold_mem) + kFoldBytes);      // (64-byte aligned: kFoldBytes is a multiple of 64)
 
     int R = 0;                                        // square image -> XCD strip order of the rays; otherwise linear order
     for (int r = 1; r * r <= M; ++r) if (r * r == M) R = r;
@@ -1607,10 +1625,11 @@ extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
     a.noise_c = noise_c; a.u_f = u_f; a.seed = seed;
     a.rgb = rgb; a.depth = depth; a.wsum = wsum; a.rgb_cm = rgb_channel_major ? 1 : 0;
     a.clk = prof_clock_slot(R3D_PROF_RENDER);
+    a.park_g = (Nc > 48 || Nf > 48) ? park_g : nullptr;      // (exactly the calls the dispatch below sends to a shape with more than 3 coarse tiles)
 
     // (R computed above: square image -> XCD strip order; otherwise linear order)
     const int waves_needed = nrays;
-    int grid = 512;                                   // 2 blocks per CU on 256 CUs, multiple of 8 (XCD strips)
+    int grid = kMaxGrid;                              // 2 blocks per CU on 256 CUs, multiple of 8 (XCD strips)
     const int max_blocks = ((waves_needed + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8;
     if (grid > max_blocks) grid = max_blocks;
 
