@@ -31,6 +31,9 @@ static constexpr int kWavesPerBlock = 4;
 #ifndef R3D_RENDER_BIG_OCC_DEFAULT
 #define R3D_RENDER_BIG_OCC_DEFAULT 2
 #endif
+#ifndef R3D_RENDER_GPARK_ALL
+#define R3D_RENDER_GPARK_ALL 0   // experiment switch: 1 = every shape with a fine pass parks its colours in the workspace (no LDS parking: 45 KB blocks)
+#endif
 #ifndef R3D_RENDER_GPARK
 #define R3D_RENDER_GPARK 1       // experiment switch: 0 = the big shapes leave their coarse colours to the register allocator (round 4)
 #endif
@@ -762,9 +765,10 @@ struct RayLds {
 struct FeatLds { uint4 v[2][2 * 64]; };           // [hi|lo][slot parity * 64 + swizzled lane]: 4 KB per wave
 
 typedef __amdgpu_buffer_rsrc_t PlaneRsrc;
+template <int NB = 2>
 struct TileGather {                               // one lane quad = one sample; lane q owns channels 8q..8q+7
-    f32x4 lo[2][4], hi[2][4];                     // two load buffers: the first tile of a pass keeps two planes in flight, the pipelined tiles one
-    float tw[2][4];
+    f32x4 lo[NB][4], hi[NB][4];                   // NB = 2 load buffers: the first tile of a pass keeps two planes in flight, the pipelined tiles one (NB = 1: the 3-waves-per-SIMD variant)
+    float tw[NB][4];
     Tap tq[4];
     float acc[8];
     // the taps of the tile: this lane computes plane min(q, 2)'s (the quad shares them by DPP, see gather_sample)
@@ -830,7 +834,7 @@ struct TileGather {                               // one lane quad = one sample;
 };
 
 // One pass over NT tiles.  depth_of(t): depth of the sample this lane gathers for in tile t.  col0 / col1 / sig: the per-tile outputs.
-template <int NT, int GPF, bool TRI, typename DepthFn>
+template <int NT, int GPF, bool TRI, int NB = 2, typename DepthFn>
 __device__ __forceinline__ void decode_pass(FeatLds& F, const DecoderLds& dec, const float4* __restrict__ P, int H, int W, int D, int lane,
                                             float ox, float oy, float oz, float dx, float dy, float dz, float scale, float xs3,
                                             DepthFn depth_of, f32x4 (&col0)[NT], f32x4 (&col1)[NT], float (&sig)[NT], f32x4* gp = nullptr)
@@ -848,7 +852,7 @@ __device__ __forceinline__ void decode_pass(FeatLds& F, const DecoderLds& dec, c
                                                    (unsigned)__builtin_amdgcn_readfirstlane((int)(pb & 0xffffffffu))));
     const PlaneRsrc pl = __builtin_amdgcn_make_buffer_rsrc(pu, 0, __builtin_amdgcn_readfirstlane(3 * (TRI ? D : 1) * H * W * 128), 0x00020000);
     const unsigned qoff = 32u * (unsigned)gq;
-    TileGather g;
+    TileGather<NB> g;
     auto gather_whole = [&](int t) {                                           // tri-grids / the first tile of a pass: not overlapped with a decode
         const float tg = depth_of(t);
         if constexpr (TRI) {
@@ -860,11 +864,19 @@ __device__ __forceinline__ void decode_pass(FeatLds& F, const DecoderLds& dec, c
             f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = z0;
             g.start(H, W, gq, ox + tg * dx, oy + tg * dy, oz + tg * dz, scale);
             g.template issue<0, 0>(pl, qoff);
-            g.template issue<1, 1>(pl, qoff);                                        // two planes in flight
-            g.template pin<0>(z0, z1); g.template consume<0, 0>();
-            g.template issue<2, 0>(pl, qoff);
-            g.template pin<1>(z0, z1); g.template consume<1, 1>();
-            g.template pin<0>(z0, z1); g.template consume<2, 0>();
+            if constexpr (NB == 2) {
+                g.template issue<1, 1>(pl, qoff);                                    // two planes in flight
+                g.template pin<0>(z0, z1); g.template consume<0, 0>();
+                g.template issue<2, 0>(pl, qoff);
+                g.template pin<1>(z0, z1); g.template consume<1, 1>();
+                g.template pin<0>(z0, z1); g.template consume<2, 0>();
+            } else {                                                                 // one buffer: plane by plane (per-plane sums in the same order: bit-identical)
+                g.template pin<0>(z0, z1); g.template consume<0, 0>();
+                g.template issue<1, 0>(pl, qoff);
+                g.template pin<0>(z0, z1); g.template consume<1, 0>();
+                g.template issue<2, 0>(pl, qoff);
+                g.template pin<0>(z0, z1); g.template consume<2, 0>();
+            }
             g.finish(F, t & 1, wi, xs3);
         }
     };
@@ -1006,11 +1018,11 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
     // The coarse pass's colours (8 registers per tile) wait in LDS while the fine pass runs: they are only needed again for the composite,
     // and the fine pass (its own colours + the gather pipeline's load buffers) is where the register file runs out (REF shape: 256 VGPRs and
     // spills to scratch, whose loads share vmcnt with the gather).  6 KB per wave; only for shapes whose block stays under 80 KB of LDS.
-    constexpr bool PARK = NTF > 0 && NTC <= 3;
+    constexpr bool PARK = NTF > 0 && NTC <= 3 && !R3D_RENDER_GPARK_ALL;
     // Round 5: the bigger shapes park ALL colours of a ray -- coarse and fine, tile by tile as the decode produces them -- in the workspace (2 (NTC +
     // NTF) KB per wave, each 16 B per lane written once and read once per ray, served by L2) instead of leaving 96 live registers to the allocator
     // (built without packed-f32 instructions <6,6> spilled 131 registers and BASELINE config 5's render took 15.0 instead of 12.5 ms).
-    constexpr bool GPARK = NTF > 0 && NTC > 3 && R3D_RENDER_GPARK;
+    constexpr bool GPARK = NTF > 0 && ((NTC > 3 && R3D_RENDER_GPARK) || R3D_RENDER_GPARK_ALL);
     __shared__ __attribute__((aligned(16))) f32x4 park[PARK ? kWavesPerBlock : 1][PARK ? 2 * NTC : 1][64];
 
     stage_decoder(dec, a.w1, a.b1, a.w2, a.b2, a.fold);
@@ -1096,7 +1108,7 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
             }
             wave_lds_sync();
             auto dof = [&](int t) { const int k = 16 * t + gs; return k < Nc ? L.t[k] : start; };
-            decode_pass<NTC, GPF, TRI>(F, dec, P, A.H, A.W, A.D, lane, ox, oy, oz, dx, dy, dz, A.scale, xs3, dof, colc[0], colc[1], sigc, gpark);
+            decode_pass<NTC, GPF, TRI, (OCC >= 3 ? 1 : 2)>(F, dec, P, A.H, A.W, A.D, lane, ox, oy, oz, dx, dy, dz, A.scale, xs3, dof, colc[0], colc[1], sigc, gpark);
         }
         constexpr bool parked = PARK;                  // (an instantiation with NTF > 0 is only launched with Nf > 0)
         if (parked) {
@@ -1168,7 +1180,7 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderArgs a, int R)
             float sigf[NTF > 0 ? NTF : 1];
             {
                 auto dof = [&](int t) { const int k = 16 * t + gs; return L.t[Nc + (k < Nf ? k : 0)]; };
-                decode_pass<(NTF > 0 ? NTF : 1), GPF, TRI>(F, dec, P, A.H, A.W, A.D, lane, ox, oy, oz, dx, dy, dz, A.scale, xs3, dof, colf[0], colf[1], sigf, GPARK ? gpark + 2 * NTC * 64 : nullptr);
+                decode_pass<(NTF > 0 ? NTF : 1), GPF, TRI, (OCC >= 3 ? 1 : 2)>(F, dec, P, A.H, A.W, A.D, lane, ox, oy, oz, dx, dy, dz, A.scale, xs3, dof, colf[0], colf[1], sigf, GPARK ? gpark + 2 * NTC * 64 : nullptr);
             }
             if (q == 0) {
 #pragma unroll
@@ -1454,7 +1466,10 @@ __global__ __launch_bounds__(256, 2) void run_model_kernel(const float4* __restr
 static inline size_t render_state_bytes(size_t nrays) { return ((kStateHeader + 3 * ((nrays + kLimitsBlock - 1) / kLimitsBlock)) * sizeof(int) + 63) & ~(size_t)63; }
 // decoder fold record (64 bytes) + room for the partials of plane_absmax_kernel (when the caller passes none)
 static constexpr size_t kFoldBytes = 64 + kAbsmaxBlocks * sizeof(float);
-static constexpr int kMaxGrid = 512;                     // blocks of a render launch (2 per CU)
+#ifndef R3D_RENDER_GRID
+#define R3D_RENDER_GRID 512         // blocks of a render launch: 2 per CU (experiment builds with 3 waves per SIMD: 768)
+#endif
+static constexpr int kMaxGrid = R3D_RENDER_GRID;
 
 // launches (plane_absmax_kernel if needed +) decoder_fold_kernel; returns the device address of the DecFold record
 static const DecFold* launch_decoder_fold(const float* planes_nhwc, size_t plane_floats, const float* plane_absmax, int n_plane_absmax,
@@ -1558,7 +1573,7 @@ extern "C" size_t r3d_render_workspace_bytes(int N, int M, int Nc, int Nf)
 {
     const size_t nrays = (size_t)N * M;
     // + the colour parking of the shapes with more than 3 tiles per pass (Nc or Nf above 48: <4,4>, <6,6> and their tri-grid twins): 512 blocks x 4 waves x 2 * (6 + 6) tiles x 1 KB = 50 MB
-    const size_t park = (Nc > 48 || Nf > 48) ? (size_t)kMaxGrid * kWavesPerBlock * 24 * 64 * sizeof(f32x4) : 0;
+    const size_t park = (Nc > 48 || Nf > 48 || R3D_RENDER_GPARK_ALL) ? (size_t)kMaxGrid * kWavesPerBlock * 24 * 64 * sizeof(f32x4) : 0;
     return render_state_bytes(nrays) + 2 * nrays * sizeof(float) + 64 + kFoldBytes + park;
 }
 
@@ -1625,7 +1640,7 @@ extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
     a.noise_c = noise_c; a.u_f = u_f; a.seed = seed;
     a.rgb = rgb; a.depth = depth; a.wsum = wsum; a.rgb_cm = rgb_channel_major ? 1 : 0;
     a.clk = prof_clock_slot(R3D_PROF_RENDER);
-    a.park_g = (Nc > 48 || Nf > 48) ? park_g : nullptr;      // (exactly the calls the dispatch below sends to a shape with more than 3 coarse tiles)
+    a.park_g = (Nc > 48 || Nf > 48 || R3D_RENDER_GPARK_ALL) ? park_g : nullptr;      // (exactly the calls the dispatch below sends to a shape with more than 3 coarse tiles)
 
     // (R computed above: square image -> XCD strip order; otherwise linear order)
     const int waves_needed = nrays;
