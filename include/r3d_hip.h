@@ -95,7 +95,9 @@ int r3d_raygen(const float* c2w, const float* intrinsics, int N, int R,
  *                The bound must be RIGOROUS (max of the array >= max |planes_nhwc| as the kernel will read them): the per-sample fp16
  *                split has no saturation guard, so a stale or too small bound yields inf / NaN, not a clamp.  Pass NULL whenever the
  *                planes were modified after the partials were written (the Python operator does: it ties them to the tensor version).
- *   workspace    r3d_render_workspace_bytes() bytes of device scratch, 64-byte aligned
+ *   workspace    r3d_render_workspace_bytes() bytes of device scratch, 64-byte aligned.  Per-ray limits and the decoder's fold record; when Nc or Nf
+ *                exceeds 48 (the kernel shapes with more than three 16-sample tiles per pass) also 48 MB in which every wave of the launch parks
+ *                the colours of the ray it is rendering between the decode and the composite (ABI 0.5.0: they do not fit the register file).
  */
 size_t r3d_render_workspace_bytes(int N, int M, int Nc, int Nf);
 int r3d_render_forward(const float* planes_nhwc, int N, int H, int W, int triplane_depth,
