@@ -107,6 +107,19 @@ def test_product_has_no_oracle_dependency():
                 assert "r3d_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
 
 
+def test_render_workspace_grows_for_the_shapes_that_park_colours():
+    """r3d_render_workspace_bytes: per-ray limits + the fold record, plus -- when Nc or Nf exceeds 48, i.e. the kernel shapes with more than three
+    16-sample tiles per pass -- 512 blocks x 4 waves x 2 (6 + 6) tiles x 1 KB in which a wave parks its ray's colours (round 5)."""
+    from real3dportrait_amd import _lib
+    lib = _lib.load()
+    base = lib.r3d_render_workspace_bytes(1, 128 * 128, 48, 48)
+    park = 512 * 4 * 24 * 64 * 16
+    assert lib.r3d_render_workspace_bytes(1, 128 * 128, 96, 96) == base + park
+    assert lib.r3d_render_workspace_bytes(1, 128 * 128, 40, 60) == base + park          # <4,4> is dispatched for Nf > 48 too
+    assert lib.r3d_render_workspace_bytes(1, 128 * 128, 96, 0) == base + park           # (a coarse-only 96-sample call does not use it; the size is a bound)
+    assert lib.r3d_render_workspace_bytes(1, 128 * 128, 16, 16) == base
+
+
 def test_no_hazardous_packed_f32_forms(tmp_path):
     """gfx950 erratum found in round 3: a packed-f32 instruction whose src1 / src2 op_sel bit is set returns a wrong low half
     in lanes 48-63 while another wave of the SIMD executes MFMAs.  Since round 5 the product is compiled WITHOUT packed-f32 instructions (they buy
