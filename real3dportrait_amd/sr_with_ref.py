@@ -21,6 +21,12 @@ from . import _lib
 from .superresolution import (_BoundMeter, _f32c, _keep_tags, _tag, blend_cat, bound_of, chain_fold, const_bound, resize_bilinear)
 
 
+import os
+
+# A/B switch: 1 = head_torso_block's conv1 operand is re-folded from the measured max of fuse_head_torso_convs' output (rounds 3-4)
+_HB_TAIL_FOLD = os.environ.get("R3D_HB_TAIL_FOLD", "0") == "1"
+
+
 def blend(a, b, mask):
     """a * mask + b * (1 - mask)   (sr_with_ref.py:103,113)."""
     lib = _lib.load()
@@ -219,10 +225,14 @@ def _forward_v2(self, S, rgb, x, ws, ref_torso_rgb, ref_bg_rgb, weights_img, seg
     rgb1 = blend(rgb0, rgb_torso, alpha)                                                                # :103
     preph = hb.prepare(ws3, dev, ws_key=ws)
     ops, head, last = fuse_ht.chain_ops(N, dev, -1, -2, base=0)
-    chain_fold(ops + [hb.chain_op(last)], N, [m_x0, bound_of(x_torso, S.meter_hid, 3)[0]], zero=[m_y])
+    if _HB_TAIL_FOLD:
+        chain_fold(ops + [hb.chain_op(last)], N, [m_x0, bound_of(x_torso, S.meter_hid, 3)[0]], zero=[m_y])
+    else:       # round 5: head_torso_block's conv1 operand is three layers from the measured max|x0| (= MAX_DEPTH): no tail fold, no max|y| measurement
+        chain_fold(ops + [hb.chain_op(last)], N, [m_x0, bound_of(x_torso, S.meter_hid, 3)[0]], zero=[m_x2])
     xs = blend_cat(x0, x_torso, alpha, fuse_ht, _folded_head=head)                                      # :104
-    y = fuse_ht(xs, out_format="split_mx" if hb.wants_mx() else "split", _next=hb, _y_absmax=m_y)       # :105
-    chain_fold([hb.chain_op(-1, tail=True)], N, [m_y], zero=[m_x2])
+    y = fuse_ht(xs, out_format="split_mx" if hb.wants_mx() else "split", _next=hb, _y_absmax=m_y if _HB_TAIL_FOLD else None)       # :105
+    if _HB_TAIL_FOLD:
+        chain_fold([hb.chain_op(-1, tail=True)], N, [m_y], zero=[m_x2])
     hb.out_format, hb.return_x = "cb8", True
     x2, rgb2 = hb(y, rgb1, ws3, _prepared=preph, _folded=True, _x_absmax=m_x2, **kw)                   # :106
 
