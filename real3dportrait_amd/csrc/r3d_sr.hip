@@ -539,7 +539,8 @@ extern "C" size_t r3d_sr_block_prepacked_bytes(int Cin, int Cout)
 {
     // conv0 (plain layout) + conv1 + conv0 again in the fused up-conv layout (f16x3) + the two per-cout weight-row tails + conv0 with fp8
     // records in the up-conv layout and in the plain layout (R3D_SR_F16MX: SynthesisBlock / SynthesisBlockNoUp on R3D_FMT_SPLIT_MX inputs)
-    return ((size_t)4 * 9 * Cin * Cout + (size_t)9 * Cout * Cout + 2 * conv_tail_layout(Cout).total) * sizeof(float);
+    // + conv1 again as the 12 transformed tap matrices of the Winograd F(2,3) kernel (r3d_sr_wino.h)
+    return ((size_t)4 * 9 * Cin * Cout + (size_t)9 * Cout * Cout + 2 * conv_tail_layout(Cout).total + (size_t)12 * Cout * Cout) * sizeof(float);
 }
 
 extern "C" size_t r3d_sr_block_styles_bytes(int N, int Cin, int Cout)

@@ -287,7 +287,9 @@ struct Conv2Args {
 // round 1 measured); from LDS the loop has no global loads, so its stores stream out back to back.
 // The caller has passed a __syncthreads() after its last LDS read; `ev` may alias the main loop's buffers.
 static constexpr int EV_STRIDE = BLOCK_M;              // floats per staged vector
-template <bool FULL_EPI, int WN, int NT>
+// PIXMAP = 1 (conv_wino_f16x3_kernel, NT = 2): acc[mt][nt] holds column parity nt of the column pairs -- lane li <-> (row 4 wn + li / 8,
+// columns 2 (li % 8) + nt) -- and the accumulators carry the transformed operands' factor 1/4 (r3d_sr_wino.h).
+template <bool FULL_EPI, int WN, int NT, int PIXMAP = 0>
 __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhase& ph, int n, f32x16 (&acc)[2][NT],
                                               int i0, int j0, int m0, float* ev)
 {
@@ -311,6 +313,7 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
                 else if (v == 2) { if (FULL_EPI && a.y_split && a.next_scale) val = a.next_scale[(size_t)n * a.next_scale_stride_n + co]; }
                 else if (do_rgb) val = a.wrgb[(size_t)n * a.wrgb_stride_n + (size_t)(v - 3) * a.CoutReal + co];
             }
+            if (PIXMAP && v == 0) val *= 4.0f;
             ev[e] = val;
         }
         __syncthreads();
@@ -332,7 +335,7 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
     bool inside_nt[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int i = i0 + row0 + nt * 2 + prow, j = j0 + pcol;
+        const int i = PIXMAP ? i0 + 4 * wn + (li >> 3) : i0 + row0 + nt * 2 + prow, j = PIXMAP ? j0 + 2 * (li & 7) + nt : j0 + pcol;
         inside_nt[nt] = i < ph.outH && j < ph.outW;
         p0[nt] = (unsigned)(i * ph.oy_mul + ph.oy_add) * (unsigned)a.OW + (unsigned)(j * ph.ox_mul + ph.ox_add);
     }
@@ -438,7 +441,7 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
             float* P = a.rgb_partial + (size_t)n * a.rgbp_stride_n + (size_t)(m0 / 64 + wm) * 3 * a.OH * a.OW;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const int i = i0 + row0 + nt * 2 + prow, j = j0 + pcol;
+                const int i = PIXMAP ? i0 + 4 * wn + (li >> 3) : i0 + row0 + nt * 2 + prow, j = PIXMAP ? j0 + 2 * (li & 7) + nt : j0 + pcol;
                 if (i < ph.outH && j < ph.outW) {
                     const int oy = i * ph.oy_mul + ph.oy_add, ox = j * ph.ox_mul + ph.ox_add;
 #pragma unroll
@@ -887,6 +890,8 @@ __device__ __forceinline__ void conv3x3_dma_block(const Conv2Args& a, const Conv
     R3D_STAMP_CLOCKS(26);
 #endif
 }
+
+#include "r3d_sr_wino.h"
 
 static constexpr int F_LDS_UINT4 = 2 * 2 * F_PATCH_PIX + 2 * 3 * 2 * 256;      // patch (20.7 KB) + 2 x 3-tap weight sub-stage (2 x 24.6 KB)
 
@@ -1672,8 +1677,15 @@ int upsample2x_bilinear_f16x3(const float* x_cb8, int N, int C, int H, int W, vo
 }
 
 // ---- host ------------------------------------------------------------------------------------------------------
+// A/B switch of the Winograd F(2,3) conv (r3d_sr_wino.h): R3D_CONV_WINO=0 keeps every plain 3x3 conv on the direct kernels
+static int wino_mode() { static const int v = getenv("R3D_CONV_WINO") ? atoi(getenv("R3D_CONV_WINO")) : 3; return v; }   // 0 off, 1 both precisions, 2 f16mx only, 3 f16x3 only
+// ... and the shapes it takes: whole 16 x 16-pixel tiles, 16-channel stages, 128-cout blocks
+static bool wino_shape_ok(int Cin, int Cout, int H, int W) { return wino_mode() && (H & 15) == 0 && (W & 15) == 0 && (Cin & 15) == 0 && (Cout % BLOCK_M) == 0; }
+// float offset of conv1's Winograd pack inside an SR block's prepacked buffer (after everything sr_prepack_f16x3 wrote before round 6)
+static size_t sr_wino_offset(int Cin, int Cout) { return (size_t)4 * 9 * Cin * Cout + (size_t)9 * Cout * Cout + 2 * conv_tail_layout(Cout).total; }
+
 // prepacked = conv0 (plain layout) ++ conv1 ++ conv0 (fused up-conv layout) ++ ConvTail(conv0) ++ ConvTail(conv1) ++ conv0 (up-conv layout
-// with fp8 records, for R3D_FMT_SPLIT_MX inputs; written for R3D_SR_F16MX only)
+// with fp8 records, for R3D_FMT_SPLIT_MX inputs; written for R3D_SR_F16MX only) ++ conv0 (plain layout with fp8 records) ++ conv1 (Winograd pack)
 int sr_prepack_f16x3(int Cin, int Cout, const float* c0_w, const float* c1_w, void* prepacked, hipStream_t st, bool mx)
 {
     float* out = reinterpret_cast<float*>(prepacked);
@@ -1702,6 +1714,11 @@ int sr_prepack_f16x3(int Cin, int Cout, const float* c0_w, const float* c1_w, vo
             hipLaunchKernelGGL(sr_prepack_mx_kernel, dim3((unsigned)((m0 / 2 + 255) / 256)), dim3(256), 0, st, c0_w, Cin, Cout, 9, Cin, Cout,
                                tail0 + T.winv, reinterpret_cast<uint4*>(tail1 + T.total + (size_t)9 * Cin * Cout));
     }
+    {   // conv1 for conv_wino_f16x3_kernel: 12 transformed tap matrices [Cout / 128][Cout / 16][wave 8][WG_WBLK]
+        const size_t mw = (size_t)(Cout >> 7) * (Cout >> 4) * 8 * 3 * 2 * 32;
+        hipLaunchKernelGGL(sr_prepack_wino_kernel, dim3((unsigned)((mw + 255) / 256)), dim3(256), 0, st, c1_w, Cout, Cout, tail1 + T.winv,
+                           reinterpret_cast<uint4*>(out + sr_wino_offset(Cin, Cout)), mx ? 1 : 0);
+    }
     return check_launch("sr_block_prepack");
 }
 
@@ -1709,10 +1726,18 @@ int sr_prepack_f16x3(int Cin, int Cout, const float* c0_w, const float* c1_w, vo
 // ray-kernel block of another stream on the same CU
 static unsigned lds_pad() { static const unsigned v = getenv("R3D_SR_LDS_PAD") ? (unsigned)atoi(getenv("R3D_SR_LDS_PAD")) : 0u; return v; }
 
-static void launch_conv2(Conv2Args& a, int tiles, int N, hipStream_t st, bool mx = false)
+// wino: a.wp is a Winograd pack (sr_prepack_wino_kernel), a.x plain SPLIT; mx selects the f16mx main loop
+static void launch_conv2(Conv2Args& a, int tiles, int N, hipStream_t st, bool mx = false, bool wino = false)
 {
     a.clk = prof_clock_slot(R3D_PROF_CONV);
     dim3 grid(tiles, a.Cout / BLOCK_M, N * a.nphase);
+    if (wino) {
+        static const int order = getenv("R3D_CONV_ORDER") ? atoi(getenv("R3D_CONV_ORDER")) : 2;
+        a.order = (tiles & 7) == 0 ? order : 0;
+        if (mx) hipLaunchKernelGGL(conv_wino_f16x3_kernel<true>, grid, dim3(512), 0, st, a);
+        else hipLaunchKernelGGL(conv_wino_f16x3_kernel<false>, grid, dim3(512), 0, st, a);
+        return;
+    }
     static const int rows8 = getenv("R3D_CONV_ROWS8") ? atoi(getenv("R3D_CONV_ROWS8")) : 1;   // A/B switch: 0 = always 16x16 tiles
     if (rows8 && (rows8 == 1 || (rows8 == 2 && !a.rgb_partial) || (rows8 == 3 && a.rgb_partial)) && a.nphase == 1 && a.ph[0].ntaps == 9 && (size_t)tiles * grid.y * grid.z <= 256) {
         // under-filled launch (<= half of the 512 block slots): 8x16-pixel tiles, twice the blocks (bit-identical results)
@@ -1767,6 +1792,9 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
                            reinterpret_cast<const float*>(x), x_format == R3D_FMT_CB8 ? 1 : 0, pk + L.s0f, L.total, xin, Cin, Cin, Hin * Win);
         xs = xin;
     }
+    // conv1 on the Winograd F(2,3) kernel: its operand is transformed in fp32 inside the kernel, so conv0 hands over plain SPLIT (no fp8 records)
+    const bool wino1 = wino_shape_ok(Cout, Cout, OH, OW) && (wino_mode() == 1 || (wino_mode() == 2 && mx) || (wino_mode() == 3 && !mx));
+    const bool mx0 = mx && !wino1;                            // does conv0's epilogue write the fp8 records of conv1's operand?
     static const int fused_up = getenv("R3D_UPCONV") ? atoi(getenv("R3D_UPCONV")) : 1;   // A/B switch: 0 = per-phase T-conv + FIR kernel
     if (up && fused_up) {
         // ---- conv0: fused transposed conv + FIR + bias + lrelu -> SPLIT (one kernel, T stays on chip) ----------------
@@ -1789,12 +1817,14 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
         // block: that launch is bound by the LDS-DMA fill rate of its two K stages and by the VALU work of its epilogue one after the other,
         // not by latency.  The instantiation stays available behind R3D_UPCONV_NW8=1 for experiments.)
         static const int up8 = getenv("R3D_UPCONV_NW8") ? atoi(getenv("R3D_UPCONV_NW8")) : 0;
-        const bool nw8 = up8 && Cin <= 64 && !mx_in && !mx && clamp < 0.f;
-        if (mx_in && clamp >= 0.f) hipLaunchKernelGGL((upconv_fir_f16x3_kernel<true, true, true>), ugrid, dim3(256), 0, st, u);
-        else if (mx_in) hipLaunchKernelGGL((upconv_fir_f16x3_kernel<false, true, true>), ugrid, dim3(256), 0, st, u);
+        const bool nw8 = up8 && Cin <= 64 && !mx_in && !mx0 && clamp < 0.f;
+        if (mx_in && clamp >= 0.f && mx0) hipLaunchKernelGGL((upconv_fir_f16x3_kernel<true, true, true>), ugrid, dim3(256), 0, st, u);
+        else if (mx_in && mx0) hipLaunchKernelGGL((upconv_fir_f16x3_kernel<false, true, true>), ugrid, dim3(256), 0, st, u);
+        else if (mx_in && clamp >= 0.f) hipLaunchKernelGGL((upconv_fir_f16x3_kernel<true, false, true>), ugrid, dim3(256), 0, st, u);
+        else if (mx_in) hipLaunchKernelGGL((upconv_fir_f16x3_kernel<false, false, true>), ugrid, dim3(256), 0, st, u);
         else if (nw8) hipLaunchKernelGGL((upconv_fir_f16x3_kernel<false, false, false, 8>), ugrid, dim3(512), 0, st, u);
-        else if (mx && clamp >= 0.f) hipLaunchKernelGGL((upconv_fir_f16x3_kernel<true, true>), ugrid, dim3(256), 0, st, u);
-        else if (mx) hipLaunchKernelGGL((upconv_fir_f16x3_kernel<false, true>), ugrid, dim3(256), 0, st, u);
+        else if (mx0 && clamp >= 0.f) hipLaunchKernelGGL((upconv_fir_f16x3_kernel<true, true>), ugrid, dim3(256), 0, st, u);
+        else if (mx0) hipLaunchKernelGGL((upconv_fir_f16x3_kernel<false, true>), ugrid, dim3(256), 0, st, u);
         else if (clamp >= 0.f) hipLaunchKernelGGL(upconv_fir_f16x3_kernel<true>, ugrid, dim3(256), 0, st, u);
         else hipLaunchKernelGGL(upconv_fir_f16x3_kernel<false>, ugrid, dim3(256), lds_pad(), st, u);
     } else if (up) {
@@ -1827,7 +1857,7 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
         a.out_scale = pk + L.d0f; a.out_scale_stride_n = L.total; a.bias = pk + L.b0; a.bias_stride_n = L.total;
         a.OH = OH; a.OW = OW;
         a.y_split = y0; a.y_split_stride_n = (size_t)Cout / 8 * OH * OW * 2; a.next_scale = pk + L.s1f; a.next_scale_stride_n = L.total;
-        a.y_split_mx = mx ? 1 : 0;                                   // f16mx: conv1 reads fp8 records
+        a.y_split_mx = mx0 ? 1 : 0;                                  // f16mx: conv1 reads fp8 records (the Winograd kernel: plain SPLIT)
         if (mx_in) a.wp = reinterpret_cast<const uint4*>(wpk + (size_t)3 * 9 * Cin * Cout + (size_t)9 * Cout * Cout + 2 * conv_tail_layout(Cout).total);
         a.Cin = Cin; a.Cout = Cout; a.CoutReal = Cout; a.H = Hin; a.W = Win; a.nphase = 1;
         a.act = 1; a.act_slope = 0.2f; a.act_gain = 1.4142135623730951f; a.clamp = clamp;
@@ -1854,8 +1884,9 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
         a.Cin = Cout; a.Cout = Cout; a.CoutReal = Cout; a.H = OH; a.W = OW; a.nphase = 1;
         a.act = 1; a.act_slope = 0.2f; a.act_gain = 1.4142135623730951f; a.clamp = clamp;
         sr_fill_conv3x3_phase(a.ph, OH, OW);
+        if (wino1) a.wp = reinterpret_cast<const uint4*>(wpk + sr_wino_offset(Cin, Cout));
         ProfScope ps(R3D_PROF_CONV, st);
-        launch_conv2(a, tiles_of(OH, OW), N, st, mx);
+        launch_conv2(a, tiles_of(OH, OW), N, st, mx, wino1);
     }
     (void)xo;
     {

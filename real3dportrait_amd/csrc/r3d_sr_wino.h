@@ -1,0 +1,460 @@
+// Winograd F(2,3) along x for the plain 3x3 convolutions of the SR blocks (block0.conv1, block1.conv1: modulated_conv2d of
+// modules/eg3ds/models/networks_stylegan2.py:37-94 with up = down = 1, padding 1) -- included by r3d_sr_f16x3.hip.
+//
+// Per pair of output columns (x, x+1) and kernel row ky the direct form spends 6 tap-products, F(2,3) spends 4:
+//     d0..d3 = in(x-1 .. x+2)          V0 = d0 - d2   V1 = d1 + d2   V2 = d2 - d1   V3 = d1 - d3          (input transform, fp32)
+//     g0..g2 = w[ky][0..2]             U0 = g0        U1 = (g0+g1+g2)/2   U2 = (g0-g1+g2)/2   U3 = g2     (weight transform, at prepack)
+//     M_p = sum_{ci, ky} U_p[ky] V_p(row + ky)          y(x) = M0 + M1 + M2      y(x+1) = M1 - M2 - M3   (output transform, epilogue)
+// i.e. four independent "3x1 convolutions" over half-width images V_p: 12 instead of 18 matrix products per column pair.
+//
+// Why the shape below.  A wave that held all four positions of its pixels would use every A (weight) and B (V) operand
+// for ONE 32x32 tile: 6 ds_read_b128 per (f16 + f16 + fp8) tile unit, 75 % of the CU's LDS bandwidth before any transform traffic.
+// So a wave owns ONE position: wave w = 4 wm + pos computes M_pos for 64 couts (wm) x all 128 column pairs of the 16 x 16-pixel tile
+// = 2 x 4 tiles of 32 x 32 = 128 accumulator registers, two waves per SIMD, one block per CU.  Then
+//   * B (V_pos) is shared by two waves, A (U_pos of the wave's 64 couts) by NOBODY: the weights go global -> VGPR directly (coalesced
+//     16-byte loads of a prepacked per-wave stream, L2-resident), never through LDS;
+//   * the input transform is done once per block: the raw SPLIT patch (fp16 hi + lo) is staged in LDS by LDS-DMA, each wave transforms
+//     the V rows of ITS position (its 8-channel chunk wm of the 16-channel stage) and writes V as fp16 hi + {fp16 lo | e5m2 records};
+//   * the four positions of a pixel meet in the epilogue through LDS (two rounds of 128 KB), after which the wave holds the ordinary
+//     64 couts x 64 pixels of conv_epilogue<.., PIXMAP = 1>.
+// K stage = 16 input channels.  f16mx: per (ky, tile) one f16 MFMA (hi * hi) and the cross products of (ky0 | ky1) and (ky2 | zero) on
+// the K = 64 fp8 MFMA (lane half h <-> kernel row h): 3 x 32 + 2 x 64 = 224 matrix cycles per (stage, tile) against 2 x 9 x 64 / 4 = 288
+// for the same outputs in the direct kernel (1.29 x; pairing ky2 with the next stage's ky0 would make it 192).  f16x3: 9 f16 MFMAs = 288
+// against 432 (1.5 x).
+// Range: the fold guarantees |x| < 2^15; V' = (a +- b) / 2 keeps |V'| < 2^15 and U' = U 2^(kw-1) keeps |U'| < 2^11 (|U| <= 1.5 max|g|);
+// the factor 4 is taken out with the per-cout epilogue multiplier (exact).
+// The two waves of a SIMD (w, w + 4: same position) run a stage in opposite orders -- wm = 0: MFMAs then transform of the next stage,
+// wm = 1: transform then MFMAs -- so that one wave's VALU / LDS phase sits under the other's matrix phase.
+
+static constexpr int WG_VPLANE = 18 * 8;                            // uint4 slots of one V plane: [V row 18][column pair 8]
+static constexpr int WG_VPOS = 4 * WG_VPLANE;                       // per position: hi chunk 0 | hi chunk 1 | (lo chunk 0 | lo chunk 1) or (rec_h | rec_l)
+static constexpr int WG_VBUF = 4 * WG_VPOS;                         // 2304 uint4 = 36 KB per stage
+static constexpr int WG_RPLANE = 18 * 8;                            // raw patch plane k = (hi|lo, chunk, column parity): [row 18][8], column index rotated by k
+static constexpr int WG_REXTRA = 8 * WG_RPLANE;                     // the ninth column index of every plane: [row 18][plane 8]
+static constexpr int WG_RBUF = 9 * WG_RPLANE;                       // 1296 uint4 = 20.25 KB per stage
+static constexpr int WG_RSEGS = (WG_RBUF + 63) / 64;                // 21 DMA segments of 64 slots
+static constexpr int WG_RSTRIDE = WG_RSEGS * 64;                    // 1344: the last segment's tail lanes land in padding
+static constexpr int WG_LDS_UINT4 = 8192;                           // main loop: 2 x 2304 + 2 x 1344 = 7296; epilogue exchange: 8192 (128 KB)
+static constexpr int WG_WBLK = 768;                                 // uint4 of weights per (cout tile, stage, wave)
+
+// d = (float)half(x, HI) * m + c   (v_fma_mix_f32: one instruction instead of v_cvt_f32_f16 + v_fma_f32)
+template <int HI>
+__device__ __forceinline__ float mix_hf(unsigned x, float m, float c)
+{
+    float d;
+    if (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(x), "s"(m), "v"(c));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(x), "s"(m), "v"(c));
+    return d;
+}
+// d = (float)half(x, HI) * m + (float)half(c, HI)
+template <int HI>
+__device__ __forceinline__ float mix_hh(unsigned x, float m, unsigned c)
+{
+    float d;
+    if (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(x), "s"(m), "v"(c));
+    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(x), "s"(m), "v"(c));
+    return d;
+}
+
+// ---- weights: U = G g per kernel row, times 2^(kw[co] - 1), split and laid out as the per-wave streams the kernel loads ----------------
+// block (ct, st, w = 4 wm + pos) of WG_WBLK uint4, cout = 128 ct + 64 wm + 32 mt + li, channels 16 st ..:
+//   f16x3:  [(ky 3, mt 2, hi|lo 2)][lane 64]                          lane = 32 chunk + li
+//   f16mx:  [(ky 3, mt 2)][lane 64] hi   ++   [(mt 2, wl8|wh8 2)][lane 64] records of kernel row h = lane / 32 (ky 0 | ky 1)
+//                                        ++   [(mt 2, wl8|wh8 2)][li 32]   records of ky 2 (lanes h = 1 of that MFMA read a zero block)
+// Record bytes: channel j of the stage at byte j (the V records of the kernel use the same order).
+__global__ void sr_prepack_wino_kernel(const float* __restrict__ w, int Cin, int Cout, const float* __restrict__ winv, uint4* __restrict__ out, int mx)
+{
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int nst = Cin >> 4;
+    const size_t total = (size_t)(Cout >> 7) * nst * 8 * 3 * 2 * 32;
+    if (e >= total) return;
+    const int li = e & 31, mt = (e >> 5) & 1;
+    const int ky = (int)((e >> 6) % 3);
+    size_t r = (e >> 6) / 3;
+    const int w8 = (int)(r & 7); r >>= 3;
+    const int st = (int)(r % nst), ct = (int)(r / nst);
+    const int pos = w8 & 3, wm = w8 >> 2;
+    const int co = ct * 128 + wm * 64 + mt * 32 + li;
+    const double ws = 0.5 / (double)winv[co];                       // 2^(kw - 1)
+    float u[16], hif[16], lof[16];
+    h8 hi[2], lo[2];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float* g = w + (((size_t)co * Cin + st * 16 + j) * 3 + ky) * 3;
+        const double g0 = g[0], g1 = g[1], g2 = g[2];
+        const double uu = pos == 0 ? g0 : (pos == 1 ? 0.5 * (g0 + g1 + g2) : (pos == 2 ? 0.5 * (g0 - g1 + g2) : g2));
+        u[j] = (float)(uu * ws);
+        _Float16 a, b; split1(u[j], a, b);
+        hi[j >> 3][j & 7] = a; lo[j >> 3][j & 7] = b;
+        hif[j] = (float)a; lof[j] = u[j] - (float)a;
+    }
+    uint4* blk = out + ((size_t)(ct * nst + st) * 8 + w8) * WG_WBLK;
+    if (!mx) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            blk[((ky * 2 + mt) * 2 + 0) * 64 + c * 32 + li] = *reinterpret_cast<uint4*>(&hi[c]);
+            blk[((ky * 2 + mt) * 2 + 1) * 64 + c * 32 + li] = *reinterpret_cast<uint4*>(&lo[c]);
+        }
+        return;
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) blk[(ky * 2 + mt) * 64 + c * 32 + li] = *reinterpret_cast<uint4*>(&hi[c]);
+    uint4 wl8, wh8;
+    unsigned* pl = reinterpret_cast<unsigned*>(&wl8); unsigned* phh = reinterpret_cast<unsigned*>(&wh8);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        pl[q] = pack4_fp8(lof[4 * q] * kMxWl, lof[4 * q + 1] * kMxWl, lof[4 * q + 2] * kMxWl, lof[4 * q + 3] * kMxWl);
+        phh[q] = pack4_fp8(hif[4 * q] * kMxWh, hif[4 * q + 1] * kMxWh, hif[4 * q + 2] * kMxWh, hif[4 * q + 3] * kMxWh);
+    }
+    if (ky < 2) {
+        blk[384 + (mt * 2 + 0) * 64 + ky * 32 + li] = wl8;
+        blk[384 + (mt * 2 + 1) * 64 + ky * 32 + li] = wh8;
+    } else {
+        blk[640 + (mt * 2 + 0) * 32 + li] = wl8;
+        blk[640 + (mt * 2 + 1) * 32 + li] = wh8;
+    }
+}
+
+template <bool MX>
+__global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(Conv2Args a)
+{
+    __shared__ uint4 lds[WG_LDS_UINT4];
+    const ConvPhase& ph = a.ph[0];
+    const int n = blockIdx.z;
+    const int tiles_x = (ph.outW + F_TILE_W - 1) / F_TILE_W;
+    int tile = blockIdx.x, cgi = blockIdx.y;
+    if (a.order) {                                                   // XCD-aware block order of conv3x3_dma_block
+        const int G = gridDim.y, b = blockIdx.x + gridDim.x * blockIdx.y;
+        const int xcd = b & 7, slot = b >> 3;
+        cgi = slot % G;
+        const int t = slot / G;
+        tile = a.order == 1 ? t * 8 + xcd : xcd * (gridDim.x >> 3) + t;
+    }
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int i0 = ty * F_TILE_H, j0 = tx * F_TILE_W;
+    const int m0 = cgi * BLOCK_M;
+    const int lane = threadIdx.x & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pos = wave_u & 3, wm = wave_u >> 2;
+    const int li = lane & 31, h = lane >> 5;
+    const int nst = a.Cin >> 4, nchunks = a.Cin >> 3;
+    const int chunk_stride = a.H * a.W;
+    const size_t plane = (size_t)nchunks * chunk_stride;
+    const uint4* X = a.x + (size_t)n * a.x_stride_n;
+    if (blockIdx.x == (gridDim.x >> 1) && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) clk_begin(kernarg_clk<Conv2Args>());
+
+    // ---- raw patch DMA: slot e of a raw buffer <-> (plane k = 4 hl + 2 chunk + parity, row, column index idx), patch column 2 idx + parity
+    unsigned pf_off[3];
+    unsigned pf_valid = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int e = (8 * k + wave_u) * 64 + lane;
+        unsigned off = 0;
+        if (e < WG_RBUF) {
+            int kp, row, idx;
+            if (e < WG_REXTRA) { kp = e / WG_RPLANE; const int rem = e - kp * WG_RPLANE; row = rem >> 3; idx = ((rem & 7) - kp) & 7; }
+            else { const int rem = e - WG_REXTRA; row = rem >> 3; kp = rem & 7; idx = 8; }
+            const int hl = kp >> 2, c = (kp >> 1) & 1, par = kp & 1;
+            const int iy = i0 - 1 + row, ix = j0 - 1 + 2 * idx + par;
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+                off = (unsigned)(hl * plane) + (unsigned)(c * chunk_stride + iy * a.W + ix);
+                pf_valid |= 1u << k;
+            }
+        }
+        pf_off[k] = off;
+    }
+    const bool three = wave_u < WG_RSEGS - 16;                        // waves 0..4 issue three patch DMAs per stage, the others two
+    auto dma_raw = [&](int st, uint4* dst) {
+        const uint4* Xs = X + (size_t)(2 * st) * chunk_stride;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (k < 2 || three) dma64((pf_valid & (1u << k)) ? Xs + pf_off[k] : g_zero16, dst + 64 * (8 * k + wave_u));
+    };
+    uint4* const vbuf = lds;                                          // [2][WG_VBUF]
+    uint4* const rbuf = lds + 2 * WG_VBUF;                            // [2][WG_RSTRIDE]
+
+    // ---- input transform of this wave: position pos, chunk wm; item = (V row, column pair), 3 passes of 8 rows (the last: rows 16, 17)
+    // V = A + sgn B with (parity, column index offset) of A and B:  pos 0: (0,0) - (0,1)   1: (1,0) + (0,1)   2: (0,1) - (1,0)   3: (1,0) - (1,1)
+    const int parA = (pos == 1 || pos == 3) ? 1 : 0, offA = pos == 2 ? 1 : 0;
+    const int parB = (pos >= 2) ? 1 : 0, offB = (pos == 2) ? 0 : 1;
+    const float sgnh = pos == 1 ? 0.5f : -0.5f;
+    float halfv = 0.5f, neg1 = -1.0f, sgnv = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(pos == 1 ? 0x3f000000 : (int)0xbf000000));
+    asm volatile("" : "+s"(halfv), "+s"(neg1), "+s"(sgnv));           // multipliers of the mix ops: one SGPR operand each (constant-bus limit 1)
+    typedef _Float16 hh2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const hh2 half2 = {(_Float16)0.5f, (_Float16)0.5f};
+    const hh2 sgn2 = {(_Float16)sgnh, (_Float16)sgnh};
+    const int r8 = lane >> 3, p8 = lane & 7;
+    auto raw_slot = [&](int kp, int off) {                            // slot of (plane kp, row r8, column index p8 + off) for pass 0
+        const int idx = p8 + off;
+        return idx < 8 ? kp * WG_RPLANE + r8 * 8 + ((idx + kp) & 7) : WG_REXTRA + r8 * 8 + kp;
+    };
+    const int kA = 2 * wm + parA, kB = 2 * wm + parB;                 // hi planes; + 4 for the lo planes
+    const int sAh = raw_slot(kA, offA), sAl = raw_slot(kA + 4, offA), sBh = raw_slot(kB, offB), sBl = raw_slot(kB + 4, offB);
+    const int vw_slot = pos * WG_VPOS + r8 * 8 + p8;                  // + plane * WG_VPLANE + pass * 64
+
+    auto transform = [&](int bufi) {                                  // raw[bufi] -> V[bufi]
+#ifdef WG_NO_TRANSFORM
+        return;
+#endif
+        const uint4* R = rbuf + bufi * WG_RSTRIDE;
+        uint4* V = vbuf + bufi * WG_VBUF + vw_slot;
+#pragma unroll
+        for (int pass = 0; pass < 3; ++pass) {
+            if (pass == 2 && lane >= 16) break;
+            const uint4 ah = R[sAh + pass * 64], al = R[sAl + pass * 64], bh = R[sBh + pass * 64], bl = R[sBl + pass * 64];
+            const unsigned* pah = reinterpret_cast<const unsigned*>(&ah); const unsigned* pal = reinterpret_cast<const unsigned*>(&al);
+            const unsigned* pbh = reinterpret_cast<const unsigned*>(&bh); const unsigned* pbl = reinterpret_cast<const unsigned*>(&bl);
+            float v[8];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const hh2 la = __builtin_bit_cast(hh2, pal[d]) * half2;
+                const hh2 ls = __builtin_elementwise_fma(__builtin_bit_cast(hh2, pbl[d]), sgn2, la);       // (lo_a + sgn lo_b) / 2, fp16 (2^-22 of x)
+                const unsigned lsu = __builtin_bit_cast(unsigned, ls);
+                const float t0 = mix_hh<0>(pbh[d], sgnv, lsu), t1 = mix_hh<1>(pbh[d], sgnv, lsu);
+                v[2 * d] = mix_hf<0>(pah[d], halfv, t0);
+                v[2 * d + 1] = mix_hf<1>(pah[d], halfv, t1);
+            }
+            uint4 vh;
+            unsigned* pvh = reinterpret_cast<unsigned*>(&vh);
+            float lo[8];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const hh2 hi2 = __builtin_convertvector((f2){v[2 * d], v[2 * d + 1]}, hh2);
+                pvh[d] = __builtin_bit_cast(unsigned, hi2);
+                lo[2 * d] = mix_hf<0>(pvh[d], neg1, v[2 * d]);
+                lo[2 * d + 1] = mix_hf<1>(pvh[d], neg1, v[2 * d + 1]);
+            }
+            V[wm * WG_VPLANE + pass * 64] = vh;
+            if constexpr (MX) {
+                // e5m2 records of V (hi part straight from the fp32 value) and of lo * 2^11; chunk wm = bytes [8 wm, +8) of both 16-byte records
+                const uint2 rh = make_uint2(pack4_x8(v[0] * kMxXh, v[1] * kMxXh, v[2] * kMxXh, v[3] * kMxXh), pack4_x8(v[4] * kMxXh, v[5] * kMxXh, v[6] * kMxXh, v[7] * kMxXh));
+                const uint2 rl = make_uint2(pack4_x8(lo[0] * kMxXl, lo[1] * kMxXl, lo[2] * kMxXl, lo[3] * kMxXl), pack4_x8(lo[4] * kMxXl, lo[5] * kMxXl, lo[6] * kMxXl, lo[7] * kMxXl));
+                reinterpret_cast<uint2*>(V + 2 * WG_VPLANE + pass * 64)[wm] = rh;
+                reinterpret_cast<uint2*>(V + 3 * WG_VPLANE + pass * 64)[wm] = rl;
+            } else {
+                uint4 vl;
+                unsigned* pvl = reinterpret_cast<unsigned*>(&vl);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) pvl[d] = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){lo[2 * d], lo[2 * d + 1]}, hh2));
+                V[(2 + wm) * WG_VPLANE + pass * 64] = vl;
+            }
+        }
+    };
+
+    // ---- accumulators: M_pos of couts [64 wm, +64) x (16 rows x 8 column pairs) = acc[mt][nt], N tile nt = rows 4 nt .. 4 nt + 3
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    // A operands: this wave's stream [ct][st][w] (WG_WBLK uint4 per stage), per-lane pointer
+    // (buffer loads: one VGPR of lane offset for every load of the kernel, the rest of the address on the scalar unit; lanes that must read
+    // zeros -- the second K half of the unpaired ky 2 records -- point past num_records)
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.wp), 0, 0x7ffffff0, 0x00020000);
+    const unsigned wa_blk = (unsigned)((cgi * nst * 8 + wave_u) * WG_WBLK) * 16u;      // byte offset of this wave's block of stage 0 (host: the pack is < 2 GB)
+    const unsigned wa_stage = 8u * WG_WBLK * 16u;
+    const int lane16 = lane * 16, z16 = h ? 0x7ffffff0 : li * 16;
+    auto ldw = [&](int voff, unsigned soff) { return __builtin_amdgcn_raw_buffer_load_b128(wrs, voff, (int)soff, 0); };
+    auto ldw_h8 = [&](int voff, unsigned soff) { return __builtin_bit_cast(h8, ldw(voff, soff)); };
+    auto ldw_i8 = [&](int voff, unsigned s0, unsigned s1) {
+        const auto q0 = ldw(voff, s0), q1 = ldw(voff, s1);
+        return (i8v){(int)q0[0], (int)q0[1], (int)q0[2], (int)q0[3], (int)q1[0], (int)q1[1], (int)q1[2], (int)q1[3]};
+    };
+    auto ld_h8 = [](const uint4* p) { const uint4 q = *p; return *reinterpret_cast<const h8*>(&q); };
+    auto ld_i8 = [](const uint4* p0, const uint4* p1) {
+        const uint4 q0 = *p0, q1 = *p1;
+        return (i8v){(int)q0.x, (int)q0.y, (int)q0.z, (int)q0.w, (int)q1.x, (int)q1.y, (int)q1.z, (int)q1.w};
+    };
+    // carried across stages (16 registers): MX: the f16 rows ky 0, ky 1;  f16x3: hi and lo of ky 0
+    h8 ca[2], cb[2];
+    auto load_a_carried = [&](int st) {
+        const unsigned W = wa_blk + (unsigned)st * wa_stage;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            if constexpr (MX) { ca[mt] = ldw_h8(lane16, W + ((0 * 2 + mt) * 64) * 16); cb[mt] = ldw_h8(lane16, W + ((1 * 2 + mt) * 64) * 16); }
+            else { ca[mt] = ldw_h8(lane16, W + (((0 * 2 + mt) * 2 + 0) * 64) * 16); cb[mt] = ldw_h8(lane16, W + (((0 * 2 + mt) * 2 + 1) * 64) * 16); }
+        }
+    };
+    const int boff = pos * WG_VPOS + li;                              // B slot: + plane * WG_VPLANE + (4 nt + ky) * 8
+
+    // One stage of matrix work as a pipeline of HALF groups (4 MFMAs on two N tiles each): the B operands of half group i + 1 are read, and the
+    // A operands of a later group loaded, right before the MFMAs of half group i are issued; the fences keep hipcc from hoisting every read
+    // and load of the stage to its top (485 spilled registers in the first version).  Live operands: <= 40 (A) + 32 (B) registers.
+    auto mfma_phase = [&](int st, int bufi) {
+        const uint4* V = vbuf + bufi * WG_VBUF + boff;
+        const unsigned W = wa_blk + (unsigned)st * wa_stage;
+        const bool more = st + 1 < nst;
+#define WG_SB __builtin_amdgcn_sched_barrier(0)
+        if constexpr (MX) {
+            // groups: G0 f16 ky 0 (ca) | G1 f16 ky 1 (cb) | G2 fp8 (ky0 | ky1) (a8p0) | G3 f16 ky 2 (ak2) | G4 fp8 (ky2 | zero) (a8p1)
+            h8 bf[2][2], ak2[2];
+            i8v b8[2][2], a8p0[2], a8p1[2];
+            auto rd_f = [&](int s, int ky, int np) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) bf[s][j] = ld_h8(V + h * WG_VPLANE + (4 * (2 * np + j) + ky) * 8);
+            };
+            auto rd_8 = [&](int s, int kyh, int np) {              // kyh: kernel row of this lane half
+#pragma unroll
+                for (int j = 0; j < 2; ++j) b8[s][j] = ld_i8(V + 2 * WG_VPLANE + (4 * (2 * np + j) + kyh) * 8, V + 3 * WG_VPLANE + (4 * (2 * np + j) + kyh) * 8);
+            };
+            auto mm_f = [&](const h8 (&A)[2], int s, int np) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) acc[mt][2 * np + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[mt], bf[s][j], acc[mt][2 * np + j], 0, 0, 0);
+            };
+            auto mm_8 = [&](const i8v (&A)[2], int s, int np) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        acc[mt][2 * np + j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[mt], b8[s][j], acc[mt][2 * np + j], 0, kMxFmtB, 0, kMxScaleA, 0, kMxScaleB);
+            };
+            rd_f(0, 0, 0);
+            WG_SB;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) a8p0[mt] = ldw_i8(lane16, W + (384 + (mt * 2 + 0) * 64) * 16, W + (384 + (mt * 2 + 1) * 64) * 16);
+            rd_f(1, 0, 1);
+            mm_f(ca, 0, 0);                                           // G0
+            WG_SB;
+            rd_f(0, 1, 0);
+            mm_f(ca, 1, 1);
+            WG_SB;
+            rd_f(1, 1, 1);
+            mm_f(cb, 0, 0);                                           // G1
+            WG_SB;
+            rd_8(0, h, 0);
+            mm_f(cb, 1, 1);
+            WG_SB;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) ak2[mt] = ldw_h8(lane16, W + ((2 * 2 + mt) * 64) * 16);
+            rd_8(1, h, 1);
+            mm_8(a8p0, 0, 0);                                         // G2
+            WG_SB;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)                            // ky 2 alone in its pair: lanes h = 1 (the second K half) read zeros (out of range)
+                a8p1[mt] = ldw_i8(z16, W + (640 + (mt * 2 + 0) * 32) * 16, W + (640 + (mt * 2 + 1) * 32) * 16);
+            rd_f(0, 2, 0);
+            mm_8(a8p0, 1, 1);
+            WG_SB;
+            rd_f(1, 2, 1);
+            mm_f(ak2, 0, 0);                                          // G3
+            WG_SB;
+            if (more) load_a_carried(st + 1);
+            rd_8(0, 2, 0);
+            mm_f(ak2, 1, 1);
+            WG_SB;
+            rd_8(1, 2, 1);
+            mm_8(a8p1, 0, 0);                                         // G4
+            WG_SB;
+            mm_8(a8p1, 1, 1);
+            WG_SB;
+        } else {
+            // f16x3: per kernel row  lo(U) hi(V) + hi(U) lo(V) + hi(U) hi(V); half group = (ky, two N tiles) = 12 MFMAs
+            h8 bh[2][2], bl[2][2], ah1[2], al1[2], ah2[2], al2[2];
+            auto rd = [&](int s, int ky, int np) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    bh[s][j] = ld_h8(V + h * WG_VPLANE + (4 * (2 * np + j) + ky) * 8);
+                    bl[s][j] = ld_h8(V + (2 + h) * WG_VPLANE + (4 * (2 * np + j) + ky) * 8);
+                }
+            };
+            auto mm = [&](const h8 (&AH)[2], const h8 (&AL)[2], int s, int np) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        acc[mt][2 * np + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL[mt], bh[s][j], acc[mt][2 * np + j], 0, 0, 0);
+                        acc[mt][2 * np + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[mt], bl[s][j], acc[mt][2 * np + j], 0, 0, 0);
+                        acc[mt][2 * np + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[mt], bh[s][j], acc[mt][2 * np + j], 0, 0, 0);
+                    }
+            };
+            rd(0, 0, 0);
+            WG_SB;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) { ah1[mt] = ldw_h8(lane16, W + (((1 * 2 + mt) * 2 + 0) * 64) * 16); al1[mt] = ldw_h8(lane16, W + (((1 * 2 + mt) * 2 + 1) * 64) * 16); }
+            rd(1, 0, 1);
+            mm(ca, cb, 0, 0);
+            WG_SB;
+            rd(0, 1, 0);
+            mm(ca, cb, 1, 1);
+            WG_SB;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) { ah2[mt] = ldw_h8(lane16, W + (((2 * 2 + mt) * 2 + 0) * 64) * 16); al2[mt] = ldw_h8(lane16, W + (((2 * 2 + mt) * 2 + 1) * 64) * 16); }
+            rd(1, 1, 1);
+            mm(ah1, al1, 0, 0);
+            WG_SB;
+            rd(0, 2, 0);
+            mm(ah1, al1, 1, 1);
+            WG_SB;
+            if (more) load_a_carried(st + 1);
+            rd(1, 2, 1);
+            mm(ah2, al2, 0, 0);
+            WG_SB;
+            mm(ah2, al2, 1, 1);
+            WG_SB;
+        }
+#undef WG_SB
+    };
+
+    // ---- prologue: raw(0), raw(1) -> LDS; first-half operands of stage 0; V(0)
+    dma_raw(0, rbuf);
+    if (nst > 1) dma_raw(1, rbuf + WG_RSTRIDE);
+    load_a_carried(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    transform(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    for (int st = 0; st < nst; ++st) {
+        const int cur = st & 1;
+        // raw(st + 2) -> the buffer transform(st) has finished with; issued while nothing this wave will wait for with a counted vmcnt is in flight
+        if (st + 2 < nst) dma_raw(st + 2, rbuf + cur * WG_RSTRIDE);
+        // the two waves of a SIMD take the two halves of a stage in opposite orders (ONE copy of each half in the code: with the stage written
+        // twice -- if (wm) { transform; mfma } else { mfma; transform } -- hipcc's allocator spilled 400+ registers at the merge)
+#pragma clang loop unroll(disable)
+        for (int half = 0; half < 2; ++half) {
+            if ((half ^ wm) == 0) mfma_phase(st, cur);
+            else if (st + 1 < nst) transform(cur ^ 1);
+        }
+        // V(st + 1) written, raw(st + 2) landed, this wave's reads of V(st) / raw(st + 1) complete -> everybody's
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+
+    // ---- the four positions of a pixel meet: two rounds (mt) through LDS; wave (pos, wm) ends up with output rows [4 pos, +4) of its couts
+    f32x16 out[2][2];
+#ifdef WG_NO_EXCHANGE
+    for (int mt = 0; mt < 2; ++mt) for (int q = 0; q < 2; ++q) out[mt][q] = acc[mt][q] + acc[mt][q + 2];
+#else
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        f32x4* Xc = reinterpret_cast<f32x4*>(lds);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                Xc[((wave_u * 4 + nt) * 4 + q) * 64 + lane] = (f32x4){acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 M0 = Xc[(((wm * 4 + 0) * 4 + pos) * 4 + q) * 64 + lane], M1 = Xc[(((wm * 4 + 1) * 4 + pos) * 4 + q) * 64 + lane];
+            const f32x4 M2 = Xc[(((wm * 4 + 2) * 4 + pos) * 4 + q) * 64 + lane], M3 = Xc[(((wm * 4 + 3) * 4 + pos) * 4 + q) * 64 + lane];
+            const f32x4 ev = (M0 + M1) + M2, od = (M1 - M2) - M3;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { out[mt][0][4 * q + r] = ev[r]; out[mt][1][4 * q + r] = od[r]; }
+        }
+        __syncthreads();
+    }
+#endif
+    conv_epilogue<true, 4, 2, 1>(a, ph, n, out, i0, j0, m0, reinterpret_cast<float*>(lds));
+    if (blockIdx.x == (gridDim.x >> 1) && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) clk_end(kernarg_clk<Conv2Args>());
+}
