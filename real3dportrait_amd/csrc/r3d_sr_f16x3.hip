@@ -287,8 +287,8 @@ struct Conv2Args {
 // round 1 measured); from LDS the loop has no global loads, so its stores stream out back to back.
 // The caller has passed a __syncthreads() after its last LDS read; `ev` may alias the main loop's buffers.
 static constexpr int EV_STRIDE = BLOCK_M;              // floats per staged vector
-// PIXMAP = 1 (conv_wino_f16x3_kernel, NT = 2): acc[mt][nt] holds column parity nt of the column pairs -- lane li <-> (row 4 wn + li / 8,
-// columns 2 (li % 8) + nt) -- and the accumulators carry the transformed operands' factor 1/4 (r3d_sr_wino.h).
+// PIXMAP = 1 (experiment): acc[mt][nt] holds column parity nt of the column pairs -- lane li <-> (row 4 wn + li / 8, columns 2 (li % 8) + nt).
+// PIXMAP != 0 (conv_wino_f16x3_kernel): the accumulators carry the transformed operands' factor 1/4 (r3d_sr_wino.h); 2 = the ordinary pixel map.
 template <bool FULL_EPI, int WN, int NT, int PIXMAP = 0>
 __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhase& ph, int n, f32x16 (&acc)[2][NT],
                                               int i0, int j0, int m0, float* ev)
@@ -335,7 +335,7 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
     bool inside_nt[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        const int i = PIXMAP ? i0 + 4 * wn + (li >> 3) : i0 + row0 + nt * 2 + prow, j = PIXMAP ? j0 + 2 * (li & 7) + nt : j0 + pcol;
+        const int i = PIXMAP == 1 ? i0 + 4 * wn + (li >> 3) : i0 + row0 + nt * 2 + prow, j = PIXMAP == 1 ? j0 + 2 * (li & 7) + nt : j0 + pcol;
         inside_nt[nt] = i < ph.outH && j < ph.outW;
         p0[nt] = (unsigned)(i * ph.oy_mul + ph.oy_add) * (unsigned)a.OW + (unsigned)(j * ph.ox_mul + ph.ox_add);
     }
@@ -441,7 +441,7 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
             float* P = a.rgb_partial + (size_t)n * a.rgbp_stride_n + (size_t)(m0 / 64 + wm) * 3 * a.OH * a.OW;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const int i = PIXMAP ? i0 + 4 * wn + (li >> 3) : i0 + row0 + nt * 2 + prow, j = PIXMAP ? j0 + 2 * (li & 7) + nt : j0 + pcol;
+                const int i = PIXMAP == 1 ? i0 + 4 * wn + (li >> 3) : i0 + row0 + nt * 2 + prow, j = PIXMAP == 1 ? j0 + 2 * (li & 7) + nt : j0 + pcol;
                 if (i < ph.outH && j < ph.outW) {
                     const int oy = i * ph.oy_mul + ph.oy_add, ox = j * ph.ox_mul + ph.ox_add;
 #pragma unroll

@@ -16,15 +16,14 @@
 //   * the input transform is done once per block: the raw SPLIT patch (fp16 hi + lo) is staged in LDS by LDS-DMA, each wave transforms
 //     the V rows of ITS position (its 8-channel chunk wm of the 16-channel stage) and writes V as fp16 hi + {fp16 lo | e5m2 records};
 //   * the four positions of a pixel meet in the epilogue through LDS (two rounds of 128 KB), after which the wave holds the ordinary
-//     64 couts x 64 pixels of conv_epilogue<.., PIXMAP = 1>.
+//     64 couts x 64 pixels of conv_epilogue, in the direct kernel's lane <-> pixel map.
 // K stage = 16 input channels.  f16mx: per (ky, tile) one f16 MFMA (hi * hi) and the cross products of (ky0 | ky1) and (ky2 | zero) on
 // the K = 64 fp8 MFMA (lane half h <-> kernel row h): 3 x 32 + 2 x 64 = 224 matrix cycles per (stage, tile) against 2 x 9 x 64 / 4 = 288
 // for the same outputs in the direct kernel (1.29 x; pairing ky2 with the next stage's ky0 would make it 192).  f16x3: 9 f16 MFMAs = 288
 // against 432 (1.5 x).
 // Range: the fold guarantees |x| < 2^15; V' = (a +- b) / 2 keeps |V'| < 2^15 and U' = U 2^(kw-1) keeps |U'| < 2^11 (|U| <= 1.5 max|g|);
 // the factor 4 is taken out with the per-cout epilogue multiplier (exact).
-// The two waves of a SIMD (w, w + 4: same position) run a stage in opposite orders -- wm = 0: MFMAs then transform of the next stage,
-// wm = 1: transform then MFMAs -- so that one wave's VALU / LDS phase sits under the other's matrix phase.
+// The transform of stage s + 1 rides inside the matrix pipeline of stage s in six small pieces (stage_body).
 
 static constexpr int WG_VPLANE = 18 * 8;                            // uint4 slots of one V plane: [V row 18][column pair 8]
 static constexpr int WG_VPOS = 4 * WG_VPLANE;                       // per position: hi chunk 0 | hi chunk 1 | (lo chunk 0 | lo chunk 1) or (rec_h | rec_l)
@@ -193,53 +192,49 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(Conv2Args a)
     const int sAh = raw_slot(kA, offA), sAl = raw_slot(kA + 4, offA), sBh = raw_slot(kB, offB), sBl = raw_slot(kB + 4, offB);
     const int vw_slot = pos * WG_VPOS + r8 * 8 + p8;                  // + plane * WG_VPLANE + pass * 64
 
-    auto transform = [&](int bufi) {                                  // raw[bufi] -> V[bufi]
-#ifdef WG_NO_TRANSFORM
-        return;
-#endif
-        const uint4* R = rbuf + bufi * WG_RSTRIDE;
-        uint4* V = vbuf + bufi * WG_VBUF + vw_slot;
+    // The transform of a stage in six PIECES k = 2 pass + c4 (pass: V rows 8 pass .. 8 pass + 7, rows 16, 17 in lanes 0..15 of pass 2; c4: channels
+    // 4 c4 .. 4 c4 + 3 of the chunk), each small enough (8 + ~12 registers) to ride inside a step of the matrix pipeline below: its four 8-byte LDS
+    // reads are issued in front of the step's MFMAs, its ~30 VALU instructions and three LDS writes behind them.
+    uint2 tr[4];
+    auto tp_load = [&](int bufi, int k) {
+        const int pass = k >> 1, c4 = k & 1;
+        if (pass == 2 && lane >= 16) return;
+        const uint2* R = reinterpret_cast<const uint2*>(rbuf + bufi * WG_RSTRIDE) + c4;
+        tr[0] = R[2 * (sAh + pass * 64)]; tr[1] = R[2 * (sAl + pass * 64)]; tr[2] = R[2 * (sBh + pass * 64)]; tr[3] = R[2 * (sBl + pass * 64)];
+    };
+    auto tp_compute = [&](int bufi, int k) {
+        const int pass = k >> 1, c4 = k & 1;
+        if (pass == 2 && lane >= 16) return;
+        uint4* V = vbuf + bufi * WG_VBUF + vw_slot + pass * 64;
+        const unsigned pah[2] = {tr[0].x, tr[0].y}, pal[2] = {tr[1].x, tr[1].y}, pbh[2] = {tr[2].x, tr[2].y}, pbl[2] = {tr[3].x, tr[3].y};
+        float v[4], lo[4];
+        unsigned hw[2];
 #pragma unroll
-        for (int pass = 0; pass < 3; ++pass) {
-            if (pass == 2 && lane >= 16) break;
-            const uint4 ah = R[sAh + pass * 64], al = R[sAl + pass * 64], bh = R[sBh + pass * 64], bl = R[sBl + pass * 64];
-            const unsigned* pah = reinterpret_cast<const unsigned*>(&ah); const unsigned* pal = reinterpret_cast<const unsigned*>(&al);
-            const unsigned* pbh = reinterpret_cast<const unsigned*>(&bh); const unsigned* pbl = reinterpret_cast<const unsigned*>(&bl);
-            float v[8];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const hh2 la = __builtin_bit_cast(hh2, pal[d]) * half2;
-                const hh2 ls = __builtin_elementwise_fma(__builtin_bit_cast(hh2, pbl[d]), sgn2, la);       // (lo_a + sgn lo_b) / 2, fp16 (2^-22 of x)
-                const unsigned lsu = __builtin_bit_cast(unsigned, ls);
-                const float t0 = mix_hh<0>(pbh[d], sgnv, lsu), t1 = mix_hh<1>(pbh[d], sgnv, lsu);
-                v[2 * d] = mix_hf<0>(pah[d], halfv, t0);
-                v[2 * d + 1] = mix_hf<1>(pah[d], halfv, t1);
-            }
-            uint4 vh;
-            unsigned* pvh = reinterpret_cast<unsigned*>(&vh);
-            float lo[8];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const hh2 hi2 = __builtin_convertvector((f2){v[2 * d], v[2 * d + 1]}, hh2);
-                pvh[d] = __builtin_bit_cast(unsigned, hi2);
-                lo[2 * d] = mix_hf<0>(pvh[d], neg1, v[2 * d]);
-                lo[2 * d + 1] = mix_hf<1>(pvh[d], neg1, v[2 * d + 1]);
-            }
-            V[wm * WG_VPLANE + pass * 64] = vh;
-            if constexpr (MX) {
-                // e5m2 records of V (hi part straight from the fp32 value) and of lo * 2^11; chunk wm = bytes [8 wm, +8) of both 16-byte records
-                const uint2 rh = make_uint2(pack4_x8(v[0] * kMxXh, v[1] * kMxXh, v[2] * kMxXh, v[3] * kMxXh), pack4_x8(v[4] * kMxXh, v[5] * kMxXh, v[6] * kMxXh, v[7] * kMxXh));
-                const uint2 rl = make_uint2(pack4_x8(lo[0] * kMxXl, lo[1] * kMxXl, lo[2] * kMxXl, lo[3] * kMxXl), pack4_x8(lo[4] * kMxXl, lo[5] * kMxXl, lo[6] * kMxXl, lo[7] * kMxXl));
-                reinterpret_cast<uint2*>(V + 2 * WG_VPLANE + pass * 64)[wm] = rh;
-                reinterpret_cast<uint2*>(V + 3 * WG_VPLANE + pass * 64)[wm] = rl;
-            } else {
-                uint4 vl;
-                unsigned* pvl = reinterpret_cast<unsigned*>(&vl);
-#pragma unroll
-                for (int d = 0; d < 4; ++d) pvl[d] = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){lo[2 * d], lo[2 * d + 1]}, hh2));
-                V[(2 + wm) * WG_VPLANE + pass * 64] = vl;
-            }
+        for (int d = 0; d < 2; ++d) {
+            const hh2 la = __builtin_bit_cast(hh2, pal[d]) * half2;
+            const hh2 ls = __builtin_elementwise_fma(__builtin_bit_cast(hh2, pbl[d]), sgn2, la);       // (lo_a + sgn lo_b) / 2, fp16 (2^-22 of x)
+            const unsigned lsu = __builtin_bit_cast(unsigned, ls);
+            const float t0 = mix_hh<0>(pbh[d], sgnv, lsu), t1 = mix_hh<1>(pbh[d], sgnv, lsu);
+            v[2 * d] = mix_hf<0>(pah[d], halfv, t0);
+            v[2 * d + 1] = mix_hf<1>(pah[d], halfv, t1);
+            const hh2 hi2 = __builtin_convertvector((f2){v[2 * d], v[2 * d + 1]}, hh2);
+            hw[d] = __builtin_bit_cast(unsigned, hi2);
+            lo[2 * d] = mix_hf<0>(hw[d], neg1, v[2 * d]);
+            lo[2 * d + 1] = mix_hf<1>(hw[d], neg1, v[2 * d + 1]);
         }
+        reinterpret_cast<uint2*>(V + wm * WG_VPLANE)[c4] = make_uint2(hw[0], hw[1]);
+        if constexpr (MX) {
+            // e5m2 records of V (hi part straight from the fp32 value) and of lo * 2^11: bytes [8 wm + 4 c4, +4) of the two 16-byte records of the stage
+            reinterpret_cast<unsigned*>(V + 2 * WG_VPLANE)[2 * wm + c4] = pack4_x8(v[0] * kMxXh, v[1] * kMxXh, v[2] * kMxXh, v[3] * kMxXh);
+            reinterpret_cast<unsigned*>(V + 3 * WG_VPLANE)[2 * wm + c4] = pack4_x8(lo[0] * kMxXl, lo[1] * kMxXl, lo[2] * kMxXl, lo[3] * kMxXl);
+        } else {
+            const hh2 l0 = __builtin_convertvector((f2){lo[0], lo[1]}, hh2), l1 = __builtin_convertvector((f2){lo[2], lo[3]}, hh2);
+            reinterpret_cast<uint2*>(V + (2 + wm) * WG_VPLANE)[c4] = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
+        }
+    };
+    auto transform = [&](int bufi) {                                  // raw[bufi] -> V[bufi] in one go (prologue)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { tp_load(bufi, k); tp_compute(bufi, k); }
     };
 
     // ---- accumulators: M_pos of couts [64 wm, +64) x (16 rows x 8 column pairs) = acc[mt][nt], N tile nt = rows 4 nt .. 4 nt + 3
@@ -281,126 +276,116 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(Conv2Args a)
     };
     const int boff = pos * WG_VPOS + li;                              // B slot: + plane * WG_VPLANE + (4 nt + ky) * 8
 
-    // One stage of matrix work as a pipeline of HALF groups (4 MFMAs on two N tiles each): the B operands of half group i + 1 are read, and the
-    // A operands of a later group loaded, right before the MFMAs of half group i are issued; the fences keep hipcc from hoisting every read
-    // and load of the stage to its top (485 spilled registers in the first version).  Live operands: <= 40 (A) + 32 (B) registers.
-    auto mfma_phase = [&](int st, int bufi) {
+    // One stage = a pipeline of STEPS of 128 (f16mx) / 192 (f16x3) matrix cycles.  Step s: the B operands of step s + 1 are read (and, at a few
+    // steps, A operands loaded ~512 matrix cycles ahead of their use; and the LDS reads of transform piece s issued) | the step's MFMAs | the VALU
+    // part of transform piece s (next stage's V).  The fences keep hipcc from hoisting every read and load of the stage to its top (485 spilled
+    // registers in the first version).  Both waves of a SIMD run the same sequence and cover each other's LDS / L2 latencies.
+    // (First version: one wave's whole transform under the other's whole matrix phase, the waves of a SIMD in opposite orders -- a single wave
+    // then has to keep the matrix pipe fed alone, and a B read issued one step ahead does not arrive in time: the matrix phase took 2.06 x its MFMA time.)
+    auto stage_body = [&](int st, int bufi) {
         const uint4* V = vbuf + bufi * WG_VBUF + boff;
         const unsigned W = wa_blk + (unsigned)st * wa_stage;
         const bool more = st + 1 < nst;
+        const int nxt = bufi ^ 1;
 #define WG_SB __builtin_amdgcn_sched_barrier(0)
         if constexpr (MX) {
-            // groups: G0 f16 ky 0 (ca) | G1 f16 ky 1 (cb) | G2 fp8 (ky0 | ky1) (a8p0) | G3 f16 ky 2 (ak2) | G4 fp8 (ky2 | zero) (a8p1)
+            // steps: F(ky 0) x 2 | F(ky 1) x 2 | E(ky0 | ky1) x 4 | F(ky 2) x 2 | E(ky2 | zero) x 4;  F = f16 hi * hi on two N tiles, E = fp8 cross products on one
             h8 bf[2][2], ak2[2];
-            i8v b8[2][2], a8p0[2], a8p1[2];
-            auto rd_f = [&](int s, int ky, int np) {
+            i8v b8[2], a8p0[2], a8p1[2];
+            auto rd_step = [&](int s) {                                // the B operands of step s
+                const bool isE = (s >= 4 && s < 8) || s >= 10;
+                if (!isE) {
+                    const int ky = s < 4 ? s >> 1 : 2, np = s & 1;
 #pragma unroll
-                for (int j = 0; j < 2; ++j) bf[s][j] = ld_h8(V + h * WG_VPLANE + (4 * (2 * np + j) + ky) * 8);
-            };
-            auto rd_8 = [&](int s, int kyh, int np) {              // kyh: kernel row of this lane half
-#pragma unroll
-                for (int j = 0; j < 2; ++j) b8[s][j] = ld_i8(V + 2 * WG_VPLANE + (4 * (2 * np + j) + kyh) * 8, V + 3 * WG_VPLANE + (4 * (2 * np + j) + kyh) * 8);
-            };
-            auto mm_f = [&](const h8 (&A)[2], int s, int np) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) acc[mt][2 * np + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A[mt], bf[s][j], acc[mt][2 * np + j], 0, 0, 0);
-            };
-            auto mm_8 = [&](const i8v (&A)[2], int s, int np) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-#pragma unroll
-                    for (int mt = 0; mt < 2; ++mt)
-                        acc[mt][2 * np + j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A[mt], b8[s][j], acc[mt][2 * np + j], 0, kMxFmtB, 0, kMxScaleA, 0, kMxScaleB);
-            };
-            rd_f(0, 0, 0);
-            WG_SB;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) a8p0[mt] = ldw_i8(lane16, W + (384 + (mt * 2 + 0) * 64) * 16, W + (384 + (mt * 2 + 1) * 64) * 16);
-            rd_f(1, 0, 1);
-            mm_f(ca, 0, 0);                                           // G0
-            WG_SB;
-            rd_f(0, 1, 0);
-            mm_f(ca, 1, 1);
-            WG_SB;
-            rd_f(1, 1, 1);
-            mm_f(cb, 0, 0);                                           // G1
-            WG_SB;
-            rd_8(0, h, 0);
-            mm_f(cb, 1, 1);
-            WG_SB;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) ak2[mt] = ldw_h8(lane16, W + ((2 * 2 + mt) * 64) * 16);
-            rd_8(1, h, 1);
-            mm_8(a8p0, 0, 0);                                         // G2
-            WG_SB;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)                            // ky 2 alone in its pair: lanes h = 1 (the second K half) read zeros (out of range)
-                a8p1[mt] = ldw_i8(z16, W + (640 + (mt * 2 + 0) * 32) * 16, W + (640 + (mt * 2 + 1) * 32) * 16);
-            rd_f(0, 2, 0);
-            mm_8(a8p0, 1, 1);
-            WG_SB;
-            rd_f(1, 2, 1);
-            mm_f(ak2, 0, 0);                                          // G3
-            WG_SB;
-            if (more) load_a_carried(st + 1);
-            rd_8(0, 2, 0);
-            mm_f(ak2, 1, 1);
-            WG_SB;
-            rd_8(1, 2, 1);
-            mm_8(a8p1, 0, 0);                                         // G4
-            WG_SB;
-            mm_8(a8p1, 1, 1);
-            WG_SB;
-        } else {
-            // f16x3: per kernel row  lo(U) hi(V) + hi(U) lo(V) + hi(U) hi(V); half group = (ky, two N tiles) = 12 MFMAs
-            h8 bh[2][2], bl[2][2], ah1[2], al1[2], ah2[2], al2[2];
-            auto rd = [&](int s, int ky, int np) {
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    bh[s][j] = ld_h8(V + h * WG_VPLANE + (4 * (2 * np + j) + ky) * 8);
-                    bl[s][j] = ld_h8(V + (2 + h) * WG_VPLANE + (4 * (2 * np + j) + ky) * 8);
+                    for (int j = 0; j < 2; ++j) bf[s & 1][j] = ld_h8(V + h * WG_VPLANE + (4 * (2 * np + j) + ky) * 8);
+                } else {
+                    const int nt = s < 8 ? s - 4 : s - 10;
+                    const int kyh = s < 8 ? h : 2;                    // kernel row of this lane half
+                    b8[s & 1] = ld_i8(V + 2 * WG_VPLANE + (4 * nt + kyh) * 8, V + 3 * WG_VPLANE + (4 * nt + kyh) * 8);
                 }
             };
-            auto mm = [&](const h8 (&AH)[2], const h8 (&AL)[2], int s, int np) {
+            rd_step(0);
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+            for (int s = 0; s < 14; ++s) {
+                WG_SB;
+                if (s + 1 < 14) rd_step(s + 1);
+                if (s == 0) {
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        acc[mt][2 * np + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL[mt], bh[s][j], acc[mt][2 * np + j], 0, 0, 0);
-                        acc[mt][2 * np + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[mt], bl[s][j], acc[mt][2 * np + j], 0, 0, 0);
-                        acc[mt][2 * np + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH[mt], bh[s][j], acc[mt][2 * np + j], 0, 0, 0);
-                    }
+                    for (int mt = 0; mt < 2; ++mt) a8p0[mt] = ldw_i8(lane16, W + (384 + (mt * 2 + 0) * 64) * 16, W + (384 + (mt * 2 + 1) * 64) * 16);
+                }
+                if (s == 4) {
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) ak2[mt] = ldw_h8(lane16, W + ((2 * 2 + mt) * 64) * 16);
+                }
+                if (s == 6) {
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)                    // ky 2 alone in its pair: lanes h = 1 (the second K half) read zeros (out of range)
+                        a8p1[mt] = ldw_i8(z16, W + (640 + (mt * 2 + 0) * 32) * 16, W + (640 + (mt * 2 + 1) * 32) * 16);
+                }
+                if (s == 10 && more) load_a_carried(st + 1);
+                if (s < 6 && more) tp_load(nxt, s);
+                WG_SB;
+                const bool isE = (s >= 4 && s < 8) || s >= 10;
+                if (!isE) {
+                    const int np = s & 1;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) {
+                            const h8 A = s < 2 ? ca[mt] : (s < 4 ? cb[mt] : ak2[mt]);
+                            acc[mt][2 * np + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, bf[s & 1][j], acc[mt][2 * np + j], 0, 0, 0);
+                        }
+                } else {
+                    const int nt = s < 8 ? s - 4 : s - 10;
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(s < 8 ? a8p0[mt] : a8p1[mt], b8[s & 1], acc[mt][nt], 0, kMxFmtB, 0, kMxScaleA, 0, kMxScaleB);
+                }
+                WG_SB;
+                if (s < 6 && more) tp_compute(nxt, s);
+            }
+            WG_SB;
+        } else {
+            // f16x3: step = (kernel row ky, N tile nt): lo(U) hi(V) + hi(U) lo(V) + hi(U) hi(V) on both cout tiles = 6 MFMAs
+            h8 bh[2], bl[2], ah1[2], al1[2], ah2[2], al2[2];
+            auto rd_step = [&](int s) {
+                const int ky = s >> 2, nt = s & 3;
+                bh[s & 1] = ld_h8(V + h * WG_VPLANE + (4 * nt + ky) * 8);
+                bl[s & 1] = ld_h8(V + (2 + h) * WG_VPLANE + (4 * nt + ky) * 8);
             };
-            rd(0, 0, 0);
-            WG_SB;
+            rd_step(0);
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) { ah1[mt] = ldw_h8(lane16, W + (((1 * 2 + mt) * 2 + 0) * 64) * 16); al1[mt] = ldw_h8(lane16, W + (((1 * 2 + mt) * 2 + 1) * 64) * 16); }
-            rd(1, 0, 1);
-            mm(ca, cb, 0, 0);
-            WG_SB;
-            rd(0, 1, 0);
-            mm(ca, cb, 1, 1);
-            WG_SB;
+            for (int s = 0; s < 12; ++s) {
+                WG_SB;
+                if (s + 1 < 12) rd_step(s + 1);
+                if (s == 0) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) { ah2[mt] = ldw_h8(lane16, W + (((2 * 2 + mt) * 2 + 0) * 64) * 16); al2[mt] = ldw_h8(lane16, W + (((2 * 2 + mt) * 2 + 1) * 64) * 16); }
-            rd(1, 1, 1);
-            mm(ah1, al1, 0, 0);
-            WG_SB;
-            rd(0, 2, 0);
-            mm(ah1, al1, 1, 1);
-            WG_SB;
-            if (more) load_a_carried(st + 1);
-            rd(1, 2, 1);
-            mm(ah2, al2, 0, 0);
-            WG_SB;
-            mm(ah2, al2, 1, 1);
+                    for (int mt = 0; mt < 2; ++mt) { ah1[mt] = ldw_h8(lane16, W + (((1 * 2 + mt) * 2 + 0) * 64) * 16); al1[mt] = ldw_h8(lane16, W + (((1 * 2 + mt) * 2 + 1) * 64) * 16); }
+                }
+                if (s == 4) {
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) { ah2[mt] = ldw_h8(lane16, W + (((2 * 2 + mt) * 2 + 0) * 64) * 16); al2[mt] = ldw_h8(lane16, W + (((2 * 2 + mt) * 2 + 1) * 64) * 16); }
+                }
+                if (s == 8 && more) load_a_carried(st + 1);
+                if (s < 6 && more) tp_load(nxt, s);
+                WG_SB;
+                const int ky = s >> 2, nt = s & 3;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const h8 AH = ky == 0 ? ca[mt] : (ky == 1 ? ah1[mt] : ah2[mt]), AL = ky == 0 ? cb[mt] : (ky == 1 ? al1[mt] : al2[mt]);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AL, bh[s & 1], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, bl[s & 1], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, bh[s & 1], acc[mt][nt], 0, 0, 0);
+                }
+                WG_SB;
+                if (s < 6 && more) tp_compute(nxt, s);
+            }
             WG_SB;
         }
 #undef WG_SB
     };
 
+    R3D_STAMP_DECL;
     // ---- prologue: raw(0), raw(1) -> LDS; first-half operands of stage 0; V(0)
     dma_raw(0, rbuf);
     if (nst > 1) dma_raw(1, rbuf + WG_RSTRIDE);
@@ -413,21 +398,19 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(Conv2Args a)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
+    R3D_STAMP(4);
     for (int st = 0; st < nst; ++st) {
         const int cur = st & 1;
         // raw(st + 2) -> the buffer transform(st) has finished with; issued while nothing this wave will wait for with a counted vmcnt is in flight
         if (st + 2 < nst) dma_raw(st + 2, rbuf + cur * WG_RSTRIDE);
-        // the two waves of a SIMD take the two halves of a stage in opposite orders (ONE copy of each half in the code: with the stage written
-        // twice -- if (wm) { transform; mfma } else { mfma; transform } -- hipcc's allocator spilled 400+ registers at the merge)
-#pragma clang loop unroll(disable)
-        for (int half = 0; half < 2; ++half) {
-            if ((half ^ wm) == 0) mfma_phase(st, cur);
-            else if (st + 1 < nst) transform(cur ^ 1);
-        }
+        stage_body(st, cur);
+        R3D_STAMP(5);
         // V(st + 1) written, raw(st + 2) landed, this wave's reads of V(st) / raw(st + 1) complete -> everybody's
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        R3D_STAMP(7);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
+        R3D_STAMP(8);
     }
 
     // ---- the four positions of a pixel meet: two rounds (mt) through LDS; wave (pos, wm) ends up with output rows [4 pos, +4) of its couts
@@ -444,17 +427,33 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(Conv2Args a)
             for (int q = 0; q < 4; ++q)
                 Xc[((wave_u * 4 + nt) * 4 + q) * 64 + lane] = (f32x4){acc[mt][nt][4 * q], acc[mt][nt][4 * q + 1], acc[mt][nt][4 * q + 2], acc[mt][nt][4 * q + 3]};
         __syncthreads();
+        // read back in the pixel map of conv_epilogue (lane li <-> row 2 nt + li / 16, column (li % 16 - 2 (li / 16)) % 16 of the wave's four rows): a
+        // lane takes ONE column of its pair -- even: (M1 + M2) + M0, odd: (M1 - M2) - M3 -- so the stores below are the direct kernel's contiguous
+        // 16-pixel rows (with the lane <-> column-pair map the first version kept, every store instruction wrote every other pixel: 59 k cycles of epilogue)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 M0 = Xc[(((wm * 4 + 0) * 4 + pos) * 4 + q) * 64 + lane], M1 = Xc[(((wm * 4 + 1) * 4 + pos) * 4 + q) * 64 + lane];
-            const f32x4 M2 = Xc[(((wm * 4 + 2) * 4 + pos) * 4 + q) * 64 + lane], M3 = Xc[(((wm * 4 + 3) * 4 + pos) * 4 + q) * 64 + lane];
-            const f32x4 ev = (M0 + M1) + M2, od = (M1 - M2) - M3;
+        for (int nt = 0; nt < 2; ++nt) {
+            const int prow = li >> 4, pcol = ((li & 15) - 2 * prow) & 15, par = pcol & 1;
+            const int lw = (2 * nt + prow) * 8 + (pcol >> 1) + 32 * h;
+            const float sg = par ? -1.0f : 1.0f;
+            const f32x4* Xr = Xc + (size_t)((wm * 4) * 4 + pos) * 4 * 64 + lw;               // + p * 1024 + q * 64
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { out[mt][0][4 * q + r] = ev[r]; out[mt][1][4 * q + r] = od[r]; }
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 R0 = Xr[(par ? 3 : 0) * 1024 + q * 64], M1 = Xr[1 * 1024 + q * 64], M2 = Xr[2 * 1024 + q * 64];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[mt][nt][4 * q + r] = __builtin_fmaf(sg, R0[r], __builtin_fmaf(sg, M2[r], M1[r]));
+            }
         }
         __syncthreads();
     }
 #endif
-    conv_epilogue<true, 4, 2, 1>(a, ph, n, out, i0, j0, m0, reinterpret_cast<float*>(lds));
+    R3D_STAMP(9);
+    conv_epilogue<true, 4, 2, 2>(a, ph, n, out, i0, j0, m0, reinterpret_cast<float*>(lds));
+    R3D_STAMP(10);
     if (blockIdx.x == (gridDim.x >> 1) && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) clk_end(kernarg_clk<Conv2Args>());
+#ifdef R3D_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    R3D_STAMP(11);
+    if ((threadIdx.x & 63) == 0) { for (int i_ = 4; i_ < 12; ++i_) atomicAdd(&r3d::g_stamps[8 + i_], st_acc_[i_]); atomicAdd(&r3d::g_stamps[30], 1ull); }
+    R3D_STAMP_CLOCKS(26);
+#endif
 }
