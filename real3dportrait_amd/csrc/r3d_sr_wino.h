@@ -34,26 +34,29 @@ static constexpr int WG_RBUF = 9 * WG_RPLANE;                       // 1296 uint
 static constexpr int WG_RSEGS = (WG_RBUF + 63) / 64;                // 21 DMA segments of 64 slots
 static constexpr int WG_RSTRIDE = WG_RSEGS * 64;                    // 1344: the last segment's tail lanes land in padding
 static constexpr int WG_LDS_UINT4 = 8192;                           // main loop: 2 x 2304 + 2 x 1344 = 7296; epilogue exchange: 8192 (128 KB)
+#ifndef WG_X_PIECE
+#define WG_X_PIECE 0                // timing experiments: 1 = transform pieces without their LDS traffic, 2 = without their VALU work
+#endif
+#ifndef WG_PD
+#define WG_PD 3                     // a transform piece is consumed this many (odd: 1 or 3) steps after its LDS reads were issued
+#endif
+#ifndef WG_BD
+#define WG_BD 1                     // B operands are read this many steps ahead of their MFMAs
+#endif
+#ifndef WG_RL
+#define WG_RL 4
+#define WG_RS 10
+#endif
 static constexpr int WG_WBLK = 768;                                 // uint4 of weights per (cout tile, stage, wave)
 
-// d = (float)half(x, HI) * m + c   (v_fma_mix_f32: one instruction instead of v_cvt_f32_f16 + v_fma_f32)
+// d = (float)half(x, HI) * m + c  and  d = (float)half(x, HI) * m + (float)half(c, HI): hipcc selects v_fma_mix_f32 for these (one instruction instead of
+// v_cvt_f32_f16 + v_fma_f32) as long as the multiplier is not a literal it can fold (+-1).  Plain expressions, not inline asm: hipcc's hazard recogniser
+// does not look inside an asm statement, and with the VALU work interleaved between MFMAs (sched_group_barrier) the asm form computed garbage.
+typedef _Float16 wg_hh2 __attribute__((ext_vector_type(2)));
 template <int HI>
-__device__ __forceinline__ float mix_hf(unsigned x, float m, float c)
-{
-    float d;
-    if (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(x), "s"(m), "v"(c));
-    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(x), "s"(m), "v"(c));
-    return d;
-}
-// d = (float)half(x, HI) * m + (float)half(c, HI)
+__device__ __forceinline__ float mix_hf(unsigned x, float m, float c) { return __builtin_fmaf((float)__builtin_bit_cast(wg_hh2, x)[HI], m, c); }
 template <int HI>
-__device__ __forceinline__ float mix_hh(unsigned x, float m, unsigned c)
-{
-    float d;
-    if (HI) asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(x), "s"(m), "v"(c));
-    else asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(x), "s"(m), "v"(c));
-    return d;
-}
+__device__ __forceinline__ float mix_hh(unsigned x, float m, unsigned c) { return __builtin_fmaf((float)__builtin_bit_cast(wg_hh2, x)[HI], m, (float)__builtin_bit_cast(wg_hh2, c)[HI]); }
 
 // ---- weights: U = G g per kernel row, times 2^(kw[co] - 1), split and laid out as the per-wave streams the kernel loads ----------------
 // block (ct, st, w = 4 wm + pos) of WG_WBLK uint4, cout = 128 ct + 64 wm + 32 mt + li, channels 16 st ..:
@@ -142,32 +145,38 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(Conv2Args a)
     const uint4* X = a.x + (size_t)n * a.x_stride_n;
     if (blockIdx.x == (gridDim.x >> 1) && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) clk_begin(kernarg_clk<Conv2Args>());
 
-    // ---- raw patch DMA: slot e of a raw buffer <-> (plane k = 4 hl + 2 chunk + parity, row, column index idx), patch column 2 idx + parity
-    unsigned pf_off[3];
-    unsigned pf_valid = 0;
+    // ---- raw patch staging: slot e of a raw buffer <-> (plane k = 4 hl + 2 chunk + parity, row, column index idx), patch column 2 idx + parity.
+    // Global -> VGPR (buffer loads: out-of-image slots point past num_records and read zeros) -> ds_write_b128, half a stage apart, NOT LDS-DMA:
+    // an LDS-DMA issued from inline asm is invisible to hipcc's vmcnt bookkeeping, and every counted wait hipcc emits for a weight load older than
+    // the DMA then waits for the DMA too -- the first version stalled on the patch's HBM latency at the top of every stage.
+    int pf_voff[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int e = (8 * k + wave_u) * 64 + lane;
-        unsigned off = 0;
+        int off = (int)0x80000000;
         if (e < WG_RBUF) {
             int kp, row, idx;
             if (e < WG_REXTRA) { kp = e / WG_RPLANE; const int rem = e - kp * WG_RPLANE; row = rem >> 3; idx = ((rem & 7) - kp) & 7; }
             else { const int rem = e - WG_REXTRA; row = rem >> 3; kp = rem & 7; idx = 8; }
             const int hl = kp >> 2, c = (kp >> 1) & 1, par = kp & 1;
             const int iy = i0 - 1 + row, ix = j0 - 1 + 2 * idx + par;
-            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
-                off = (unsigned)(hl * plane) + (unsigned)(c * chunk_stride + iy * a.W + ix);
-                pf_valid |= 1u << k;
-            }
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) off = (int)(((unsigned)(hl * plane) + (unsigned)(c * chunk_stride + iy * a.W + ix)) * 16u);
         }
-        pf_off[k] = off;
+        pf_voff[k] = off;
     }
-    const bool three = wave_u < WG_RSEGS - 16;                        // waves 0..4 issue three patch DMAs per stage, the others two
-    auto dma_raw = [&](int st, uint4* dst) {
-        const uint4* Xs = X + (size_t)(2 * st) * chunk_stride;
+    const bool three = wave_u < WG_RSEGS - 16;                        // waves 0..4 stage three 64-slot segments per stage, the others two
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(X), 0, (unsigned)(2 * plane) * 16u, 0x00020000);   // host: a sample is < 2 GB
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    auto raw_load = [&](int st, u32x4 (&rr)[3]) {
+        const unsigned soff = (unsigned)(2 * st * chunk_stride) * 16u;
 #pragma unroll
         for (int k = 0; k < 3; ++k)
-            if (k < 2 || three) dma64((pf_valid & (1u << k)) ? Xs + pf_off[k] : g_zero16, dst + 64 * (8 * k + wave_u));
+            if (k < 2 || three) rr[k] = __builtin_amdgcn_raw_buffer_load_b128(xrs, pf_voff[k], (int)soff, 0);
+    };
+    auto raw_store = [&](uint4* dst, const u32x4 (&rr)[3]) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (k < 2 || three) dst[64 * (8 * k + wave_u) + lane] = make_uint4(rr[k][0], rr[k][1], rr[k][2], rr[k][3]);
     };
     uint4* const vbuf = lds;                                          // [2][WG_VBUF]
     uint4* const rbuf = lds + 2 * WG_VBUF;                            // [2][WG_RSTRIDE]
@@ -191,26 +200,38 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(Conv2Args a)
     const int kA = 2 * wm + parA, kB = 2 * wm + parB;                 // hi planes; + 4 for the lo planes
     const int sAh = raw_slot(kA, offA), sAl = raw_slot(kA + 4, offA), sBh = raw_slot(kB, offB), sBl = raw_slot(kB + 4, offB);
     const int vw_slot = pos * WG_VPOS + r8 * 8 + p8;                  // + plane * WG_VPLANE + pass * 64
+    const int d2 = (16 + (r8 & 1) - r8) * 8 - 128;                    // pass 2: every lane takes row 16 + (r8 & 1) (rows 16, 17 eight times over: same values to the same slots)
 
-    // The transform of a stage in six PIECES k = 2 pass + c4 (pass: V rows 8 pass .. 8 pass + 7, rows 16, 17 in lanes 0..15 of pass 2; c4: channels
-    // 4 c4 .. 4 c4 + 3 of the chunk), each small enough (8 + ~12 registers) to ride inside a step of the matrix pipeline below: its four 8-byte LDS
-    // reads are issued in front of the step's MFMAs, its ~30 VALU instructions and three LDS writes behind them.
-    uint2 tr[4];
-    auto tp_load = [&](int bufi, int k) {
-        const int pass = k >> 1, c4 = k & 1;
-        if (pass == 2 && lane >= 16) return;
-        const uint2* R = reinterpret_cast<const uint2*>(rbuf + bufi * WG_RSTRIDE) + c4;
-        tr[0] = R[2 * (sAh + pass * 64)]; tr[1] = R[2 * (sAl + pass * 64)]; tr[2] = R[2 * (sBh + pass * 64)]; tr[3] = R[2 * (sBl + pass * 64)];
-    };
-    auto tp_compute = [&](int bufi, int k) {
-        const int pass = k >> 1, c4 = k & 1;
-        if (pass == 2 && lane >= 16) return;
-        uint4* V = vbuf + bufi * WG_VBUF + vw_slot + pass * 64;
-        const unsigned pah[2] = {tr[0].x, tr[0].y}, pal[2] = {tr[1].x, tr[1].y}, pbh[2] = {tr[2].x, tr[2].y}, pbl[2] = {tr[3].x, tr[3].y};
-        float v[4], lo[4];
-        unsigned hw[2];
+    // The transform of a stage in three PIECES (pass p: V rows 8 p .. 8 p + 7, pass 2 = rows 16, 17; the wave's 8-channel chunk): four 16-byte LDS reads
+    // issued in step 2 p of the matrix pipeline below, ~70 VALU instructions spread between the MFMAs of step 2 p + 1, then one 16-byte and two 8-byte
+    // LDS writes.  (A version with six 4-channel pieces -- 8-byte reads, 8- and 4-byte writes -- spent 2 100 LDS cycles per stage and CU on them; this 980.)
+    // Unconditional (the last stage transforms stale bytes into a V buffer nobody reads): a branch would cut the scheduling region the interleave needs.
+    uint4 tr[2][4];                                                   // two pieces in flight: piece p is read in step 2 p and consumed WG_PD steps later
+    auto tp_load = [&](int bufi, int pass) {
+        const uint4* R = rbuf + bufi * WG_RSTRIDE;
+        const int o = pass == 2 ? d2 : 0;
+#if WG_X_PIECE == 1
+        (void)R; (void)o;
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
+        for (int q = 0; q < 4; ++q) { tr[pass & 1][q] = make_uint4(0x3c003c00u + lane, 0x3c003c00u + pass, 0x38003800u, 0x34003400u + q); asm volatile("" : "+v"(tr[pass & 1][q].x), "+v"(tr[pass & 1][q].y), "+v"(tr[pass & 1][q].z), "+v"(tr[pass & 1][q].w)); }
+#else
+        tr[pass & 1][0] = R[sAh + o + pass * 64]; tr[pass & 1][1] = R[sAl + o + pass * 64]; tr[pass & 1][2] = R[sBh + o + pass * 64]; tr[pass & 1][3] = R[sBl + o + pass * 64];
+#endif
+    };
+    auto tp_compute = [&](int bufi, int pass) {
+        uint4* V = vbuf + bufi * WG_VBUF + vw_slot + pass * 64 + (pass == 2 ? d2 : 0);
+        const unsigned* pah = reinterpret_cast<const unsigned*>(&tr[pass & 1][0]); const unsigned* pal = reinterpret_cast<const unsigned*>(&tr[pass & 1][1]);
+        const unsigned* pbh = reinterpret_cast<const unsigned*>(&tr[pass & 1][2]); const unsigned* pbl = reinterpret_cast<const unsigned*>(&tr[pass & 1][3]);
+#if WG_X_PIECE == 2
+        V[wm * WG_VPLANE] = make_uint4(pah[0] ^ pbh[0], pah[1] ^ pbh[1], pah[2] ^ pbh[2], pah[3] ^ pbh[3]);
+        reinterpret_cast<uint2*>(V + 2 * WG_VPLANE)[wm] = make_uint2(pal[0], pal[1]);
+        reinterpret_cast<uint2*>(V + 3 * WG_VPLANE)[wm] = make_uint2(pbl[0], pbl[1]);
+        return;
+#endif
+        float v[8], lo[8];
+        unsigned hw[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
             const hh2 la = __builtin_bit_cast(hh2, pal[d]) * half2;
             const hh2 ls = __builtin_elementwise_fma(__builtin_bit_cast(hh2, pbl[d]), sgn2, la);       // (lo_a + sgn lo_b) / 2, fp16 (2^-22 of x)
             const unsigned lsu = __builtin_bit_cast(unsigned, ls);
@@ -222,19 +243,28 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(Conv2Args a)
             lo[2 * d] = mix_hf<0>(hw[d], neg1, v[2 * d]);
             lo[2 * d + 1] = mix_hf<1>(hw[d], neg1, v[2 * d + 1]);
         }
-        reinterpret_cast<uint2*>(V + wm * WG_VPLANE)[c4] = make_uint2(hw[0], hw[1]);
+#if WG_X_PIECE == 1
+        {
+            const unsigned r0 = pack4_x8(v[0], v[1], v[2], v[3]), r1 = pack4_x8(v[4], v[5], v[6], v[7]), r2 = pack4_x8(lo[0] * kMxXl, lo[1] * kMxXl, lo[2] * kMxXl, lo[3] * kMxXl), r3 = pack4_x8(lo[4] * kMxXl, lo[5] * kMxXl, lo[6] * kMxXl, lo[7] * kMxXl);
+            asm volatile("" :: "v"(hw[0]), "v"(hw[1]), "v"(hw[2]), "v"(hw[3]), "v"(r0), "v"(r1), "v"(r2), "v"(r3));
+            return;
+        }
+#endif
+        V[wm * WG_VPLANE] = make_uint4(hw[0], hw[1], hw[2], hw[3]);
         if constexpr (MX) {
-            // e5m2 records of V (hi part straight from the fp32 value) and of lo * 2^11: bytes [8 wm + 4 c4, +4) of the two 16-byte records of the stage
-            reinterpret_cast<unsigned*>(V + 2 * WG_VPLANE)[2 * wm + c4] = pack4_x8(v[0] * kMxXh, v[1] * kMxXh, v[2] * kMxXh, v[3] * kMxXh);
-            reinterpret_cast<unsigned*>(V + 3 * WG_VPLANE)[2 * wm + c4] = pack4_x8(lo[0] * kMxXl, lo[1] * kMxXl, lo[2] * kMxXl, lo[3] * kMxXl);
+            // e5m2 records of V (hi part straight from the fp32 value) and of lo * 2^11: chunk wm = bytes [8 wm, +8) of the two 16-byte records of the stage
+            reinterpret_cast<uint2*>(V + 2 * WG_VPLANE)[wm] = make_uint2(pack4_x8(v[0] * kMxXh, v[1] * kMxXh, v[2] * kMxXh, v[3] * kMxXh), pack4_x8(v[4] * kMxXh, v[5] * kMxXh, v[6] * kMxXh, v[7] * kMxXh));
+            reinterpret_cast<uint2*>(V + 3 * WG_VPLANE)[wm] = make_uint2(pack4_x8(lo[0] * kMxXl, lo[1] * kMxXl, lo[2] * kMxXl, lo[3] * kMxXl), pack4_x8(lo[4] * kMxXl, lo[5] * kMxXl, lo[6] * kMxXl, lo[7] * kMxXl));
         } else {
-            const hh2 l0 = __builtin_convertvector((f2){lo[0], lo[1]}, hh2), l1 = __builtin_convertvector((f2){lo[2], lo[3]}, hh2);
-            reinterpret_cast<uint2*>(V + (2 + wm) * WG_VPLANE)[c4] = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
+            unsigned lw[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) lw[d] = __builtin_bit_cast(unsigned, __builtin_convertvector((f2){lo[2 * d], lo[2 * d + 1]}, hh2));
+            V[(2 + wm) * WG_VPLANE] = make_uint4(lw[0], lw[1], lw[2], lw[3]);
         }
     };
     auto transform = [&](int bufi) {                                  // raw[bufi] -> V[bufi] in one go (prologue)
 #pragma unroll
-        for (int k = 0; k < 6; ++k) { tp_load(bufi, k); tp_compute(bufi, k); }
+        for (int k = 0; k < 3; ++k) { tp_load(bufi, k); tp_compute(bufi, k); }
     };
 
     // ---- accumulators: M_pos of couts [64 wm, +64) x (16 rows x 8 column pairs) = acc[mt][nt], N tile nt = rows 4 nt .. 4 nt + 3
@@ -249,10 +279,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(Conv2Args a)
     // A operands: this wave's stream [ct][st][w] (WG_WBLK uint4 per stage), per-lane pointer
     // (buffer loads: one VGPR of lane offset for every load of the kernel, the rest of the address on the scalar unit; lanes that must read
     // zeros -- the second K half of the unpaired ky 2 records -- point past num_records)
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.wp), 0, 0x7ffffff0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.wp), 0, (unsigned)((a.Cout >> 7) * nst * 8 * WG_WBLK) * 16u, 0x00020000);
     const unsigned wa_blk = (unsigned)((cgi * nst * 8 + wave_u) * WG_WBLK) * 16u;      // byte offset of this wave's block of stage 0 (host: the pack is < 2 GB)
     const unsigned wa_stage = 8u * WG_WBLK * 16u;
-    const int lane16 = lane * 16, z16 = h ? 0x7ffffff0 : li * 16;
+    const int lane16 = lane * 16, z16 = h ? (int)0x80000000 : li * 16;
     auto ldw = [&](int voff, unsigned soff) { return __builtin_amdgcn_raw_buffer_load_b128(wrs, voff, (int)soff, 0); };
     auto ldw_h8 = [&](int voff, unsigned soff) { return __builtin_bit_cast(h8, ldw(voff, soff)); };
     auto ldw_i8 = [&](int voff, unsigned s0, unsigned s1) {
@@ -285,30 +315,35 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(Conv2Args a)
     auto stage_body = [&](int st, int bufi) {
         const uint4* V = vbuf + bufi * WG_VBUF + boff;
         const unsigned W = wa_blk + (unsigned)st * wa_stage;
-        const bool more = st + 1 < nst;
         const int nxt = bufi ^ 1;
+        u32x4 rr[3];                                                  // raw patch of stage st + 2 on its way to raw[bufi] (which the pieces of stage st - 1 have finished with)
 #define WG_SB __builtin_amdgcn_sched_barrier(0)
         if constexpr (MX) {
             // steps: F(ky 0) x 2 | F(ky 1) x 2 | E(ky0 | ky1) x 4 | F(ky 2) x 2 | E(ky2 | zero) x 4;  F = f16 hi * hi on two N tiles, E = fp8 cross products on one
-            h8 bf[2][2], ak2[2];
-            i8v b8[2], a8p0[2], a8p1[2];
+            h8 bf[WG_BD + 1][2], ak2[2];
+            i8v b8[WG_BD + 1], a8p0[2], a8p1[2];
+#ifdef WG_X_NOA
+            ak2[0] = ca[0]; ak2[1] = ca[1]; a8p0[0] = a8p0[1] = a8p1[0] = a8p1[1] = (i8v){lane, li, h, 1, 2, 3, 4, 5};
+#endif
             auto rd_step = [&](int s) {                                // the B operands of step s
                 const bool isE = (s >= 4 && s < 8) || s >= 10;
                 if (!isE) {
                     const int ky = s < 4 ? s >> 1 : 2, np = s & 1;
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) bf[s & 1][j] = ld_h8(V + h * WG_VPLANE + (4 * (2 * np + j) + ky) * 8);
+                    for (int j = 0; j < 2; ++j) bf[s % (WG_BD + 1)][j] = ld_h8(V + h * WG_VPLANE + (4 * (2 * np + j) + ky) * 8);
                 } else {
                     const int nt = s < 8 ? s - 4 : s - 10;
                     const int kyh = s < 8 ? h : 2;                    // kernel row of this lane half
-                    b8[s & 1] = ld_i8(V + 2 * WG_VPLANE + (4 * nt + kyh) * 8, V + 3 * WG_VPLANE + (4 * nt + kyh) * 8);
+                    b8[s % (WG_BD + 1)] = ld_i8(V + 2 * WG_VPLANE + (4 * nt + kyh) * 8, V + 3 * WG_VPLANE + (4 * nt + kyh) * 8);
                 }
             };
-            rd_step(0);
+#pragma unroll
+            for (int s = 0; s < WG_BD; ++s) rd_step(s);
 #pragma unroll
             for (int s = 0; s < 14; ++s) {
                 WG_SB;
-                if (s + 1 < 14) rd_step(s + 1);
+                if (s + WG_BD < 14) rd_step(s + WG_BD);
+#ifndef WG_X_NOA
                 if (s == 0) {
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) a8p0[mt] = ldw_i8(lane16, W + (384 + (mt * 2 + 0) * 64) * 16, W + (384 + (mt * 2 + 1) * 64) * 16);
@@ -322,9 +357,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(Conv2Args a)
                     for (int mt = 0; mt < 2; ++mt)                    // ky 2 alone in its pair: lanes h = 1 (the second K half) read zeros (out of range)
                         a8p1[mt] = ldw_i8(z16, W + (640 + (mt * 2 + 0) * 32) * 16, W + (640 + (mt * 2 + 1) * 32) * 16);
                 }
-                if (s == 10 && more) load_a_carried(st + 1);
-                if (s < 6 && more) tp_load(nxt, s);
-                WG_SB;
+                if (s == 10) load_a_carried(min(st + 1, nst - 1));      // (last stage: loads its own operands again, unused)
+#endif
+#ifndef WG_X_NORAW
+                if (s == WG_RL) raw_load(min(st + 2, nst - 1), rr);
+                if (s == WG_RS) raw_store(rbuf + bufi * WG_RSTRIDE, rr);
+#endif
+#ifndef WG_X_NOPIECE
+                if (s < 6 && !(s & 1)) tp_load(nxt, s >> 1);
+#endif
                 const bool isE = (s >= 4 && s < 8) || s >= 10;
                 if (!isE) {
                     const int np = s & 1;
@@ -333,16 +374,30 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(Conv2Args a)
 #pragma unroll
                         for (int mt = 0; mt < 2; ++mt) {
                             const h8 A = s < 2 ? ca[mt] : (s < 4 ? cb[mt] : ak2[mt]);
-                            acc[mt][2 * np + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, bf[s & 1][j], acc[mt][2 * np + j], 0, 0, 0);
+                            acc[mt][2 * np + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A, bf[s % (WG_BD + 1)][j], acc[mt][2 * np + j], 0, 0, 0);
                         }
                 } else {
                     const int nt = s < 8 ? s - 4 : s - 10;
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(s < 8 ? a8p0[mt] : a8p1[mt], b8[s & 1], acc[mt][nt], 0, kMxFmtB, 0, kMxScaleA, 0, kMxScaleB);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(s < 8 ? a8p0[mt] : a8p1[mt], b8[s % (WG_BD + 1)], acc[mt][nt], 0, kMxFmtB, 0, kMxScaleA, 0, kMxScaleB);
                 }
-                WG_SB;
-                if (s < 6 && more) tp_compute(nxt, s);
+#ifndef WG_X_NOPIECE
+                if (s >= WG_PD && s < 6 + WG_PD && ((s - WG_PD) & 1) == 0) tp_compute(nxt, (s - WG_PD) >> 1);
+#endif
+#ifndef WG_X_NOSGB
+                // order inside the step: LDS reads and global loads first, then the VALU work of the piece spread between the MFMAs, LDS writes last
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
+                if (!isE) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 19, 0); }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 38, 0); }
+                }
+                __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);
+#endif
             }
             WG_SB;
         } else {
@@ -366,9 +421,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(Conv2Args a)
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) { ah2[mt] = ldw_h8(lane16, W + (((2 * 2 + mt) * 2 + 0) * 64) * 16); al2[mt] = ldw_h8(lane16, W + (((2 * 2 + mt) * 2 + 1) * 64) * 16); }
                 }
-                if (s == 8 && more) load_a_carried(st + 1);
-                if (s < 6 && more) tp_load(nxt, s);
-                WG_SB;
+                if (s == 8) load_a_carried(min(st + 1, nst - 1));
+                if (s == 6) raw_load(min(st + 2, nst - 1), rr);
+                if (s == 10) raw_store(rbuf + bufi * WG_RSTRIDE, rr);
+                if (s < 6 && !(s & 1)) tp_load(nxt, s >> 1);
                 const int ky = s >> 2, nt = s & 3;
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
@@ -377,8 +433,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(Conv2Args a)
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, bl[s & 1], acc[mt][nt], 0, 0, 0);
                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, bh[s & 1], acc[mt][nt], 0, 0, 0);
                 }
-                WG_SB;
-                if (s < 6 && more) tp_compute(nxt, s);
+                if (s >= WG_PD && s < 6 + WG_PD && ((s - WG_PD) & 1) == 0) tp_compute(nxt, (s - WG_PD) >> 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 13, 0); }
+                __builtin_amdgcn_sched_group_barrier(0x200, 4, 0);
             }
             WG_SB;
         }
@@ -387,10 +447,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(Conv2Args a)
 
     R3D_STAMP_DECL;
     // ---- prologue: raw(0), raw(1) -> LDS; first-half operands of stage 0; V(0)
-    dma_raw(0, rbuf);
-    if (nst > 1) dma_raw(1, rbuf + WG_RSTRIDE);
-    load_a_carried(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    {
+        u32x4 r0[3], r1[3];
+        raw_load(0, r0);
+        if (nst > 1) raw_load(1, r1);
+        load_a_carried(0);
+        raw_store(rbuf, r0);
+        if (nst > 1) raw_store(rbuf + WG_RSTRIDE, r1);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     transform(0);
@@ -401,12 +466,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_f16x3_kernel(Conv2Args a)
     R3D_STAMP(4);
     for (int st = 0; st < nst; ++st) {
         const int cur = st & 1;
-        // raw(st + 2) -> the buffer transform(st) has finished with; issued while nothing this wave will wait for with a counted vmcnt is in flight
-        if (st + 2 < nst) dma_raw(st + 2, rbuf + cur * WG_RSTRIDE);
         stage_body(st, cur);
         R3D_STAMP(5);
-        // V(st + 1) written, raw(st + 2) landed, this wave's reads of V(st) / raw(st + 1) complete -> everybody's
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // V(st + 1) and raw(st + 2) written, this wave's reads of V(st) / raw(st + 1) complete -> everybody's (the carried weight loads stay in flight)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         R3D_STAMP(7);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
