@@ -922,6 +922,20 @@ def main():
         if ref is not None:
             out["cpu_baseline_reference"] = ref
     if rank == 0:
+        # the driver keeps `roofline` and `config` verbatim and drops the other extras, so the per-kernel record of ITS box rides inside them
+        rf = out["roofline"]
+        for k in ("breakdown_ms_per_frame", "render_kernel", "value_single_stream", "stream_pipelining_gain", "value_cold_start"):
+            if k in out:
+                rf[k] = out[k]
+        if "value_synthesis_api" in out:
+            api_o = out["value_synthesis_api"]
+            rf["value_synthesis_api"] = dict({api_o["precision"]: api_o["value"]}, **{p_: v_["value"] for p_, v_ in api_o.get("other_precisions", {}).items()})
+        if "alt_f16x3" in out:
+            rf["alt_f16x3"] = out["alt_f16x3"].get("value") if isinstance(out["alt_f16x3"], dict) else out["alt_f16x3"]
+        if "repeats" in out:
+            out["config"]["value_is"] = "the FIRST of five back-to-back timed regions (the driver's protocol); their median: %.1f frames/s (min %.1f, max %.1f)" % (
+                out["repeats"]["median"], out["repeats"]["min"], out["repeats"]["max"])
+            out["config"]["value_median_of_5"] = out["repeats"]["median"]
         print(json.dumps(out))
     if use_dist:
         dist.barrier()

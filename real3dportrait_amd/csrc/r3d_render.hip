@@ -1569,12 +1569,22 @@ extern "C" int r3d_raygen(const float* c2w, const float* intrinsics, int N, int 
     return check_launch("raygen");
 }
 
+// The grid r3d_render_forward launches for nrays rays, and whether the shape it dispatches parks a ray's colours in the workspace (one helper for the size
+// query and the launch, so that the two cannot drift apart; ADVICE r5: the query used to add a fixed 48 MB whenever Nc or Nf exceeded 48, also for Nf = 0
+// -- <4,0> / <6,0> never park -- and for small launches whose grid is a fraction of kMaxGrid).
+static int render_grid(size_t nrays)
+{
+    const size_t max_blocks = ((nrays + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8;
+    return max_blocks < (size_t)kMaxGrid ? (int)max_blocks : kMaxGrid;
+}
+static bool render_parks(int Nc, int Nf) { return ((Nc > 48 || Nf > 48) && Nf > 0) || R3D_RENDER_GPARK_ALL; }
+// per wave of the grid: 2 (NTC + NTF) tiles of 64 f32x4; 24 covers <6,6> and its tri-grid twin (a tri-grid call with 49..64 samples runs <6,6> too)
+static size_t render_park_bytes(size_t nrays, int Nc, int Nf) { return render_parks(Nc, Nf) ? (size_t)render_grid(nrays) * kWavesPerBlock * 24 * 64 * sizeof(f32x4) : 0; }
+
 extern "C" size_t r3d_render_workspace_bytes(int N, int M, int Nc, int Nf)
 {
     const size_t nrays = (size_t)N * M;
-    // + the colour parking of the shapes with more than 3 tiles per pass (Nc or Nf above 48: <4,4>, <6,6> and their tri-grid twins): 512 blocks x 4 waves x 2 * (6 + 6) tiles x 1 KB = 50 MB
-    const size_t park = (Nc > 48 || Nf > 48 || R3D_RENDER_GPARK_ALL) ? (size_t)kMaxGrid * kWavesPerBlock * 24 * 64 * sizeof(f32x4) : 0;
-    return render_state_bytes(nrays) + 2 * nrays * sizeof(float) + 64 + kFoldBytes + park;
+    return render_state_bytes(nrays) + 2 * nrays * sizeof(float) + 64 + kFoldBytes + render_park_bytes(nrays, Nc, Nf);
 }
 
 extern "C" size_t r3d_run_model_workspace_bytes(void) { return kFoldBytes; }
@@ -1640,13 +1650,11 @@ extern "C" int r3d_render_forward(const float* planes_nhwc, int N, int H, int W,
     a.noise_c = noise_c; a.u_f = u_f; a.seed = seed;
     a.rgb = rgb; a.depth = depth; a.wsum = wsum; a.rgb_cm = rgb_channel_major ? 1 : 0;
     a.clk = prof_clock_slot(R3D_PROF_RENDER);
-    a.park_g = (Nc > 48 || Nf > 48 || R3D_RENDER_GPARK_ALL) ? park_g : nullptr;      // (exactly the calls the dispatch below sends to a shape with more than 3 coarse tiles)
+    a.park_g = render_parks(Nc, Nf) ? park_g : nullptr;      // (exactly the calls the dispatch below sends to a parking shape: launch_render_big / the tri-grid <6,6>)
 
     // (R computed above: square image -> XCD strip order; otherwise linear order)
     const int waves_needed = nrays;
-    int grid = kMaxGrid;                              // 2 blocks per CU on 256 CUs, multiple of 8 (XCD strips)
-    const int max_blocks = ((waves_needed + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8 * 8;
-    if (grid > max_blocks) grid = max_blocks;
+    const int grid = render_grid((size_t)waves_needed);      // <= 2 blocks per CU on 256 CUs, multiple of 8 (XCD strips)
 
     const int ntc = (Nc + 15) / 16, ntf = (Nf + 15) / 16;
     {

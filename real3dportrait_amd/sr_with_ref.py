@@ -252,6 +252,7 @@ def _forward_v2(self, S, rgb, x, ws, ref_torso_rgb, ref_bg_rgb, weights_img, seg
     return rgb_out, ret
 
 
+@torch.no_grad()
 def infer_forward_stage1(self, rgb, x, ws, ref_torso_rgb, ref_bg_rgb, weights_img, segmap, kp_s, kp_d, **block_kwargs):
     """sr_with_ref.py:164-188 (the reference's two-stage entry, unused by real3d_infer.py): block0 + the warp network's first stage; returns
     the dict the second stage continues from (keys as the reference: the torso model's own + 'ref_bg_rgb_256', 'weights_256', 'x', 'ws',
@@ -280,6 +281,7 @@ def infer_forward_stage1(self, rgb, x, ws, ref_torso_rgb, ref_bg_rgb, weights_im
     return ret
 
 
+@torch.no_grad()
 def infer_forward_stage2(self, facev2v_ret, **block_kwargs):
     """sr_with_ref.py:190-218: the warp network's second stage, the alpha / occlusion blends, fuse_fg_bg_convs, block1 -> (rgb, ret).
     (This entry blends x and x_torso directly -- no fuse_head_torso_convs / head_torso_block -- and thresholds the head mask at 0.5.)"""
@@ -312,7 +314,8 @@ def infer_forward_stage2(self, facev2v_ret, **block_kwargs):
 
 
 class SuperresolutionHybrid8XDC_Warp(torch.nn.Module):
-    """Mirror of the reference class (sr_with_ref.py:16-63) for the shipped configuration (weight_fuse, fuse mode 'v2'): same
+    """Mirror of the reference class (sr_with_ref.py:16-63) for weight_fuse=True with fuse mode 'v2' (the shipped configuration; fused forward) or 'v1'
+    (operator by operator; like the reference it then has no head_torso_alpha_predictor / fuse_head_torso_convs / head_torso_block): same
     attribute names and state_dict keys for everything except `torso_model`, which is PASSED IN (the reference's face-vid2vid
     network, any module with its forward signature); forward = the fused HIP evaluation above.  `patch_model` does not need this
     class (it converts a constructed reference module in place); it serves callers that build the pipeline without the reference."""
@@ -334,12 +337,14 @@ class SuperresolutionHybrid8XDC_Warp(torch.nn.Module):
         self.torso_encoder = ConvStack(Conv2d(64, 256, 1, 1, padding=0))
         self.bg_encoder = ConvStack(Conv2d(3, 64, 3, 1, padding=1), lrelu(), Conv2d(64, 256, 3, 1, padding=1), lrelu(),
                                     Conv2d(256, 256, 3, 1, padding=1))
-        # unused by fuse mode v2, kept (plain torch) so that a reference checkpoint loads strict=True (sr_with_ref.py:41-48)
-        self.head_torso_alpha_predictor = nn.Sequential(nn.Conv2d(3 + 1 + 3, 32, 3, 1, padding=1), lrelu(), nn.Conv2d(32, 32, 3, 1, padding=1),
-                                                        lrelu(), nn.Conv2d(32, 1, 3, 1, padding=1), nn.Sigmoid())
-        self.fuse_head_torso_convs = ConvStack(Conv2d(512, 256, 3, 1, padding=1), lrelu(), Conv2d(256, 256, 3, 1, padding=1))
-        self.head_torso_block = SynthesisBlockNoUp(256, 256, w_dim=512, resolution=256, img_channels=3, is_last=False, use_fp16=False,
-                                                   conv_clamp=None, **block_kwargs)
+        if hp.get("weight_fuse", True) and hp.get("htbsr_head_weight_fuse_mode") != "v1":
+            # the reference builds these three for every fuse mode except v1 (sr_with_ref.py:36-54): a v1 checkpoint has no such keys and must load strict=True.
+            # head_torso_alpha_predictor is unused by fuse mode v2 and stays plain torch.
+            self.head_torso_alpha_predictor = nn.Sequential(nn.Conv2d(3 + 1 + 3, 32, 3, 1, padding=1), lrelu(), nn.Conv2d(32, 32, 3, 1, padding=1),
+                                                            lrelu(), nn.Conv2d(32, 1, 3, 1, padding=1), nn.Sigmoid())
+            self.fuse_head_torso_convs = ConvStack(Conv2d(512, 256, 3, 1, padding=1), lrelu(), Conv2d(256, 256, 3, 1, padding=1))
+            self.head_torso_block = SynthesisBlockNoUp(256, 256, w_dim=512, resolution=256, img_channels=3, is_last=False, use_fp16=False,
+                                                       conv_clamp=None, **block_kwargs)
         self.fuse_fg_bg_convs = ConvStack(Conv2d(512, 64, 1, 1, padding=0), lrelu(), Conv2d(64, 256, 3, 1, padding=1), lrelu(),
                                           Conv2d(256, 256, 3, 1, padding=1))
         self._r3d_state = WarpSRState(hp)

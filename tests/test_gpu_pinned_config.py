@@ -196,8 +196,10 @@ SPIKES = [6, 10, 14]
 # so the typical outputs no longer depend on how far the tensor's bound sits above them.  Until round 4 the records were e4m3 with one exponent
 # per tensor and went subnormal from max / rms = 2^10 on (far 1.6e-4 at 2^10, 3.6e-4 at 2^14: asserted 1e-3 then, and the reason 'f16mx' was
 # not the library default); profiles/r05/mx_format_model.txt is the numpy model of both formats, `make EXTRA=-DR3D_MX_ACT_E4M3=1` the A/B build.
-_TIER = {"f16x3": 2e-5, "f16mx": SR_TOL}
-_TIER_FAR = {("f16x3", 6): 2e-5, ("f16x3", 10): 2e-5, ("f16x3", 14): 2e-5, ("f16mx", 6): SR_TOL, ("f16mx", 10): SR_TOL, ("f16mx", 14): SR_TOL}
+# Round 6: the f16mx tiers are asserted at 1e-4 near / 5e-5 far instead of at the stated tolerance itself (measured 6.3e-5 / 2.5e-5
+# in round 5: a 3 x regression would have passed unnoticed).  The far figure only means something where a spike has a far field (`where == "input"`).
+_TIER = {"f16x3": 2e-5, "f16mx": 1e-4}
+_TIER_FAR = {("f16x3", 6): 2e-5, ("f16x3", 10): 2e-5, ("f16x3", 14): 2e-5, ("f16mx", 6): 5e-5, ("f16mx", 10): 5e-5, ("f16mx", 14): 5e-5}
 
 
 def _far_mask(shape_hw, centers, radius):
@@ -256,7 +258,38 @@ def test_sr_block_heavy_tail(torch_cuda, precision, k, where):
     else:
         fx, fi = ex, ei
     print("SR block heavy tail [%s] %s 2^%d: x %.2e (far %.2e), img %.2e (far %.2e) of max|ref|" % (precision, where, k, ex, fx, ei, fi))
-    assert max(ex, ei) <= _TIER[precision] and max(fx, fi) <= _TIER_FAR[(precision, k)], (precision, where, k, ex, fx, ei, fi)
+    far_tier = _TIER_FAR[(precision, k)] if where == "input" else _TIER[precision]
+    assert max(ex, ei) <= _TIER[precision] and max(fx, fi) <= far_tier, (precision, where, k, ex, fx, ei, fi)
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_sr_block_dense_heavy_tail(torch_cuda, precision):
+    """The case the e5m2 records are weakest on: a DENSE heavy tail -- every element log-normal with sigma = 4 (the 16-channel group
+    of every pixel spans > 2^10 in magnitude, the tensor > 2^30), random signs -- through a SynthesisBlock, vs float64.  No far field here: every output
+    sees large and small operands alike."""
+    torch = torch_cuda
+    from real3dportrait_amd import synth
+    from real3dportrait_amd.superresolution import SynthesisBlock
+    N, Cin, Cout, H, W = 1, 32, 128, 24, 20
+    p = {kk: tuple(np.array(a) for a in v) for kk, v in synth.synth_sr_block(95, Cin, Cout, 512, 710).items()}
+    g = synth.hash_unitvar(96, (N, Cin, H, W), stream=1).astype(np.float64)
+    sg = np.sign(synth.hash_unitvar(96, (N, Cin, H, W), stream=2)).astype(np.float64)
+    x = (sg * np.exp(4.0 * g)).astype(np.float32)
+    span = np.log2(np.abs(x).reshape(N, Cin // 16, 16, H * W).max(2) / np.abs(x).reshape(N, Cin // 16, 16, H * W).min(2))
+    assert np.median(span) >= 10.0, np.median(span)
+    img = synth.hash_unitvar(96, (N, 3, H, W), stream=3) * np.float32(0.5)
+    ws = np.ones((N, 3, 512), np.float32)
+    blk = SynthesisBlock(Cin, Cout, w_dim=512, resolution=2 * H, img_channels=3, is_last=False, conv_clamp=None).cuda()
+    load_block(torch, blk, p)
+    blk.precision = precision
+    xo, io = blk(T(torch, x), T(torch, img), T(torch, ws), noise_mode="none")
+    rx, ri = _block_fp64(torch, p, torch.from_numpy(x), torch.from_numpy(img), torch.from_numpy(ws), True, None)
+    assert torch.isfinite(xo).all() and torch.isfinite(io).all()
+    ex = float((xo.cpu().double() - rx).abs().max() / rx.abs().max()); ei = float((io.cpu().double() - ri).abs().max() / ri.abs().max())
+    # the typical output (median |ref|) against the typical error: the figure a uniform bound / max comparison hides
+    med = float((xo.cpu().double() - rx).abs().median() / rx.abs().median())
+    print("SR block dense heavy tail [%s] (median group span 2^%.1f): x %.2e img %.2e of max|ref|; median error / median |ref| %.2e" % (precision, np.median(span), ex, ei, med))
+    assert max(ex, ei) <= _TIER[precision], (precision, ex, ei)
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -307,7 +340,7 @@ def test_conv_stack_heavy_tail(torch_cuda, k, where, precision):
     else:
         # e5m2 activation records (round 5): the far-field no longer depends on the spike (round 4, e4m3 with one exponent per tensor: 2.3e-4 at a
         # spike of 2^10 sigma, 3.6e-4 at 2^14 -- the third conv's operand is two propagated bounds, ~10 binades, from the measured input on top of it)
-        assert e <= SR_TOL and f <= SR_TOL, (where, k, e, f)
+        assert e <= 1e-4 and f <= (5e-5 if where == "input" else 1e-4), (where, k, e, f)
 
 
 @pytest.mark.parametrize("k", SPIKES)
