@@ -287,6 +287,9 @@ struct Conv2Args {
 // round 1 measured); from LDS the loop has no global loads, so its stores stream out back to back.
 // The caller has passed a __syncthreads() after its last LDS read; `ev` may alias the main loop's buffers.
 static constexpr int EV_STRIDE = BLOCK_M;              // floats per staged vector
+#ifndef R3D_EPI_WIDE
+#define R3D_EPI_WIDE 1        // A/B switch: 0 = the 8-byte SPLIT stores of rounds 1-5 (same values, same bytes)
+#endif
 // PIXMAP = 1 (experiment): acc[mt][nt] holds column parity nt of the column pairs -- lane li <-> (row 4 wn + li / 8, columns 2 (li % 8) + nt).
 // PIXMAP != 0 (conv_wino_f16x3_kernel): the accumulators carry the transformed operands' factor 1/4 (r3d_sr_wino.h); 2 = the ordinary pixel map.
 template <bool FULL_EPI, int WN, int NT, int PIXMAP = 0>
@@ -358,6 +361,10 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
             const float4 w1 = *reinterpret_cast<const float4*>(ev + 4 * EV_STRIDE + cl);
             const float4 w2 = *reinterpret_cast<const float4*>(ev + 5 * EV_STRIDE + cl);
             const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w}, sv[4] = {s4.x, s4.y, s4.z, s4.w};
+#if R3D_EPI_WIDE
+            uint2 hiw[NT], low[NT];
+            unsigned xh8w[NT], xl8w[NT];
+#endif
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const bool inside = inside_nt[nt];
@@ -378,7 +385,7 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
                     rgbp[nt][1] = __builtin_fmaf(v[3], w1.w, __builtin_fmaf(v[2], w1.z, __builtin_fmaf(v[1], w1.y, __builtin_fmaf(v[0], w1.x, rgbp[nt][1]))));
                     rgbp[nt][2] = __builtin_fmaf(v[3], w2.w, __builtin_fmaf(v[2], w2.z, __builtin_fmaf(v[1], w2.y, __builtin_fmaf(v[0], w2.x, rgbp[nt][2]))));
                 }
-                if (!inside) continue;
+                if (inside) {
                 if (want_max) vmax = fmaxf(vmax, fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))));
                 const unsigned pix = pbase + p0[nt];
                 if (Yf) *reinterpret_cast<float4*>(Yf + (size_t)pix * 8 + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
@@ -386,6 +393,7 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
                     float* yn = Yn + (size_t)(unsigned)(m0 + cu) * cs + (size_t)((unsigned)(4 * h) * cs + p0[nt]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) yn[(size_t)r * cs] = v[r];
+                }
                 }
                 if (Ys) {
                     h4 hi, lo;
@@ -397,6 +405,17 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
                         lf[r] = sv_ - (float)x0;
                         hi[r] = x0; lo[r] = (_Float16)lf[r];
                     }
+#if R3D_EPI_WIDE
+                    // 16-byte stores (round 6): the two lane halves hold the two 8-byte halves of a pixel's 16-byte word; the values wait for the N-tile
+                    // pair's v_permlane32_swap below (the `inside` test moves to the store)
+                    hiw[nt] = *reinterpret_cast<uint2*>(&hi);
+                    if (a.y_split_mx) {
+                        xh8w[nt] = pack4_x8((float)hi[0] * kMxXh, (float)hi[1] * kMxXh, (float)hi[2] * kMxXh, (float)hi[3] * kMxXh);
+                        xl8w[nt] = pack4_x8(lf[0] * kMxXl, lf[1] * kMxXl, lf[2] * kMxXl, lf[3] * kMxXl);
+                    } else low[nt] = *reinterpret_cast<uint2*>(&lo);
+#else
+                    if (!inside) continue;
+                    const unsigned pix = pbase + p0[nt];
                     uint2* dst = reinterpret_cast<uint2*>(Ys + pix) + h;
                     dst[0] = *reinterpret_cast<uint2*>(&hi);
                     if (a.y_split_mx) {
@@ -414,8 +433,39 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
                     } else {
                         dst[2 * oplane] = *reinterpret_cast<uint2*>(&lo);
                     }
+#endif
                 }
             }
+#if R3D_EPI_WIDE
+            if (Ys) {
+                // N tiles (nt, nt + 1) = two pixels per lane: lane half h = 0 hands its nt + 1 values to its partner (lane + 32) and receives the partner's nt
+                // values -- v_permlane32_swap: new a = {a[0..31], b[0..31]}, new b = {a[32..63], b[32..63]} -- so every lane holds all 8 couts of ONE pixel
+                // (nt + h) and stores 16 bytes: half the store instructions, whole 16-byte words (the epilogue's store tail is issue bound; same bytes, same values)
+                const unsigned c8 = (unsigned)(m0 + cu) >> 3;
+#pragma unroll
+                for (int nt = 0; nt < NT; nt += 2) {
+                    const bool ins = h ? inside_nt[nt + 1] : inside_nt[nt];
+                    const unsigned pp = h ? p0[nt + 1] : p0[nt];
+                    auto swp = [](unsigned x, unsigned y, unsigned& ox, unsigned& oy) { const auto r = __builtin_amdgcn_permlane32_swap(x, y, false, false); ox = r[0]; oy = r[1]; };
+                    uint4 w;
+                    swp(hiw[nt].x, hiw[nt + 1].x, w.x, w.z); swp(hiw[nt].y, hiw[nt + 1].y, w.y, w.w);
+                    if (ins) Ys[pbase + pp] = w;
+                    if (a.y_split_mx) {
+                        if (!(c8 & 1u)) { rec_h[nt] = xh8w[nt]; rec_l[nt] = xl8w[nt]; rec_h[nt + 1] = xh8w[nt + 1]; rec_l[nt + 1] = xl8w[nt + 1]; }   // (g even: wait for the group's other chunk)
+                        else {
+                            uint4 rh, rl;                              // record dwords (2 h, 2 h + 1) = (even chunk, odd chunk) of this lane half's 4 couts
+                            swp(rec_h[nt], rec_h[nt + 1], rh.x, rh.z); swp(xh8w[nt], xh8w[nt + 1], rh.y, rh.w);
+                            swp(rec_l[nt], rec_l[nt + 1], rl.x, rl.z); swp(xl8w[nt], xl8w[nt + 1], rl.y, rl.w);
+                            uint4* rec = Ys + oplane + (size_t)((c8 & ~1u) * cs + pp);
+                            if (ins) { rec[0] = rh; rec[cs] = rl; }
+                        }
+                    } else {
+                        swp(low[nt].x, low[nt + 1].x, w.x, w.z); swp(low[nt].y, low[nt + 1].y, w.y, w.w);
+                        if (ins) Ys[oplane + pbase + pp] = w;
+                    }
+                }
+            }
+#endif
         }
     if (want_max) {
         // one atomic per BLOCK (the staged vectors in `ev` are no longer read): atomics on one word serialise in L2 at ~12 ns each, and
