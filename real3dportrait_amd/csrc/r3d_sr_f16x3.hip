@@ -361,10 +361,9 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
             const float4 w1 = *reinterpret_cast<const float4*>(ev + 4 * EV_STRIDE + cl);
             const float4 w2 = *reinterpret_cast<const float4*>(ev + 5 * EV_STRIDE + cl);
             const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w}, sv[4] = {s4.x, s4.y, s4.z, s4.w};
-#if R3D_EPI_WIDE
+            constexpr bool WIDE = R3D_EPI_WIDE && (NT % 2 == 0);    // (the 8-row tiles have one N tile per wave: 8-byte stores)
             uint2 hiw[NT], low[NT];
             unsigned xh8w[NT], xl8w[NT];
-#endif
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const bool inside = inside_nt[nt];
@@ -405,7 +404,7 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
                         lf[r] = sv_ - (float)x0;
                         hi[r] = x0; lo[r] = (_Float16)lf[r];
                     }
-#if R3D_EPI_WIDE
+                    if constexpr (WIDE) {
                     // 16-byte stores (round 6): the two lane halves hold the two 8-byte halves of a pixel's 16-byte word; the values wait for the N-tile
                     // pair's v_permlane32_swap below (the `inside` test moves to the store)
                     hiw[nt] = *reinterpret_cast<uint2*>(&hi);
@@ -413,7 +412,7 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
                         xh8w[nt] = pack4_x8((float)hi[0] * kMxXh, (float)hi[1] * kMxXh, (float)hi[2] * kMxXh, (float)hi[3] * kMxXh);
                         xl8w[nt] = pack4_x8(lf[0] * kMxXl, lf[1] * kMxXl, lf[2] * kMxXl, lf[3] * kMxXl);
                     } else low[nt] = *reinterpret_cast<uint2*>(&lo);
-#else
+                    } else {
                     if (!inside) continue;
                     const unsigned pix = pbase + p0[nt];
                     uint2* dst = reinterpret_cast<uint2*>(Ys + pix) + h;
@@ -433,11 +432,10 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
                     } else {
                         dst[2 * oplane] = *reinterpret_cast<uint2*>(&lo);
                     }
-#endif
+                    }
                 }
             }
-#if R3D_EPI_WIDE
-            if (Ys) {
+            if constexpr (WIDE) if (Ys) {
                 // N tiles (nt, nt + 1) = two pixels per lane: lane half h = 0 hands its nt + 1 values to its partner (lane + 32) and receives the partner's nt
                 // values -- v_permlane32_swap: new a = {a[0..31], b[0..31]}, new b = {a[32..63], b[32..63]} -- so every lane holds all 8 couts of ONE pixel
                 // (nt + h) and stores 16 bytes: half the store instructions, whole 16-byte words (the epilogue's store tail is issue bound; same bytes, same values)
@@ -465,7 +463,6 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
                     }
                 }
             }
-#endif
         }
     if (want_max) {
         // one atomic per BLOCK (the staged vectors in `ev` are no longer read): atomics on one word serialise in L2 at ~12 ns each, and

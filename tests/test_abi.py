@@ -108,16 +108,18 @@ def test_product_has_no_oracle_dependency():
 
 
 def test_render_workspace_grows_for_the_shapes_that_park_colours():
-    """r3d_render_workspace_bytes: per-ray limits + the fold record, plus -- when Nc or Nf exceeds 48, i.e. the kernel shapes with more than three
-    16-sample tiles per pass -- 512 blocks x 4 waves x 2 (6 + 6) tiles x 1 KB in which a wave parks its ray's colours (round 5)."""
+    """r3d_render_workspace_bytes: per-ray limits + the fold record, plus -- when Nc or Nf exceeds 48 AND there is a fine pass, i.e. the kernel shapes that
+    park a ray's colours -- grid x 4 waves x 2 (6 + 6) tiles x 1 KB, with the grid the launch really uses (round 6, ADVICE r5: a fixed 48 MB before)."""
     from real3dportrait_amd import _lib
     lib = _lib.load()
     base = lib.r3d_render_workspace_bytes(1, 128 * 128, 48, 48)
-    park = 512 * 4 * 24 * 64 * 16
+    park = 512 * 4 * 24 * 64 * 16                                                       # 16 384 rays = 4 096 blocks of 4 waves: the grid is capped at 512
     assert lib.r3d_render_workspace_bytes(1, 128 * 128, 96, 96) == base + park
     assert lib.r3d_render_workspace_bytes(1, 128 * 128, 40, 60) == base + park          # <4,4> is dispatched for Nf > 48 too
-    assert lib.r3d_render_workspace_bytes(1, 128 * 128, 96, 0) == base + park           # (a coarse-only 96-sample call does not use it; the size is a bound)
+    assert lib.r3d_render_workspace_bytes(1, 128 * 128, 96, 0) == base                  # a coarse-only call never parks (<6,0>)
     assert lib.r3d_render_workspace_bytes(1, 128 * 128, 16, 16) == base
+    small = lib.r3d_render_workspace_bytes(1, 32 * 32, 96, 96) - lib.r3d_render_workspace_bytes(1, 32 * 32, 48, 48)
+    assert small == 256 * 4 * 24 * 64 * 16                                              # 1 024 rays = 256 blocks: half the parking of a full grid
 
 
 def test_no_hazardous_packed_f32_forms(tmp_path):
