@@ -96,8 +96,9 @@ int r3d_raygen(const float* c2w, const float* intrinsics, int N, int R,
  *                split has no saturation guard, so a stale or too small bound yields inf / NaN, not a clamp.  Pass NULL whenever the
  *                planes were modified after the partials were written (the Python operator does: it ties them to the tensor version).
  *   workspace    r3d_render_workspace_bytes() bytes of device scratch, 64-byte aligned.  Per-ray limits and the decoder's fold record; when Nc or Nf
- *                exceeds 48 (the kernel shapes with more than three 16-sample tiles per pass) also 48 MB in which every wave of the launch parks
- *                the colours of the ray it is rendering between the decode and the composite (ABI 0.5.0: they do not fit the register file).
+ *                exceeds 48 AND Nf > 0 (the kernel shapes with more than three 16-sample tiles per pass and a fine pass) also 24 KB per wave of the
+ *                launch's grid (min(512, rays / 4 rounded up to 8) blocks x 4 waves: 48 MB for a full grid), in which a wave parks the colours of the
+ *                ray it is rendering between the decode and the composite (ABI 0.5.0: they do not fit the register file; 0.6.0: sized from the grid).
  */
 size_t r3d_render_workspace_bytes(int N, int M, int Nc, int Nf);
 int r3d_render_forward(const float* planes_nhwc, int N, int H, int W, int triplane_depth,
@@ -179,7 +180,12 @@ size_t r3d_run_model_workspace_bytes(void);
  *                         the path, <= 1e-4 over the 2^-20..2^14 operand sweeps vs fp64 (tests/test_gpu_mx.py, tests/test_gpu_pinned_config.py).
  *                         The records have the hi plane's exponent range: no measured bound is needed beyond what R3D_SR_F16X3 needs
  *                         (R3D_CHAIN_SR_BLOCK_TAIL stays available for chains deeper than three layers).
- *            The prepacked buffer is precision-specific (same size). */
+ *            The prepacked buffer is precision-specific (same size).
+ *            Algorithm (ABI 0.6.0): the block's plain 3x3 conv (conv1) has a second implementation, Winograd F(2,3) along x with the input transform in
+ *            the kernel (csrc/r3d_sr_wino.h: 12 instead of 18 matrix products per pair of output columns; the prepacked buffer carries the 12
+ *            transformed tap matrices).  It is taken for R3D_SR_F16X3 when the output is whole 16 x 16 tiles (-13 % per launch, fp32-class:
+ *            error x 1.4 of the direct form's 7e-8); for R3D_SR_F16MX the direct kernel is faster and stays.  Process-wide switch:
+ *            R3D_CONV_WINO = 0 (never) | 1 (both precisions) | 2 (f16mx only) | 3 (f16x3 only, the default). */
 enum r3d_sr_precision { R3D_SR_F32 = 0, R3D_SR_F16X3 = 1, R3D_SR_F16MX = 2 };
 enum r3d_act_format { R3D_FMT_NONE = -1, R3D_FMT_NCHW = 0, R3D_FMT_CB8 = 1, R3D_FMT_SPLIT = 2, R3D_FMT_SPLIT_MX = 3 };
 size_t r3d_sr_block_prepacked_bytes(int Cin, int Cout);

@@ -76,7 +76,7 @@ class ChainOp(ctypes.Structure):
 
 CHAIN_SR_BLOCK, CHAIN_CONV, CHAIN_SR_BLOCK_TAIL, CHAIN_SRC_NONE, CHAIN_MAX_OPS, CHAIN_MAX_EXT, CHAIN_MAX_ZERO = 0, 1, 2, -1000, 12, 4, 4
 
-ABI_VERSION = 50          # r3d_version() of the library this table mirrors (include/r3d_hip.h)
+ABI_VERSION = 60          # r3d_version() of the library this table mirrors (include/r3d_hip.h)
 _lib = None
 
 
