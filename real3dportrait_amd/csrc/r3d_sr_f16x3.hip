@@ -1727,7 +1727,11 @@ int upsample2x_bilinear_f16x3(const float* x_cb8, int N, int C, int H, int W, vo
 // A/B switch of the Winograd F(2,3) conv (r3d_sr_wino.h): R3D_CONV_WINO=0 keeps every plain 3x3 conv on the direct kernels
 static int wino_mode() { static const int v = getenv("R3D_CONV_WINO") ? atoi(getenv("R3D_CONV_WINO")) : 3; return v; }   // 0 off, 1 both precisions, 2 f16mx only, 3 f16x3 only
 // ... and the shapes it takes: whole 16 x 16-pixel tiles, 16-channel stages, 128-cout blocks
-static bool wino_shape_ok(int Cin, int Cout, int H, int W) { return wino_mode() && (H & 15) == 0 && (W & 15) == 0 && (Cin & 15) == 0 && (Cout % BLOCK_M) == 0; }
+static bool wino_shape_ok(int Cin, int Cout, int H, int W)
+{
+    // (the kernel addresses one sample's SPLIT activation and the weight pack through 32-bit buffer offsets)
+    return wino_mode() && (H & 15) == 0 && (W & 15) == 0 && (Cin & 15) == 0 && (Cout % BLOCK_M) == 0 && (size_t)Cin * H * W * 4 < ((size_t)1 << 31) && (size_t)48 * Cin * Cout < ((size_t)1 << 31);
+}
 // float offset of conv1's Winograd pack inside an SR block's prepacked buffer (after everything sr_prepack_f16x3 wrote before round 6)
 static size_t sr_wino_offset(int Cin, int Cout) { return (size_t)4 * 9 * Cin * Cout + (size_t)9 * Cout * Cout + 2 * conv_tail_layout(Cout).total; }
 
@@ -1763,7 +1767,7 @@ int sr_prepack_f16x3(int Cin, int Cout, const float* c0_w, const float* c1_w, vo
     }
     {   // conv1 for conv_wino_f16x3_kernel: 12 transformed tap matrices [Cout / 128][Cout / 16][wave 8][WG_WBLK]
         const size_t mw = (size_t)(Cout >> 7) * (Cout >> 4) * 8 * 3 * 2 * 32;
-        hipLaunchKernelGGL(sr_prepack_wino_kernel, dim3((unsigned)((mw + 255) / 256)), dim3(256), 0, st, c1_w, Cout, Cout, tail1 + T.winv,
+        hipLaunchKernelGGL(sr_prepack_wino_kernel, dim3((unsigned)((mw + 255) / 256)), dim3(256), 0, st, c1_w, Cout, Cout, Cout, Cout, tail1 + T.winv,
                            reinterpret_cast<uint4*>(out + sr_wino_offset(Cin, Cout)), mx ? 1 : 0);
     }
     return check_launch("sr_block_prepack");
@@ -1952,7 +1956,8 @@ size_t conv_prepacked_bytes_f16x3(int Cin, int Cout, int ksize)
 {
     const int Co = pad_to(Cout, BLOCK_M);
     const size_t w = (size_t)(ksize * ksize) * pad_to(Cin, 16) * Co;
-    return (w + conv_tail_layout(Co).total + (ksize == 3 ? w : 0)) * sizeof(float);      // 3x3: the weights again with fp8 records (R3D_FMT_SPLIT_MX inputs)
+    // 3x3: the weights again with fp8 records (R3D_FMT_SPLIT_MX inputs) and as the 12 transformed tap matrices of the Winograd F(2,3) kernel (plain SPLIT inputs, r3d_sr_wino.h)
+    return (w + conv_tail_layout(Co).total + (ksize == 3 ? w + (size_t)12 * pad_to(Cin, 16) * Co : 0)) * sizeof(float);
 }
 
 // prepacked = split weights (rows pre-scaled by 2^kw[co]) ++ ConvTail {2^-kw[co], sum|w[co]|} ++ (3x3 only) the weights in the f16mx layout
@@ -1965,9 +1970,13 @@ int conv_prepack_f16x3(const float* w, int Cin, int Cout, int ksize, void* prepa
     hipLaunchKernelGGL(weight_row_stats_kernel, dim3(Co), dim3(256), 0, st, w, Cin * nt, Cout, Co, tail);
     hipLaunchKernelGGL(sr_prepack_f16_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, w, Cin, Cout, nt, Ci, Co,
                        tail + conv_tail_layout(Co).winv, reinterpret_cast<uint4*>(prepacked));
-    if (ksize == 3)
+    if (ksize == 3) {
         hipLaunchKernelGGL(sr_prepack_mx_kernel, dim3((unsigned)((m / 2 + 255) / 256)), dim3(256), 0, st, w, Cin, Cout, nt, Ci, Co,
                            tail + conv_tail_layout(Co).winv, reinterpret_cast<uint4*>(tail + conv_tail_layout(Co).total));
+        const size_t mw = (size_t)(Co >> 7) * (Ci >> 4) * 8 * 3 * 2 * 32;
+        hipLaunchKernelGGL(sr_prepack_wino_kernel, dim3((unsigned)((mw + 255) / 256)), dim3(256), 0, st, w, Cin, Cout, Ci, Co, tail + conv_tail_layout(Co).winv,
+                           reinterpret_cast<uint4*>(tail + conv_tail_layout(Co).total + (size_t)nt * Ci * Co), 0);      // (a plain SPLIT input: the f16x3 form)
+    }
     return check_launch("conv_prepack");
 }
 
@@ -2014,8 +2023,11 @@ int conv_forward_f16x3(const void* prepacked, const float* scales, size_t scales
         p.outH = H; p.outW = W; p.oy_mul = 1; p.oy_add = 0; p.ox_mul = 1; p.ox_add = 0; p.out_off = 0;
         p.ntaps = 1; p.dy[0] = 0; p.dx[0] = 0; p.widx[0] = 0;
     }
+    // a plain SPLIT operand (the f16x3 precision, or a producer that does not write records): Winograd F(2,3) when the shape allows it
+    const bool wino = ksize == 3 && !mx_in && wino_shape_ok(Ci, Co, H, W) && (wino_mode() == 1 || wino_mode() == 3);
+    if (wino) a.wp = reinterpret_cast<const uint4*>(reinterpret_cast<const float*>(prepacked) + (size_t)2 * 9 * Ci * Co + conv_tail_layout(Co).total);
     ProfScope ps(R3D_PROF_CONV, st);
-    launch_conv2(a, tiles_of(H, W), N, st, mx_in);
+    launch_conv2(a, tiles_of(H, W), N, st, mx_in, wino);
     return check_launch("conv_forward");
 }
 

@@ -64,7 +64,8 @@ __device__ __forceinline__ float mix_hh(unsigned x, float m, unsigned c) { retur
 //   f16mx:  [(ky 3, mt 2)][lane 64] hi   ++   [(mt 2, wl8|wh8 2)][lane 64] records of kernel row h = lane / 32 (ky 0 | ky 1)
 //                                        ++   [(mt 2, wl8|wh8 2)][li 32]   records of ky 2 (lanes h = 1 of that MFMA read a zero block)
 // Record bytes: channel j of the stage at byte j (the V records of the kernel use the same order).
-__global__ void sr_prepack_wino_kernel(const float* __restrict__ w, int Cin, int Cout, const float* __restrict__ winv, uint4* __restrict__ out, int mx)
+// (w is [CoutReal][CinReal][3][3]; Cin / Cout are the padded sizes of the pack -- multiples of 16 / 128 --, channels beyond the real ones are zero)
+__global__ void sr_prepack_wino_kernel(const float* __restrict__ w, int CinReal, int CoutReal, int Cin, int Cout, const float* __restrict__ winv, uint4* __restrict__ out, int mx)
 {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int nst = Cin >> 4;
@@ -82,8 +83,10 @@ __global__ void sr_prepack_wino_kernel(const float* __restrict__ w, int Cin, int
     h8 hi[2], lo[2];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-        const float* g = w + (((size_t)co * Cin + st * 16 + j) * 3 + ky) * 3;
-        const double g0 = g[0], g1 = g[1], g2 = g[2];
+        const int ci = st * 16 + j;
+        const bool real = co < CoutReal && ci < CinReal;
+        const float* g = w + (((size_t)(real ? co : 0) * CinReal + (real ? ci : 0)) * 3 + ky) * 3;
+        const double g0 = real ? g[0] : 0.0, g1 = real ? g[1] : 0.0, g2 = real ? g[2] : 0.0;
         const double uu = pos == 0 ? g0 : (pos == 1 ? 0.5 * (g0 + g1 + g2) : (pos == 2 ? 0.5 * (g0 - g1 + g2) : g2));
         u[j] = (float)(uu * ws);
         _Float16 a, b; split1(u[j], a, b);

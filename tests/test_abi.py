@@ -30,7 +30,7 @@ def test_version_and_sizes():
     assert lib.r3d_version() >= 10
     assert lib.r3d_render_workspace_bytes(1, 16384, 48, 48) >= 2 * 16384 * 4
     assert lib.r3d_sr_block_prepacked_bytes(32, 256) == (4 * 9 * 32 * 256 + 9 * 256 * 256 + 4 * 256 + 12 * 256 * 256) * 4   # conv0 in four layouts (plain, up, up with fp8 records, plain with fp8 records) + conv1 + 2 weight-row tails + conv1's 12 Winograd F(2,3) tap matrices
-    assert lib.r3d_conv_prepacked_bytes(3, 64, 3) == (2 * 9 * 16 * 128 + 2 * 128) * 4        # padded to 16 x 128, twice (the f16x3 layout and, for 3x3 convs, the layout with fp8 records) + tail
+    assert lib.r3d_conv_prepacked_bytes(3, 64, 3) == (2 * 9 * 16 * 128 + 2 * 128 + 12 * 16 * 128) * 4        # padded to 16 x 128, twice (the f16x3 layout and, for 3x3 convs, the layout with fp8 records) + tail + (3x3) the 12 Winograd tap matrices
     assert lib.r3d_conv_scales_bytes(2, 3, 64) >= 2 * (16 + 128 + 3) * 4
     assert lib.r3d_sr_block_bound_offset(32, 256) * 4 < lib.r3d_sr_block_styles_bytes(1, 32, 256)
     assert lib.r3d_sr_block_styles_bytes(2, 32, 256) > 2 * (32 + 4 * 256) * 4
