@@ -13,8 +13,9 @@
 // = 2 x 4 tiles of 32 x 32 = 128 accumulator registers, two waves per SIMD, one block per CU.  Then
 //   * B (V_pos) is shared by two waves, A (U_pos of the wave's 64 couts) by NOBODY: the weights go global -> VGPR directly (coalesced
 //     16-byte loads of a prepacked per-wave stream, L2-resident), never through LDS;
-//   * the input transform is done once per block: the raw SPLIT patch (fp16 hi + lo) is staged in LDS by LDS-DMA, each wave transforms
-//     the V rows of ITS position (its 8-channel chunk wm of the 16-channel stage) and writes V as fp16 hi + {fp16 lo | e5m2 records};
+//   * the input transform is done once per block: the raw SPLIT patch (fp16 hi + lo) is staged in LDS (global -> VGPR -> ds_write, half a stage
+//     apart: every load of the kernel is visible to hipcc's vmcnt bookkeeping), each wave transforms the V rows of ITS position (its 8-channel chunk
+//     wm of the 16-channel stage) and writes V as fp16 hi + {fp16 lo | e5m2 records};
 //   * the four positions of a pixel meet in the epilogue through LDS (two rounds of 128 KB), after which the wave holds the ordinary
 //     64 couts x 64 pixels of conv_epilogue, in the direct kernel's lane <-> pixel map.
 // K stage = 16 input channels.  f16mx: per (ky, tile) one f16 MFMA (hi * hi) and the cross products of (ky0 | ky1) and (ky2 | zero) on
@@ -23,7 +24,10 @@
 // against 432 (1.5 x).
 // Range: the fold guarantees |x| < 2^15; V' = (a +- b) / 2 keeps |V'| < 2^15 and U' = U 2^(kw-1) keeps |U'| < 2^11 (|U| <= 1.5 max|g|);
 // the factor 4 is taken out with the per-cout epilogue multiplier (exact).
-// The transform of stage s + 1 rides inside the matrix pipeline of stage s in six small pieces (stage_body).
+// The transform of stage s + 1 rides inside the matrix pipeline of stage s in three 8-channel pieces (stage_body).
+// Measured (profiles/r06/winograd_kernel_findings.txt): f16x3 -13.7 % per launch against the direct kernel (the default there), f16mx +9 % (instruction-issue
+// bound at two waves per SIMD: the transform is 180 VALU instructions per wave and stage; stays on the direct kernel, also end to end: 1 650 vs 1 570 frames/s).
+// WG_X_* / WG_BD / WG_PD / WG_RL / WG_RS: experiment switches of that analysis (timing-only variants, prefetch depths); the defaults are the product.
 
 static constexpr int WG_VPLANE = 18 * 8;                            // uint4 slots of one V plane: [V row 18][column pair 8]
 static constexpr int WG_VPOS = 4 * WG_VPLANE;                       // per position: hi chunk 0 | hi chunk 1 | (lo chunk 0 | lo chunk 1) or (rec_h | rec_l)
@@ -31,7 +35,7 @@ static constexpr int WG_VBUF = 4 * WG_VPOS;                         // 2304 uint
 static constexpr int WG_RPLANE = 18 * 8;                            // raw patch plane k = (hi|lo, chunk, column parity): [row 18][8], column index rotated by k
 static constexpr int WG_REXTRA = 8 * WG_RPLANE;                     // the ninth column index of every plane: [row 18][plane 8]
 static constexpr int WG_RBUF = 9 * WG_RPLANE;                       // 1296 uint4 = 20.25 KB per stage
-static constexpr int WG_RSEGS = (WG_RBUF + 63) / 64;                // 21 DMA segments of 64 slots
+static constexpr int WG_RSEGS = (WG_RBUF + 63) / 64;                // 21 segments of 64 slots (one per wave and store instruction)
 static constexpr int WG_RSTRIDE = WG_RSEGS * 64;                    // 1344: the last segment's tail lanes land in padding
 static constexpr int WG_LDS_UINT4 = 8192;                           // main loop: 2 x 2304 + 2 x 1344 = 7296; epilogue exchange: 8192 (128 KB)
 #ifndef WG_X_PIECE
