@@ -286,6 +286,21 @@ int r3d_blend_cat_to_split(const float* a, int a_format, int Ca, const float* b,
                            int N, int H, int W, void* y_split, int y_format, const float* next_scale, size_t next_scale_stride,
                            r3d_stream_t stream);
 
+/* The same blend + concatenation FUSED into the 1x1 conv that consumes it (since 0.6.1):
+ *   y = act(conv_1x1(cat([a * mask, b * (1 - mask)], dim=1), W) + bias)
+ * = `x = torch.cat([x * person_occlusion, x_bg * (1 - person_occlusion)], dim=1); x = self.fuse_fg_bg_convs(x)` up to the first layer of
+ * fuse_fg_bg_convs (modules/real3d/super_resolution/sr_with_ref.py:113-114 / :125-126, the Sequential of :56-62) -- and the head / torso twin
+ * when that Sequential starts with a 1x1 conv.  The 512-channel operand is never written: the kernel blends, scales by the layer's in-multiplier
+ * and splits while it stages (bit-identical to r3d_blend_cat_to_split followed by r3d_conv_forward; 134 MB read instead of 67 + 134 MB
+ * written + 270 MB read at 256^2).  a [N,Ca/8,H,W,8], b [N,Cb/8,H,W,8] R3D_FMT_CB8 fp32, mask [N,1,H,W]; Ca % 8 == Cb % 8 == 0,
+ * (Ca + Cb) % 64 == 0.  prepacked / scales / bias / act... / y... as r3d_conv_forward with ksize 1 and Cin = Ca + Cb; the in-multiplier a
+ * conv layer's r3d_chain_fold writes is one power of two for all channels (element 0 of `scales` is read). */
+int r3d_conv_forward_blend(const void* prepacked, const void* scales, const float* bias,
+                           int N, int Ca, int Cb, int Cout, int H, int W,
+                           const float* a, const float* b, const float* mask,
+                           int act, float act_slope, float act_gain, float clamp,
+                           void* y, int y_format, const float* next_scale, size_t next_scale_stride, float* y_absmax, r3d_stream_t stream);
+
 /* torch.nn.UpsamplingBilinear2d(scale_factor=2) (align_corners=True), the resampling step inside to_plane_cnn
  * (modules/real3d/segformer.py:691-700), between two r3d_conv_forward layers: x fp32 channel-blocked [N,C/8,H,W,8] ->
  * y at 2H x 2W in R3D_FMT_CB8, R3D_FMT_SPLIT or R3D_FMT_SPLIT_MX (scaled by next_scale, NULL = 1; SPLIT_MX -- the consumer runs the f16mx

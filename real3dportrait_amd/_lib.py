@@ -22,6 +22,8 @@ SIGNATURES = {
     "r3d_last_error": (ctypes.c_char_p, []),
     "r3d_planes_to_nhwc": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, ctypes.POINTER(c_int), P]),
     "r3d_planes_absmax_partials": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "r3d_conv_forward_blend": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, c_float, c_float, c_float,
+                                       P, c_int, P, c_size_t, P, P]),
     "r3d_blend_cat_to_split": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, P, c_int, P, c_size_t, P]),
     "r3d_upsample2x_bilinear": (c_int, [P, c_int, c_int, c_int, c_int, P, c_int, P, c_size_t, P]),
     "r3d_raygen": (c_int, [P, P, c_int, c_int, P, P, P]),
@@ -76,7 +78,7 @@ class ChainOp(ctypes.Structure):
 
 CHAIN_SR_BLOCK, CHAIN_CONV, CHAIN_SR_BLOCK_TAIL, CHAIN_SRC_NONE, CHAIN_MAX_OPS, CHAIN_MAX_EXT, CHAIN_MAX_ZERO = 0, 1, 2, -1000, 12, 4, 4
 
-ABI_VERSION = 60          # r3d_version() of the library this table mirrors (include/r3d_hip.h)
+ABI_VERSION = 61          # r3d_version() of the library this table mirrors (include/r3d_hip.h)
 _lib = None
 
 

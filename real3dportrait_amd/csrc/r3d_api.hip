@@ -143,7 +143,7 @@ __global__ void person_occlusion_kernel(const float* __restrict__ alpha, const f
 
 using namespace r3d;
 
-extern "C" int r3d_version(void) { return 60; }   // 0.6.0: r3d_sr_block_prepacked_bytes grew by conv1's Winograd F(2,3) pack; r3d_render_workspace_bytes follows the real grid (0.5.0: e5m2 activation records); real3dportrait_amd/_lib.py checks the number
+extern "C" int r3d_version(void) { return 61; }   // 0.6.1: r3d_conv_forward_blend; 0.6.0: r3d_sr_block_prepacked_bytes grew by conv1's Winograd F(2,3) pack; r3d_render_workspace_bytes follows the real grid (0.5.0: e5m2 activation records); real3dportrait_amd/_lib.py checks the number
 
 extern "C" int r3d_resize_bilinear(const float* x, int planes, int H, int W, float* y, int OH, int OW, int antialias, r3d_stream_t stream)
 {

@@ -837,6 +837,31 @@ extern "C" int r3d_conv_forward(const void* prepacked, const void* scales, const
                               workspace, (hipStream_t)stream);
 }
 
+extern "C" int r3d_conv_forward_blend(const void* prepacked, const void* scales, const float* bias,
+                                      int N, int Ca, int Cb, int Cout, int H, int W,
+                                      const float* a, const float* b, const float* mask,
+                                      int act, float act_slope, float act_gain, float clamp,
+                                      void* y, int y_format, const float* next_scale, size_t next_scale_stride, float* y_absmax, r3d_stream_t stream)
+{
+    using namespace r3d;
+    if (!prepacked || !scales || !a || !b || !mask || !y || N <= 0 || Ca <= 0 || Cb <= 0 || Cout <= 0 || H <= 0 || W <= 0) {
+        set_error("conv_forward_blend: bad argument"); return R3D_ERR_INVALID_ARG;
+    }
+    if ((Ca & 7) || (Cb & 7) || ((Ca + Cb) & 63)) {
+        set_error("conv_forward_blend: Ca %d and Cb %d must be multiples of 8 and their sum a multiple of 64", Ca, Cb); return R3D_ERR_INVALID_ARG;
+    }
+    if (y_format < R3D_FMT_NCHW || y_format > R3D_FMT_SPLIT_MX || (y_format == R3D_FMT_SPLIT_MX && (Cout & 15)) || (y_format != R3D_FMT_NCHW && (Cout & 7)) || (Cout & 3)) {
+        set_error("conv_forward_blend: unsupported output (format %d, Cout %d)", y_format, Cout); return R3D_ERR_INVALID_ARG;
+    }
+    {
+        const size_t cmax = (size_t)((Ca + Cb > Cout ? Ca + Cb : Cout) + BLOCK_M);
+        if (cmax * H * W >= ((size_t)1 << 32)) { set_error("conv_forward_blend: activation of %zu elements per sample exceeds the 32-bit index range", cmax * H * W); return R3D_ERR_INVALID_ARG; }
+    }
+    const size_t stride = conv_scales_layout(Ca + Cb, (Cout + BLOCK_M - 1) / BLOCK_M * BLOCK_M).total;
+    return conv_forward_blend_f16x3(prepacked, reinterpret_cast<const float*>(scales), stride, bias, N, Ca, Cb, Cout, H, W, a, b, mask,
+                                    act, act_slope, act_gain, clamp, y, y_format, next_scale, next_scale_stride, y_absmax, (hipStream_t)stream);
+}
+
 extern "C" int r3d_upsample2x_bilinear(const float* x_cb8, int N, int C, int H, int W, void* y, int y_format,
                                        const float* next_scale, size_t next_scale_stride, r3d_stream_t stream)
 {

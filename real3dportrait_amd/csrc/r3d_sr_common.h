@@ -111,6 +111,11 @@ int conv_forward_f16x3(const void* prepacked, const float* scales, size_t scales
                        void* y, int y_format, const float* next_scale, size_t next_scale_stride, float* y_absmax,
                        void* workspace, hipStream_t st);
 
+int conv_forward_blend_f16x3(const void* prepacked, const float* scales, size_t scales_stride, const float* bias,
+                             int N, int Ca, int Cb, int Cout, int H, int W, const float* xa, const float* xb, const float* mask,
+                             int act, float slope, float gain, float clamp,
+                             void* y, int y_format, const float* next_scale, size_t next_scale_stride, float* y_absmax, hipStream_t st);
+
 int upsample2x_bilinear_f16x3(const float* x_cb8, int N, int C, int H, int W, void* y, int y_format,
                               const float* next_scale, size_t next_scale_stride, hipStream_t st);
 

@@ -275,6 +275,10 @@ struct Conv2Args {
     int act; float act_slope, act_gain, clamp; // act: leaky-relu(slope) * gain after the bias; clamp < 0: off
     unsigned long long* clk;                  // prof_clock_slot(R3D_PROF_CONV) or null (conv3x3_dma_block samples it)
     int order;                                // conv3x3_dma_block: 0 = (tile, cout tile) = (blockIdx.x, blockIdx.y); 1 / 2 = the cout tiles of a pixel tile adjacent in dispatch order on one XCD
+    // conv1x1_blend_f16x3_kernel: the operand x = cat([bl_a * m, bl_b * (1 - m)]) * in_scale is computed while it is staged, never materialised --
+    // bl_a / bl_b fp32 channel-blocked [N][C/8][H*W][8] (Ca + Cb = Cin), bl_mask [N][H*W], bl_scale [N] x stride: the layer's folded in-multiplier (uniform
+    // over the channels for a plain conv layer: element 0 is read)
+    const float* bl_a; const float* bl_b; const float* bl_mask; const float* bl_scale; size_t bl_scale_stride_n; int bl_Ca;
     ConvPhase ph[4];
 };
 
@@ -970,6 +974,124 @@ __global__ __launch_bounds__(128 * WN, OCC) void conv1x1_mfma_f16x3_kernel(Conv2
 {
     __shared__ uint4 lds[F_LDS_UINT4];
     conv2_block<1, true, WN, NT>(a, a.ph[0], blockIdx.z, lds);
+}
+
+// ---- 1x1 conv with the alpha / occlusion blend + channel concatenation of its operand fused in (round 6) ------------------------------------------------------
+// `x = torch.cat([x * m, x_bg * (1 - m)], dim=1)` followed by the 1x1 conv of fuse_fg_bg_convs (modules/real3d/super_resolution/sr_with_ref.py:113-114, :56-62).
+// Until round 5: r3d_blend_cat_to_split wrote the 512-channel operand in SPLIT form (134 MB at 256^2; 45 us) and conv1x1_mfma_f16x3_kernel read it back with the 18 x 18 halo
+// patch of the 3x3 convs it shares its block routine with (270 MB moved for the 134 MB operand, one 16-channel stage in flight per block: 52 us).  Here one thread owns one
+// (8-channel chunk, pixel) of the stage: 32 bytes of fp32 from bl_a or bl_b, times mask and in-multiplier, split into fp16 hi + lo (the arithmetic of
+// blend_cat_to_split_kernel), straight into the LDS patch; FOUR stages of loads are in flight per thread (the kernel is a stream: 134 MB in, 17 MB out, 4.3 GFLOP), the
+// weights go global -> VGPR (A operands, L2-resident, no LDS), every load is visible to hipcc's vmcnt bookkeeping.  Block = 128 couts x 16 x 16 px, 8 waves of 64 couts x 64 px in
+// the lane <-> pixel map of conv_epilogue (which it ends with: all output formats, bias, activation, max|y|); one block per CU (the grid of the 256^2 layer: 256 blocks).
+static constexpr int BL_PATCH = 2 * 2 * 256;                          // uint4 per patch buffer: [hi|lo][chunk][16 x 16 px], odd rows rotated by 2 slots (conflict-free B reads)
+static constexpr int BL_DEPTH = 4;                                    // stages of operand loads in flight
+__global__ __launch_bounds__(512, 2) void conv1x1_blend_f16x3_kernel(Conv2Args a)
+{
+    __shared__ uint4 lds[2 * BL_PATCH > 6 * BLOCK_M / 4 ? 2 * BL_PATCH : 6 * BLOCK_M / 4];
+    constexpr int WN = 4, NT = 2;
+    const ConvPhase& ph = a.ph[0];
+    const int n = blockIdx.z;
+    const int tiles_x = (ph.outW + F_TILE_W - 1) / F_TILE_W;
+    const int tile = blockIdx.x;
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int i0 = ty * F_TILE_H, j0 = tx * F_TILE_W;
+    const int m0 = blockIdx.y * BLOCK_M;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WN, wn = wave - wm * WN;
+    const int li = lane & 31, h = lane >> 5;
+    const int nst = a.Cin >> 4, hw = a.H * a.W;
+    const int ca8 = a.bl_Ca >> 3, cb8 = (a.Cin - a.bl_Ca) >> 3;
+
+    f32x16 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    // this thread's share of a stage's operand: chunk tc of the stage, pixel (py, px) of the tile
+    const int tc = threadIdx.x >> 8, py = (threadIdx.x >> 4) & 15, px = threadIdx.x & 15;
+    const bool inside = i0 + py < a.H && j0 + px < a.W;
+    const size_t pix = inside ? (size_t)(i0 + py) * a.W + (j0 + px) : 0;
+    const float m = inside ? a.bl_mask[(size_t)n * hw + pix] : 0.f;
+    const float sc = a.bl_scale[(size_t)n * a.bl_scale_stride_n];
+    const float ma = inside ? m : 0.f, mb = inside ? 1.0f - m : 0.f;      // (x * m) * s in blend_cat_to_split_kernel's order: bit-identical operand, s is a power of two
+    const int wslot = tc * 256 + py * 16 + ((px + 2 * (py & 1)) & 15);
+    auto src_of = [&](int st) -> const float4* {                       // chunk 2 st + tc of the concatenation: bl_a's channels first, then bl_b's
+        const int cc = 2 * st + tc;
+        const float* base = cc < ca8 ? a.bl_a + ((size_t)n * ca8 + cc) * hw * 8 : a.bl_b + ((size_t)n * cb8 + (cc - ca8)) * hw * 8;
+        return reinterpret_cast<const float4*>(base + pix * 8);
+    };
+    float4 raw[BL_DEPTH][2];
+    auto issue = [&](int st, float4 (&r)[2]) {                         // no branch: a stage past the end re-reads the last one (never staged), a pixel outside reads pixel 0 (times 0)
+        const float4* s4 = src_of(st < nst ? st : nst - 1); r[0] = s4[0]; r[1] = s4[1];
+    };
+    auto stage_patch = [&](int st, const float4 (&r)[2], uint4* P) {   // raw -> fp16 hi + lo -> LDS patch
+        const float f = (2 * st + tc) < ca8 ? ma : mb;
+        const float x[8] = {r[0].x, r[0].y, r[0].z, r[0].w, r[1].x, r[1].y, r[1].z, r[1].w};
+        h8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float t = as_rounded(x[j] * f * sc);
+            const float cl = fminf(fmaxf(t, -65504.f), 65504.f);
+            hi[j] = (_Float16)cl; lo[j] = (_Float16)(t - (float)hi[j]);
+        }
+        P[wslot] = *reinterpret_cast<uint4*>(&hi);
+        P[512 + wslot] = *reinterpret_cast<uint4*>(&lo);
+    };
+    // A operands of a stage: weights [tap 0][chunk][hi|lo][Cout] -> this lane's (cout 64 wm + 32 mt + li, chunk 2 st + h)
+    const uint4* WP = a.wp + m0 + 64 * wm + li;
+    auto load_a = [&](int st, h8 (&ah)[2], h8 (&al)[2]) {
+        const uint4* w = WP + (size_t)((2 * (st < nst ? st : nst - 1) + h) * 2) * a.Cout;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) { const uint4 q0 = w[32 * mt], q1 = w[a.Cout + 32 * mt]; ah[mt] = *reinterpret_cast<const h8*>(&q0); al[mt] = *reinterpret_cast<const h8*>(&q1); }
+    };
+    // B slot of this lane in N tile nt: rows (2 nt, 2 nt + 1) of the wave's four rows, columns rotated by 2 on odd rows like the patch
+    const int prow = li >> 4, row0 = wn * 2 * NT;
+    int boff[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) boff[nt] = h * 256 + (row0 + nt * 2 + prow) * 16 + (li & 15);
+
+    h8 ah[2][2], al[2][2];                                            // [stage parity][mt]
+#pragma unroll
+    for (int d = 0; d < BL_DEPTH; ++d) issue(d, raw[d]);
+    load_a(0, ah[0], al[0]);
+    stage_patch(0, raw[0], lds);
+    issue(BL_DEPTH, raw[0]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // stage s: MFMAs on patch[s & 1] | operand of stage s + 1 -> patch[(s + 1) & 1] | loads of stage s + 1 + BL_DEPTH; the ring slot of a stage is (stage % BL_DEPTH): the
+    // loop is unrolled over BL_DEPTH stages so that every slot is a fixed set of registers (a rotating copy would wait for loads still in flight)
+    for (int s0 = 0; s0 < nst; s0 += BL_DEPTH) {
+#pragma unroll
+        for (int d = 0; d < BL_DEPTH; ++d) {
+            const int s = s0 + d;                                     // (nst % BL_DEPTH == 0: the launcher's precondition Cin % 64 == 0)
+            {
+                const uint4* P = lds + (d & 1) * BL_PATCH;            // (BL_DEPTH is even: the patch parity of stage s is d & 1)
+                load_a(s + 1, ah[(d + 1) & 1], al[(d + 1) & 1]);
+                h8 bh[NT], bl[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) { const uint4 r0 = P[boff[nt]], r1 = P[512 + boff[nt]]; bh[nt] = *reinterpret_cast<const h8*>(&r0); bl[nt] = *reinterpret_cast<const h8*>(&r1); }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[d & 1][mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[d & 1][mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[d & 1][mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                    }
+                stage_patch(s + 1, raw[(d + 1) % BL_DEPTH], lds + ((d + 1) & 1) * BL_PATCH);   // (after the last stage: into the buffer nobody reads any more)
+                issue(s + 1 + BL_DEPTH, raw[(d + 1) % BL_DEPTH]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+            }
+        }
+    }
+    conv_epilogue<true, WN, NT>(a, ph, n, acc, i0, j0, m0, reinterpret_cast<float*>(lds));
 }
 
 // stride-2 transposed conv phases (4/2/2/1 taps)
@@ -2029,6 +2151,34 @@ int conv_forward_f16x3(const void* prepacked, const float* scales, size_t scales
     ProfScope ps(R3D_PROF_CONV, st);
     launch_conv2(a, tiles_of(H, W), N, st, mx_in, wino);
     return check_launch("conv_forward");
+}
+
+// cat([a * mask, b * (1 - mask)]) -> 1x1 conv in one kernel (conv1x1_blend_f16x3_kernel); the caller validated: ksize 1, a / b CB8, Ca % 8 == Cb % 8 == 0, (Ca + Cb) % 64 == 0
+int conv_forward_blend_f16x3(const void* prepacked, const float* scales, size_t scales_stride, const float* bias,
+                             int N, int Ca, int Cb, int Cout, int H, int W, const float* xa, const float* xb, const float* mask,
+                             int act, float slope, float gain, float clamp,
+                             void* y, int y_format, const float* next_scale, size_t next_scale_stride, float* y_absmax, hipStream_t st)
+{
+    const int Ci = Ca + Cb, Co = pad_to(Cout, BLOCK_M);
+    const ConvScales S = conv_scales_layout(Ci, Co);
+    Conv2Args a = {};
+    a.wp = reinterpret_cast<const uint4*>(prepacked);
+    a.bl_a = xa; a.bl_b = xb; a.bl_mask = mask; a.bl_scale = scales + S.in_vec; a.bl_scale_stride_n = scales_stride; a.bl_Ca = Ca;
+    a.out_scale = scales + S.out_vec; a.out_scale_stride_n = scales_stride; a.bias = bias; a.bias_stride_n = 0;
+    a.OH = H; a.OW = W;
+    if (y_format == R3D_FMT_CB8) { a.y_f32 = reinterpret_cast<float*>(y); a.y_f32_stride_n = (size_t)Cout * H * W; }
+    else if (y_format == R3D_FMT_NCHW) { a.y_nchw = reinterpret_cast<float*>(y); a.y_nchw_stride_n = (size_t)Cout * H * W; }
+    else { a.y_split = reinterpret_cast<uint4*>(y); a.y_split_stride_n = (size_t)Cout / 8 * H * W * 2; a.next_scale = next_scale; a.next_scale_stride_n = next_scale_stride;
+           a.y_split_mx = y_format == R3D_FMT_SPLIT_MX ? 1 : 0; }
+    a.y_absmax = reinterpret_cast<unsigned*>(y_absmax);
+    a.Cin = Ci; a.Cout = Co; a.CoutReal = Cout; a.H = H; a.W = W; a.nphase = 1;
+    a.act = act; a.act_slope = slope; a.act_gain = gain; a.clamp = clamp;
+    ConvPhase& p = a.ph[0];
+    p.outH = H; p.outW = W; p.oy_mul = 1; p.oy_add = 0; p.ox_mul = 1; p.ox_add = 0; p.out_off = 0;
+    p.ntaps = 1; p.dy[0] = 0; p.dx[0] = 0; p.widx[0] = 0;
+    ProfScope ps(R3D_PROF_CONV, st);
+    hipLaunchKernelGGL(conv1x1_blend_f16x3_kernel, dim3(tiles_of(H, W), Co / BLOCK_M, N), dim3(512), 0, st, a);
+    return check_launch("conv_forward_blend");
 }
 
 }  // namespace r3d

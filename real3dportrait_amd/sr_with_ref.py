@@ -25,6 +25,8 @@ import os
 
 # A/B switch: 1 = head_torso_block's conv1 operand is re-folded from the measured max of fuse_head_torso_convs' output (rounds 3-4)
 _HB_TAIL_FOLD = os.environ.get("R3D_HB_TAIL_FOLD", "0") == "1"
+# A/B switch: 0 = person / background blend written as a SPLIT tensor (r3d_blend_cat_to_split) and read back by fuse_fg_bg_convs' 1x1 conv (rounds 2-5)
+_FUSE_BLEND = os.environ.get("R3D_FUSE_BLEND", "1") != "0"
 
 
 def blend(a, b, mask):
@@ -243,9 +245,14 @@ def _forward_v2(self, S, rgb, x, ws, ref_torso_rgb, ref_bg_rgb, weights_img, seg
     prep1 = b1.prepare(ws3, dev, ws_key=ws)
     ops, head, last = fuse_fg.chain_ops(N, dev, -1, -2, base=0)
     chain_fold(ops + [b1.chain_op(last)], N, [m_x2, x_bg._r3d_bound], zero=[m_z])
-    xs2 = blend_cat(x2, x_bg, pocc, fuse_fg, _folded_head=head)                                         # :113
     # f16mx: the last fusion conv leaves fp8 records for block1's up-sampling conv (R3D_FMT_SPLIT_MX), as block0 does in the head-only network
-    z = fuse_fg(xs2, out_format="split_mx" if b1.wants_mx() else "split", _next=b1, _y_absmax=m_z)      # :114
+    zfmt = "split_mx" if b1.wants_mx() else "split"
+    if _FUSE_BLEND and fuse_fg.num_layers() > 1 and head.can_blend(x2, x_bg):
+        # :113 inside the 1x1 conv of :114 (r3d_conv_forward_blend): the 512-channel concatenation is never written (bit-identical to the two-step form)
+        z = fuse_fg(None, out_format=zfmt, _next=b1, _y_absmax=m_z, _blend=(x2, x_bg, pocc))
+    else:
+        xs2 = blend_cat(x2, x_bg, pocc, fuse_fg, _folded_head=head)                                     # :113
+        z = fuse_fg(xs2, out_format=zfmt, _next=b1, _y_absmax=m_z)                                      # :114
     chain_fold([b1.chain_op(-1, tail=True)], N, [m_z])
     b1.return_x = False
     _, rgb_out = b1(z, rgb3, ws3, _prepared=prep1, _folded=True, **kw)                                 # :115

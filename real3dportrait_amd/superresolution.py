@@ -463,10 +463,30 @@ class Conv2d(nn.Module):
             return x.shape[0], x.shape[1] * 8, x.shape[2], x.shape[3]
         return x.shape[0], x.shape[2] * 8, x.shape[3], x.shape[4]
 
-    def forward(self, x, negative_slope=None, out_format="nchw", _next=None, _folded=False, _y_absmax=None):
+    def can_blend(self, a, b):
+        """May `cat([a * m, b * (1 - m)])` be fused into this conv (r3d_conv_forward_blend)?  1x1, both sources channel-blocked fp32, Cin % 64 == 0."""
+        return (self.kernel_size[0] == 1 and getattr(a, "_r3d_fmt", None) == "cb8" and getattr(b, "_r3d_fmt", None) == "cb8"
+                and (a.shape[1] + b.shape[1]) * 8 == self.in_channels and self.in_channels % 64 == 0)
+
+    def forward(self, x, negative_slope=None, out_format="nchw", _next=None, _folded=False, _y_absmax=None, _blend=None):
         """negative_slope: fuse a following torch.nn.LeakyReLU(negative_slope); out_format 'nchw' | 'cb8' | 'split'
-        ('split' needs `_next`, the consumer module, folded by the caller in the same chain)."""
+        ('split' needs `_next`, the consumer module, folded by the caller in the same chain).
+        _blend = (a, b, mask) instead of x: the input is cat([a * mask, b * (1 - mask)], dim=1) (sr_with_ref.py:113-114), computed inside the
+        kernel (see can_blend; the caller has folded this layer for max(bound(a), bound(b)))."""
         lib = _lib.load()
+        if _blend is not None:
+            a, b, mask = _blend
+            assert _folded and self.can_blend(a, b), "fused blend: a folded 1x1 conv over two 'cb8' sources"
+            a, b, mask = a.contiguous(), b.contiguous(), _f32c(mask)
+            N, H, W = a.shape[0], a.shape[2], a.shape[3]
+            assert tuple(b.shape[:1] + b.shape[2:4]) == (N, H, W) and tuple(mask.shape) == (N, 1, H, W), (a.shape, b.shape, mask.shape)
+            y, next_scale, next_stride = self._alloc_out(N, H, W, out_format, _next, a.device)
+            _lib.check(lib.r3d_conv_forward_blend(_lib.ptr(self._prepacked), _lib.ptr(self._scales), _lib.ptr(self._bias32), N, a.shape[1] * 8, b.shape[1] * 8,
+                                                  self.out_channels, H, W, _lib.ptr(a), _lib.ptr(b), _lib.ptr(mask),
+                                                  0 if negative_slope is None else 1, float(negative_slope or 0.0), 1.0, -1.0,
+                                                  _lib.ptr(y), self._FMT[out_format], _lib.ptr(next_scale), next_stride, _lib.ptr(_y_absmax), _lib.stream_ptr()),
+                       "conv_forward_blend")
+            return self._tag_out(y, out_format, _next, N)
         x_fmt = getattr(x, "_r3d_fmt", "nchw")
         if x_fmt in ("split", "split_mx"):
             if getattr(x, "_r3d_for", None) is not self:
@@ -487,6 +507,16 @@ class Conv2d(nn.Module):
             chain_fold([self.chain_op(-1, negative_slope=negative_slope)], N, [bx])
         need = int(lib.r3d_conv_workspace_bytes(N, Cin, H, W))
         work = self._buf("_workspace", need, dev) if x_fmt not in ("split", "split_mx") else None
+        y, next_scale, next_stride = self._alloc_out(N, H, W, out_format, _next, dev)
+        act = 0 if negative_slope is None else 1
+        _lib.check(lib.r3d_conv_forward(_lib.ptr(self._prepacked), _lib.ptr(self._scales), _lib.ptr(self._bias32), N, Cin, Cout, H, W, k,
+                                        _lib.ptr(x), self._FMT[x_fmt], act, float(negative_slope or 0.0), 1.0, -1.0,
+                                        _lib.ptr(y), self._FMT[out_format], _lib.ptr(next_scale), next_stride, _lib.ptr(_y_absmax),
+                                        _lib.ptr(work), need if work is not None else 0, st), "conv_forward")
+        return self._tag_out(y, out_format, _next, N)
+
+    def _alloc_out(self, N, H, W, out_format, _next, dev):
+        Cout = self.out_channels
         next_scale, next_stride = None, 0
         if out_format in ("split", "split_mx"):      # split_mx: fp8 records in the lo plane, for an f16mx SynthesisBlock that consumes y
             assert _next is not None, "out_format='split' needs the consumer (its folded in-multiplier)"
@@ -496,11 +526,9 @@ class Conv2d(nn.Module):
             y = torch.empty(N, Cout // 8, H, W, 8, device=dev, dtype=torch.float32)
         else:
             y = torch.empty(N, Cout, H, W, device=dev, dtype=torch.float32)
-        act = 0 if negative_slope is None else 1
-        _lib.check(lib.r3d_conv_forward(_lib.ptr(self._prepacked), _lib.ptr(self._scales), _lib.ptr(self._bias32), N, Cin, Cout, H, W, k,
-                                        _lib.ptr(x), self._FMT[x_fmt], act, float(negative_slope or 0.0), 1.0, -1.0,
-                                        _lib.ptr(y), self._FMT[out_format], _lib.ptr(next_scale), next_stride, _lib.ptr(_y_absmax),
-                                        _lib.ptr(work), need if work is not None else 0, st), "conv_forward")
+        return y, next_scale, next_stride
+
+    def _tag_out(self, y, out_format, _next, N):
         if out_format != "nchw":
             y._r3d_fmt = out_format
         if out_format in ("split", "split_mx"):
@@ -674,13 +702,18 @@ class ConvStack(nn.Sequential):
         chain_fold(ops, N, bounds)
         return head
 
-    def forward(self, x, out_format="nchw", _next=None, _y_absmax=None):
+    def forward(self, x, out_format="nchw", _next=None, _y_absmax=None, _blend=None):
         """out_format of the LAST conv: 'nchw' (default, reference layout) | 'cb8' | 'split' (scaled for `_next`, already folded);
-        _y_absmax: device float[N] slot the last conv measures max|y| into (zeroed by a preceding fold)."""
+        _y_absmax: device float[N] slot the last conv measures max|y| into (zeroed by a preceding fold);
+        _blend = (a, b, mask) with x = None: the stack's input is cat([a * mask, b * (1 - mask)]) and its first conv computes it (Conv2d.can_blend;
+        the caller has folded the stack for the two sources, as for blend_cat(_folded_head=...))."""
         plan = self._plan()
         x_fmt = getattr(x, "_r3d_fmt", "nchw")
         dx = int(getattr(x, "_r3d_depth", 0))
-        if x_fmt in ("split", "split_mx"):
+        if _blend is not None:
+            assert x is None
+            dx = max(int(getattr(_blend[0], "_r3d_depth", 0)), int(getattr(_blend[1], "_r3d_depth", 0)))
+        elif x_fmt in ("split", "split_mx"):
             if getattr(x, "_r3d_for", None) is not plan[0][0]:
                 raise RuntimeError("SPLIT activation was scaled for a different consumer")
         else:
@@ -699,7 +732,7 @@ class ConvStack(nn.Sequential):
             if up:
                 x = upsample2x_bilinear(m(x, negative_slope=slope, out_format="cb8", _folded=True), "split_mx" if mx_next else "split", _next=nxt)
             elif nxt is not None and m.out_channels % 16 == 0:
-                x = m(x, negative_slope=slope, out_format="split_mx" if mx_next else "split", _next=nxt, _folded=True)
+                x = m(x, negative_slope=slope, out_format="split_mx" if mx_next else "split", _next=nxt, _folded=True, _blend=_blend if k == 0 else None)
             elif nxt is not None:
                 raise NotImplementedError("ConvStack: inner layers need out_channels % 16 == 0")
             else:
