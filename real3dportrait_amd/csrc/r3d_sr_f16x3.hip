@@ -982,13 +982,13 @@ __global__ __launch_bounds__(128 * WN, OCC) void conv1x1_mfma_f16x3_kernel(Conv2
 // patch of the 3x3 convs it shares its block routine with (270 MB moved for the 134 MB operand, one 16-channel stage in flight per block: 52 us).  Here one thread owns one
 // (8-channel chunk, pixel) of the stage: 32 bytes of fp32 from bl_a or bl_b, times mask and in-multiplier, split into fp16 hi + lo (the arithmetic of
 // blend_cat_to_split_kernel), straight into the LDS patch; FOUR stages of loads are in flight per thread (the kernel is a stream: 134 MB in, 17 MB out, 4.3 GFLOP), the
-// weights go global -> VGPR (A operands, L2-resident, no LDS), every load is visible to hipcc's vmcnt bookkeeping.  Block = 128 couts x 16 x 16 px, 8 waves of 64 couts x 64 px in
+// weights ride in the same ring (global -> VGPR -> LDS), every load is visible to hipcc's vmcnt bookkeeping.  Block = 128 couts x 16 x 16 px, 8 waves of 64 couts x 64 px in
 // the lane <-> pixel map of conv_epilogue (which it ends with: all output formats, bias, activation, max|y|); one block per CU (the grid of the 256^2 layer: 256 blocks).
 static constexpr int BL_PATCH = 2 * 2 * 256;                          // uint4 per patch buffer: [hi|lo][chunk][16 x 16 px], odd rows rotated by 2 slots (conflict-free B reads)
 static constexpr int BL_DEPTH = 4;                                    // stages of operand loads in flight
 __global__ __launch_bounds__(512, 2) void conv1x1_blend_f16x3_kernel(Conv2Args a)
 {
-    __shared__ uint4 lds[2 * BL_PATCH > 6 * BLOCK_M / 4 ? 2 * BL_PATCH : 6 * BLOCK_M / 4];
+    __shared__ uint4 lds[2 * BL_PATCH + 2 * 512];                     // (the epilogue's staging, 6 * BLOCK_M floats, fits)
     constexpr int WN = 4, NT = 2;
     const ConvPhase& ph = a.ph[0];
     const int n = blockIdx.z;
@@ -1041,25 +1041,26 @@ __global__ __launch_bounds__(512, 2) void conv1x1_blend_f16x3_kernel(Conv2Args a
         P[wslot] = *reinterpret_cast<uint4*>(&hi);
         P[512 + wslot] = *reinterpret_cast<uint4*>(&lo);
     };
-    // A operands of a stage: weights [tap 0][chunk][hi|lo][Cout] -> this lane's (cout 64 wm + 32 mt + li, chunk 2 st + h)
-    const uint4* WP = a.wp + m0 + 64 * wm + li;
-    auto load_a = [&](int st, h8 (&ah)[2], h8 (&al)[2]) {
-        const uint4* w = WP + (size_t)((2 * (st < nst ? st : nst - 1) + h) * 2) * a.Cout;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) { const uint4 q0 = w[32 * mt], q1 = w[a.Cout + 32 * mt]; ah[mt] = *reinterpret_cast<const h8*>(&q0); al[mt] = *reinterpret_cast<const h8*>(&q1); }
-    };
+    // weights of a stage: [chunk 2 st, 2 st + 1][hi|lo][Cout] -> this block's 128 couts of the four rows, one uint4 per thread, in the SAME ring as the operand (the
+    // vmcnt counter retires in order: a weight load issued later than an operand load and needed earlier would drain the ring -- the first version of this kernel
+    // loaded A operands global -> VGPR one stage ahead and ran at 3.3 TB/s, an effective depth of one stage)
+    const uint4* WP = a.wp + (size_t)(threadIdx.x >> 7) * a.Cout + m0 + (threadIdx.x & 127);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 wraw[BL_DEPTH];
+    auto issue_w = [&](int st, u32x4& r) { r = *reinterpret_cast<const u32x4*>(WP + (size_t)(st < nst ? st : nst - 1) * 4 * a.Cout); };
+    uint4* const Abuf = lds + 2 * BL_PATCH;                           // [parity][row = chunk * 2 + (hi|lo)][128 couts]
+    const int aoff = h * 256 + 64 * wm + li;                           // + hl * 128 + 32 * mt
     // B slot of this lane in N tile nt: rows (2 nt, 2 nt + 1) of the wave's four rows, columns rotated by 2 on odd rows like the patch
     const int prow = li >> 4, row0 = wn * 2 * NT;
     int boff[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) boff[nt] = h * 256 + (row0 + nt * 2 + prow) * 16 + (li & 15);
 
-    h8 ah[2][2], al[2][2];                                            // [stage parity][mt]
 #pragma unroll
-    for (int d = 0; d < BL_DEPTH; ++d) issue(d, raw[d]);
-    load_a(0, ah[0], al[0]);
+    for (int d = 0; d < BL_DEPTH; ++d) { issue(d, raw[d]); issue_w(d, wraw[d]); }
     stage_patch(0, raw[0], lds);
-    issue(BL_DEPTH, raw[0]);
+    *reinterpret_cast<u32x4*>(Abuf + threadIdx.x) = wraw[0];
+    issue(BL_DEPTH, raw[0]); issue_w(BL_DEPTH, wraw[0]);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
@@ -1071,7 +1072,10 @@ __global__ __launch_bounds__(512, 2) void conv1x1_blend_f16x3_kernel(Conv2Args a
             const int s = s0 + d;                                     // (nst % BL_DEPTH == 0: the launcher's precondition Cin % 64 == 0)
             {
                 const uint4* P = lds + (d & 1) * BL_PATCH;            // (BL_DEPTH is even: the patch parity of stage s is d & 1)
-                load_a(s + 1, ah[(d + 1) & 1], al[(d + 1) & 1]);
+                const uint4* A = Abuf + (d & 1) * 512 + aoff;
+                h8 ah[2], al[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) { const uint4 q0 = A[32 * mt], q1 = A[128 + 32 * mt]; ah[mt] = *reinterpret_cast<const h8*>(&q0); al[mt] = *reinterpret_cast<const h8*>(&q1); }
                 h8 bh[NT], bl[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) { const uint4 r0 = P[boff[nt]], r1 = P[512 + boff[nt]]; bh[nt] = *reinterpret_cast<const h8*>(&r0); bl[nt] = *reinterpret_cast<const h8*>(&r1); }
@@ -1079,12 +1083,13 @@ __global__ __launch_bounds__(512, 2) void conv1x1_blend_f16x3_kernel(Conv2Args a
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[d & 1][mt], bh[nt], acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[d & 1][mt], bl[nt], acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[d & 1][mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
                     }
                 stage_patch(s + 1, raw[(d + 1) % BL_DEPTH], lds + ((d + 1) & 1) * BL_PATCH);   // (after the last stage: into the buffer nobody reads any more)
-                issue(s + 1 + BL_DEPTH, raw[(d + 1) % BL_DEPTH]);
+                *reinterpret_cast<u32x4*>(Abuf + ((d + 1) & 1) * 512 + threadIdx.x) = wraw[(d + 1) % BL_DEPTH];
+                issue(s + 1 + BL_DEPTH, raw[(d + 1) % BL_DEPTH]); issue_w(s + 1 + BL_DEPTH, wraw[(d + 1) % BL_DEPTH]);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
