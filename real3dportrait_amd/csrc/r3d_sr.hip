@@ -175,6 +175,28 @@ __global__ __launch_bounds__(256) void chain_fold_kernel(ChainArgs a)
     // external bounds are read BEFORE the zero slots are cleared: a slot may be both (a fold that consumes a measured maximum and
     // re-arms the slot for the next frame's measurement, e.g. the f16mx tail fold)
     if (tid < a.next) extv[tid] = fabsf(a.ext[tid][n]);
+    // One load phase (round 6): the chain below is a sequence of DEPENDENT round trips (a layer's bound needs the previous layer's), two per SR layer and one per conv
+    // layer, each a cold miss after the convs in between have flushed the L2 -- 10 us for a three-conv + block chain, six folds per torso frame.  Every vector any op
+    // will read is touched here first, all loads independent and in flight together: the chain then runs on L2 hits.
+    {
+        float touch = 0.f;
+        for (int k = 0; k < a.nops; ++k) {
+            const r3d_chain_op& op = a.ops[k];
+            if (op.kind == R3D_CHAIN_SR_BLOCK || op.kind == R3D_CHAIN_SR_BLOCK_TAIL) {
+                const SrStyleLayout L = sr_style_layout(op.Cin, op.Cout);
+                const float* base = reinterpret_cast<const float*>(op.scales) + (size_t)n * L.total;
+                for (int i = tid; i < op.Cin; i += 256) touch += base[L.s0 + i];
+                for (int i = tid; i < op.Cout; i += 256)
+                    touch += base[L.s1 + i] + base[L.d0 + i] + base[L.d1 + i] + base[L.wi0 + i] + base[L.wi1 + i] + base[L.b0 + i] + base[L.b1 + i] + base[L.c0 + i] + base[L.c1 + i];
+            } else {
+                const int Ci = (op.Cin + 15) / 16 * 16, Co = (op.Cout + BLOCK_M - 1) / BLOCK_M * BLOCK_M;
+                const ConvTail T = conv_tail_layout(Co);
+                const float* tail = reinterpret_cast<const float*>(op.prepacked) + (size_t)(op.ksize * op.ksize) * Ci * Co;
+                for (int i = tid; i < Co; i += 256) touch += tail[T.winv + i] + tail[T.l1 + i] + (op.bias && i < op.Cout ? op.bias[i] : 0.f);
+            }
+        }
+        if (touch == 1.2345e-33f && a.nzero < 0) extv[0] = touch;     // (never true: keeps the loads)
+    }
     __syncthreads();
     if (tid < a.nzero) a.zero[tid][n] = 0.f;                  // absmax slots of the tensors the following kernels measure
     for (int k = 0; k < a.nops; ++k) {
