@@ -281,10 +281,25 @@ int r3d_conv_forward(const void* prepacked, const void* scales, const float* bia
  * twin in SuperresolutionHybrid8XDC_Warp.forward (modules/real3d/super_resolution/sr_with_ref.py:104,114,126,136).
  * y_split: [N][hi|lo][(Ca+Cb)/8][H][W][8] halfs, multiplied by next_scale ([N][Ca+Cb], the consumer's in-multiplier; NULL = 1);
  * y_format R3D_FMT_SPLIT, or R3D_FMT_SPLIT_MX (fp8 records in the lo plane) when the consumer runs the f16mx main loop (since 0.4.0).
- * Ca % 8 == Cb % 8 == 0, (Ca + Cb) % 16 == 0. */
+ * Ca % 8 == Cb % 8 == 0, (Ca + Cb) % 16 == 0.  b = NULL (since 0.6.1, Ca % 16 == 0): only the `a` part is written, the planes still hold
+ * (Ca + Cb) / 8 chunks -- the `b` part is the output of r3d_conv_forward_cat. */
 int r3d_blend_cat_to_split(const float* a, int a_format, int Ca, const float* b, int b_format, int Cb, const float* mask,
                            int N, int H, int W, void* y_split, int y_format, const float* next_scale, size_t next_scale_stride,
                            r3d_stream_t stream);
+
+/* A conv layer that writes its output as ONE PART of such a concatenation (since 0.6.1): channels [chan_off, chan_off + Cout) of the C_total-channel
+ * SPLIT / SPLIT_MX tensor y_cat [N][hi|lo][C_total/8][H][W][8], every value times mask (mask_invert = 0) or 1 - mask (1) of its pixel and the
+ * consumer's in-multiplier next_scale[chan_off + co] -- `x_torso = self.torso_encoder(hid)` followed by its half of
+ * `torch.cat([x * alpha, x_torso * (1 - alpha)], dim=1)` (sr_with_ref.py:88,104) without the fp32 x_torso in between; the other part comes from
+ * r3d_blend_cat_to_split called with b = NULL (which then writes only channels [0, Ca) of the Ca + Cb).  Bit-identical to the two-step form.
+ * ksize = 1 (the 3x3 kernels sit at their register limit and do not carry this epilogue); Cout, chan_off, C_total multiples of 16; other
+ * arguments as r3d_conv_forward (next_scale: the consumer's whole vector, indexed by the concatenated channel). */
+int r3d_conv_forward_cat(const void* prepacked, const void* scales, const float* bias,
+                         int N, int Cin, int Cout, int H, int W, int ksize,
+                         const void* x, int x_format, int act, float act_slope, float act_gain, float clamp,
+                         void* y_cat, int y_format, int C_total, int chan_off, const float* mask, int mask_invert,
+                         const float* next_scale, size_t next_scale_stride,
+                         void* workspace, size_t workspace_bytes, r3d_stream_t stream);
 
 /* The same blend + concatenation FUSED into the 1x1 conv that consumes it (since 0.6.1):
  *   y = act(conv_1x1(cat([a * mask, b * (1 - mask)], dim=1), W) + bias)

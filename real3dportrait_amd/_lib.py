@@ -22,6 +22,8 @@ SIGNATURES = {
     "r3d_last_error": (ctypes.c_char_p, []),
     "r3d_planes_to_nhwc": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, ctypes.POINTER(c_int), P]),
     "r3d_planes_absmax_partials": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "r3d_conv_forward_cat": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, c_int, c_int, c_float, c_float, c_float,
+                                     P, c_int, c_int, c_int, P, c_int, P, c_size_t, P, c_size_t, P]),
     "r3d_conv_forward_blend": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P, P, P, c_int, c_float, c_float, c_float,
                                        P, c_int, P, c_size_t, P, P]),
     "r3d_blend_cat_to_split": (c_int, [P, c_int, c_int, P, c_int, c_int, P, c_int, c_int, c_int, P, c_int, P, c_size_t, P]),

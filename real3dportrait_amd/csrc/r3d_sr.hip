@@ -859,6 +859,39 @@ extern "C" int r3d_conv_forward(const void* prepacked, const void* scales, const
                               workspace, (hipStream_t)stream);
 }
 
+extern "C" int r3d_conv_forward_cat(const void* prepacked, const void* scales, const float* bias,
+                                    int N, int Cin, int Cout, int H, int W, int ksize,
+                                    const void* x, int x_format, int act, float act_slope, float act_gain, float clamp,
+                                    void* y_cat, int y_format, int C_total, int chan_off, const float* mask, int mask_invert,
+                                    const float* next_scale, size_t next_scale_stride,
+                                    void* workspace, size_t workspace_bytes, r3d_stream_t stream)
+{
+    using namespace r3d;
+    if (!prepacked || !scales || !x || !y_cat || !mask || N <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) {
+        set_error("conv_forward_cat: bad argument"); return R3D_ERR_INVALID_ARG;
+    }
+    if (ksize != 1) { set_error("conv_forward_cat: ksize %d: only the 1x1 conv kernel carries the concatenation epilogue", ksize); return R3D_ERR_INVALID_ARG; }
+    if (y_format != R3D_FMT_SPLIT && y_format != R3D_FMT_SPLIT_MX) { set_error("conv_forward_cat: y_format %d must be SPLIT or SPLIT_MX", y_format); return R3D_ERR_INVALID_ARG; }
+    if ((Cout & 15) || (chan_off & 15) || (C_total & 15) || chan_off < 0 || chan_off + Cout > C_total) {
+        set_error("conv_forward_cat: Cout %d, chan_off %d, C_total %d must be multiples of 16 with chan_off + Cout <= C_total", Cout, chan_off, C_total); return R3D_ERR_INVALID_ARG;
+    }
+    if (x_format < R3D_FMT_NCHW || x_format > R3D_FMT_SPLIT_MX || (x_format == R3D_FMT_SPLIT_MX && (ksize != 3 || (Cin & 15))) || (x_format != R3D_FMT_NCHW && (Cin & 15))) {
+        set_error("conv_forward_cat: unsupported input (format %d, Cin %d)", x_format, Cin); return R3D_ERR_INVALID_ARG;
+    }
+    {
+        const size_t cmax = (size_t)((Cin > C_total ? Cin : C_total) + BLOCK_M);
+        if (cmax * H * W >= ((size_t)1 << 32)) { set_error("conv_forward_cat: activation of %zu elements per sample exceeds the 32-bit index range", cmax * H * W); return R3D_ERR_INVALID_ARG; }
+    }
+    if (x_format < R3D_FMT_SPLIT && (!workspace || workspace_bytes < r3d_conv_workspace_bytes(N, Cin, H, W))) {
+        set_error("conv_forward_cat: workspace too small"); return R3D_ERR_WORKSPACE;
+    }
+    const size_t stride = conv_scales_layout((Cin + 15) / 16 * 16, (Cout + BLOCK_M - 1) / BLOCK_M * BLOCK_M).total;
+    const ConvCat cat = {mask, mask_invert ? 1 : 0, C_total, chan_off};
+    return conv_forward_f16x3(prepacked, reinterpret_cast<const float*>(scales), stride, bias, N, Cin, Cout, H, W, ksize, x, x_format,
+                              act, act_slope, act_gain, clamp, y_cat, y_format, next_scale, next_scale_stride, nullptr,
+                              workspace, (hipStream_t)stream, &cat);
+}
+
 extern "C" int r3d_conv_forward_blend(const void* prepacked, const void* scales, const float* bias,
                                       int N, int Ca, int Cb, int Cout, int H, int W,
                                       const float* a, const float* b, const float* mask,
@@ -900,10 +933,10 @@ extern "C" int r3d_blend_cat_to_split(const float* a, int a_format, int Ca, cons
 {
     if (y_format != R3D_FMT_SPLIT && y_format != R3D_FMT_SPLIT_MX) { set_error("blend_cat_to_split: y_format %d must be SPLIT or SPLIT_MX", y_format); return R3D_ERR_INVALID_ARG; }
     using namespace r3d;
-    if (!a || !b || !mask || !y_split || N <= 0 || H <= 0 || W <= 0 || Ca <= 0 || Cb <= 0 || (Ca & 7) || (Cb & 7) || ((Ca + Cb) & 15)) {
-        set_error("blend_cat_to_split: bad argument (Ca %d, Cb %d: multiples of 8, sum a multiple of 16)", Ca, Cb); return R3D_ERR_INVALID_ARG;
+    if (!a || !mask || !y_split || N <= 0 || H <= 0 || W <= 0 || Ca <= 0 || Cb <= 0 || (Ca & 7) || (Cb & 7) || ((Ca + Cb) & 15) || (!b && (Ca & 15))) {
+        set_error("blend_cat_to_split: bad argument (Ca %d, Cb %d: multiples of 8, sum a multiple of 16; b = NULL needs Ca %% 16 == 0)", Ca, Cb); return R3D_ERR_INVALID_ARG;
     }
-    if ((a_format != R3D_FMT_NCHW && a_format != R3D_FMT_CB8) || (b_format != R3D_FMT_NCHW && b_format != R3D_FMT_CB8)) {
+    if ((a_format != R3D_FMT_NCHW && a_format != R3D_FMT_CB8) || (b && b_format != R3D_FMT_NCHW && b_format != R3D_FMT_CB8)) {
         set_error("blend_cat_to_split: inputs must be NCHW or CB8 (a %d, b %d)", a_format, b_format); return R3D_ERR_INVALID_ARG;
     }
     return blend_cat_to_split_f16x3(a, a_format, Ca, b, b_format, Cb, mask, N, H, W, y_split, y_format, next_scale, next_scale_stride, (hipStream_t)stream);

@@ -105,11 +105,13 @@ int sr_block_forward_f16x3(const void* prepacked, const void* styles, int N, int
 size_t conv_prepacked_bytes_f16x3(int Cin, int Cout, int ksize);
 int conv_prepack_f16x3(const float* w, int Cin, int Cout, int ksize, void* prepacked, hipStream_t st);
 size_t conv_workspace_bytes_f16x3(int N, int Cin, int H, int W);
+// the conv's SPLIT output as one part of a channel concatenation (r3d_conv_forward_cat): channels [chan_off, chan_off + Cout) of C_total, times mask or 1 - mask per pixel
+struct ConvCat { const float* mask; int mask_invert; int C_total; int chan_off; };
 int conv_forward_f16x3(const void* prepacked, const float* scales, size_t scales_stride, const float* bias,
                        int N, int Cin, int Cout, int H, int W, int ksize,
                        const void* x, int x_format, int act, float slope, float gain, float clamp,
                        void* y, int y_format, const float* next_scale, size_t next_scale_stride, float* y_absmax,
-                       void* workspace, hipStream_t st);
+                       void* workspace, hipStream_t st, const ConvCat* cat = nullptr);
 
 int conv_forward_blend_f16x3(const void* prepacked, const float* scales, size_t scales_stride, const float* bias,
                              int N, int Ca, int Cb, int Cout, int H, int W, const float* xa, const float* xb, const float* mask,

@@ -268,6 +268,10 @@ struct Conv2Args {
     float* y_nchw; size_t y_nchw_stride_n;                 // fp32 NCHW output or null
     uint4* y_split; size_t y_split_stride_n;               // SPLIT output scaled by next_scale (null = 1), or null
     int y_split_mx;                                        // 1: the lo plane of y_split holds fp8 records (R3D_FMT_SPLIT_MX) for an f16mx consumer
+    // y_split as ONE PART of a channel concatenation (r3d_conv_forward_cat, round 6): the destination has y_cat_chunks 8-channel chunks per plane (0 = this conv's
+    // own Cout / 8), this conv's couts start at chunk y_cat_off (even), and every value is multiplied by its pixel's y_mask (or 1 - y_mask) before the
+    // consumer's multiplier -- `torch.cat([.., x_torso * (1 - alpha)], dim=1)` written by the conv that produces x_torso
+    const float* y_mask; int y_mask_invert; int y_cat_chunks, y_cat_off;
     const float* next_scale; size_t next_scale_stride_n;
     unsigned* y_absmax;                                    // [N] max |activated output| (uint bits of a non-negative float) or null
     const float* wrgb; size_t wrgb_stride_n; float* rgb_partial; size_t rgbp_stride_n;   // toRGB partials [Cout/128][3][OH*OW] or null
@@ -296,7 +300,7 @@ static constexpr int EV_STRIDE = BLOCK_M;              // floats per staged vect
 #endif
 // PIXMAP = 1 (experiment): acc[mt][nt] holds column parity nt of the column pairs -- lane li <-> (row 4 wn + li / 8, columns 2 (li % 8) + nt).
 // PIXMAP != 0 (conv_wino_f16x3_kernel): the accumulators carry the transformed operands' factor 1/4 (r3d_sr_wino.h); 2 = the ordinary pixel map.
-template <bool FULL_EPI, int WN, int NT, int PIXMAP = 0>
+template <bool FULL_EPI, int WN, int NT, int PIXMAP = 0, bool CAT = false>     // CAT: the concatenation-part output (y_mask, y_cat_*) is compiled in -- the 1x1 conv only: the 3x3 kernels sit at their register limit
 __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhase& ph, int n, f32x16 (&acc)[2][NT],
                                               int i0, int j0, int m0, float* ev)
 {
@@ -332,7 +336,7 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
     float rgbp[NT][3];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) { rgbp[nt][0] = 0.f; rgbp[nt][1] = 0.f; rgbp[nt][2] = 0.f; }
-    const size_t oplane = (size_t)(a.CoutReal >> 3) * a.OH * a.OW;
+    const size_t oplane = (size_t)(CAT && a.y_cat_chunks ? a.y_cat_chunks : a.CoutReal >> 3) * a.OH * a.OW;
     // Address arithmetic in 32 bits with the per-channel-plane part on the scalar unit: plane index and plane stride are wave-uniform,
     // the pixel offset is computed once per N tile (the 64-bit multiplies per store group were a third of the epilogue's VALU cycles).
     // host: (Cout/8) * OH * OW * 8 < 2^32 for every layer that gets here (checked in launch_conv2)
@@ -348,7 +352,18 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
     }
     float* Yf = a.y_f32 ? a.y_f32 + (size_t)n * a.y_f32_stride_n + ph.out_off : nullptr;
     float* Yn = (FULL_EPI && a.y_nchw) ? a.y_nchw + (size_t)n * a.y_nchw_stride_n : nullptr;
-    uint4* Ys = (FULL_EPI && a.y_split) ? a.y_split + (size_t)n * a.y_split_stride_n : nullptr;
+    uint4* Ys = (FULL_EPI && a.y_split) ? a.y_split + (size_t)n * a.y_split_stride_n + (CAT ? (size_t)a.y_cat_off * a.OH * a.OW : 0) : nullptr;   // (y_cat_off even: record pairs stay aligned)
+    float ym[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) ym[nt] = 1.f;
+    const bool masked = CAT && FULL_EPI && a.y_mask != nullptr;
+    if (masked) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float mk = inside_nt[nt] ? a.y_mask[(size_t)n * cs + p0[nt]] : 0.f;
+            ym[nt] = a.y_mask_invert ? 1.0f - mk : mk;
+        }
+    }
     const bool want_max = FULL_EPI && a.y_absmax != nullptr;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
@@ -403,7 +418,7 @@ __device__ __forceinline__ void conv_epilogue(const Conv2Args& a, const ConvPhas
                     float lf[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float sv_ = as_rounded(v[r] * sv[r]);
+                        const float sv_ = as_rounded(masked ? v[r] * ym[nt] * sv[r] : v[r] * sv[r]);      // (blend_cat_to_split_kernel's order: the same bits)
                         const _Float16 x0 = (_Float16)sv_;
                         lf[r] = sv_ - (float)x0;
                         hi[r] = x0; lo[r] = (_Float16)lf[r];
@@ -667,7 +682,7 @@ __device__ __forceinline__ void conv2_block(const Conv2Args& a, const ConvPhase&
         }
     }
     __syncthreads();
-    conv_epilogue<FULL_EPI, WN, NT>(a, ph, n, acc, i0, j0, m0, reinterpret_cast<float*>(lds));
+    conv_epilogue<FULL_EPI, WN, NT, 0, NTAPS == 1>(a, ph, n, acc, i0, j0, m0, reinterpret_cast<float*>(lds));
 }
 
 // ---- plain 3x3 conv, LDS-DMA pipeline ------------------------------------------------------------------------------
@@ -1775,7 +1790,8 @@ int blend_cat_to_split_f16x3(const float* a, int a_format, int Ca, const float* 
                              int N, int H, int W, void* y_split, int y_format, const float* next_scale, size_t next_scale_stride, hipStream_t st)
 {
     ProfScope ps(R3D_PROF_LAYOUT, st);
-    hipLaunchKernelGGL(blend_cat_to_split_kernel, dim3((H * W + 255) / 256, (Ca + Cb) / 8, N), dim3(256), 0, st,
+    // b == nullptr: only the `a` part is written (the other part comes from r3d_conv_forward_cat); the planes still hold (Ca + Cb) / 8 chunks
+    hipLaunchKernelGGL(blend_cat_to_split_kernel, dim3((H * W + 255) / 256, (b ? Ca + Cb : Ca) / 8, N), dim3(256), 0, st,
                        a, a_format == R3D_FMT_CB8 ? 1 : 0, Ca, b, b_format == R3D_FMT_CB8 ? 1 : 0, Cb, mask,
                        reinterpret_cast<uint4*>(y_split), H * W, next_scale, next_scale_stride, y_format == R3D_FMT_SPLIT_MX ? 1 : 0);
     return check_launch("blend_cat_to_split");
@@ -2118,7 +2134,7 @@ int conv_forward_f16x3(const void* prepacked, const float* scales, size_t scales
                        int N, int Cin, int Cout, int H, int W, int ksize,
                        const void* x, int x_format, int act, float slope, float gain, float clamp,
                        void* y, int y_format, const float* next_scale, size_t next_scale_stride, float* y_absmax,
-                       void* workspace, hipStream_t st)
+                       void* workspace, hipStream_t st, const ConvCat* cat)
 {
     const int Ci = pad_to(Cin, 16), Co = pad_to(Cout, BLOCK_M);
     const ConvScales S = conv_scales_layout(Ci, Co);
@@ -2140,7 +2156,12 @@ int conv_forward_f16x3(const void* prepacked, const float* scales, size_t scales
     if (y_format == R3D_FMT_CB8) { a.y_f32 = reinterpret_cast<float*>(y); a.y_f32_stride_n = (size_t)Cout * H * W; }
     else if (y_format == R3D_FMT_NCHW) { a.y_nchw = reinterpret_cast<float*>(y); a.y_nchw_stride_n = (size_t)Cout * H * W; }
     else { a.y_split = reinterpret_cast<uint4*>(y); a.y_split_stride_n = (size_t)Cout / 8 * H * W * 2; a.next_scale = next_scale; a.next_scale_stride_n = next_scale_stride;
-           a.y_split_mx = y_format == R3D_FMT_SPLIT_MX ? 1 : 0; }
+           a.y_split_mx = y_format == R3D_FMT_SPLIT_MX ? 1 : 0;
+           if (cat) {      // y is the whole concatenated tensor [N][hi|lo][C_total / 8][H][W][8]; next_scale the consumer's whole in-multiplier vector
+               a.y_split_stride_n = (size_t)cat->C_total / 8 * H * W * 2; a.y_cat_chunks = cat->C_total / 8; a.y_cat_off = cat->chan_off / 8;
+               a.y_mask = cat->mask; a.y_mask_invert = cat->mask_invert;
+               if (next_scale) a.next_scale = next_scale + cat->chan_off;
+           } }
     a.y_absmax = reinterpret_cast<unsigned*>(y_absmax);
     a.Cin = Ci; a.Cout = Co; a.CoutReal = Cout; a.H = H; a.W = W; a.nphase = 1;
     a.act = act; a.act_slope = slope; a.act_gain = gain; a.clamp = clamp;

@@ -27,6 +27,8 @@ import os
 _HB_TAIL_FOLD = os.environ.get("R3D_HB_TAIL_FOLD", "0") == "1"
 # A/B switch: 0 = person / background blend written as a SPLIT tensor (r3d_blend_cat_to_split) and read back by fuse_fg_bg_convs' 1x1 conv (rounds 2-5)
 _FUSE_BLEND = os.environ.get("R3D_FUSE_BLEND", "1") != "0"
+# A/B switch: 0 = torso_encoder writes the fp32 x_torso and r3d_blend_cat_to_split reads it back (rounds 2-5)
+_FUSE_TORSO_CAT = os.environ.get("R3D_FUSE_TORSO_CAT", "1") != "0"
 
 
 def blend(a, b, mask):
@@ -219,19 +221,40 @@ def _forward_v2(self, S, rgb, x, ws, ref_torso_rgb, ref_bg_rgb, weights_img, seg
     else:
         rgb_torso, ret = self.torso_model.forward(ref_torso_rgb_256, segmap, kp_s, kp_d, rgb_256.detach(), weights_256.detach(),
                                                   cal_loss=True, target_torso_mask=target_torso_mask)
-    x_torso = self.torso_encoder(ret["deformed_torso_hid"], out_format="cb8")                          # :88 (1x1 conv, measured input)
+    hid = ret["deformed_torso_hid"]
+    te = self.torso_encoder._plan() if _FUSE_TORSO_CAT else ()
+    fuse_cat = len(te) == 1 and te[0][0].kernel_size[0] == 1 and te[0][0].out_channels % 16 == 0 and getattr(x0, "_r3d_fmt", None) == "cb8" \
+        and x0.shape[1] % 2 == 0 and getattr(hid, "_r3d_fmt", "nchw") == "nchw"
+    if not fuse_cat:
+        x_torso = self.torso_encoder(hid, out_format="cb8")                                            # :88 (1x1 conv, measured input)
     x_bg = S.c_xbg.get(ref_bg_rgb, lambda _: _measured(self.bg_encoder(ref_bg_rgb_256, out_format="cb8"), S))   # :90 (clip constant)
 
     # ---- head / torso fusion (:99-105) -----------------------------------------------------------------------------------------------
     alpha = weights_256                                   # `head_torso_alpha[head_torso_alpha > weights_256] = ...` (:101-102) is a no-op
     rgb1 = blend(rgb0, rgb_torso, alpha)                                                                # :103
     preph = hb.prepare(ws3, dev, ws_key=ws)
-    ops, head, last = fuse_ht.chain_ops(N, dev, -1, -2, base=0)
-    if _HB_TAIL_FOLD:
-        chain_fold(ops + [hb.chain_op(last)], N, [m_x0, bound_of(x_torso, S.meter_hid, 3)[0]], zero=[m_y])
-    else:       # round 5: head_torso_block's conv1 operand is three layers from the measured max|x0| (= MAX_DEPTH): no tail fold, no max|y| measurement
-        chain_fold(ops + [hb.chain_op(last)], N, [m_x0, bound_of(x_torso, S.meter_hid, 3)[0]], zero=[m_x2])
-    xs = blend_cat(x0, x_torso, alpha, fuse_ht, _folded_head=head)                                      # :104
+    if fuse_cat:
+        # torso_encoder writes its half of :104's concatenation itself (r3d_conv_forward_cat): x_torso * (1 - alpha), times fuse_head_torso_convs' in-multiplier,
+        # split -- the fp32 x_torso (67 MB written, 67 MB read back by blend_cat) does not exist.  The consumer's fold therefore runs BEFORE the producer, in one
+        # chain with it: op 0 = torso_encoder (bound of its output = what its tag carried), op 1.. = the fusion stack reading (max|x0|, op 0).  Same bits.
+        tconv, tslope, _ = te[0]
+        hid = _keep_tags(hid)
+        tconv.prepare(N, dev)
+        bh, dh = bound_of(hid, S.meter_hid, 1)
+        tconv._depth_in = dh
+        ops, head, last = fuse_ht.chain_ops(N, dev, -2, 0, base=1)
+        chain_fold([tconv.chain_op(-1, negative_slope=tslope)] + ops + [hb.chain_op(last)], N, [bh, m_x0], zero=[m_y] if _HB_TAIL_FOLD else [m_x2])
+        fmt = "split_mx" if head.wants_mx() else "split"
+        Ca, Cb = x0.shape[1] * 8, tconv.out_channels
+        xs = torch.empty(N, 2, (Ca + Cb) // 8, x0.shape[2], x0.shape[3], 8, device=dev, dtype=torch.float16)
+        xs._r3d_fmt, xs._r3d_for = fmt, head
+        tconv.forward_cat(hid, xs, Ca, alpha, True, head, negative_slope=tslope)
+        blend_cat(x0, None, alpha, fuse_ht, _folded_head=head, _b_channels=Cb, _dst=xs)
+    else:
+        ops, head, last = fuse_ht.chain_ops(N, dev, -1, -2, base=0)
+        # round 5: head_torso_block's conv1 operand is three layers from the measured max|x0| (= MAX_DEPTH): no tail fold, no max|y| measurement (zero = the next slot)
+        chain_fold(ops + [hb.chain_op(last)], N, [m_x0, bound_of(x_torso, S.meter_hid, 3)[0]], zero=[m_y] if _HB_TAIL_FOLD else [m_x2])
+        xs = blend_cat(x0, x_torso, alpha, fuse_ht, _folded_head=head)                                  # :104
     y = fuse_ht(xs, out_format="split_mx" if hb.wants_mx() else "split", _next=hb, _y_absmax=m_y if _HB_TAIL_FOLD else None)       # :105
     if _HB_TAIL_FOLD:
         chain_fold([hb.chain_op(-1, tail=True)], N, [m_y], zero=[m_x2])

@@ -515,6 +515,25 @@ class Conv2d(nn.Module):
                                         _lib.ptr(work), need if work is not None else 0, st), "conv_forward")
         return self._tag_out(y, out_format, _next, N)
 
+    def forward_cat(self, x, dst, chan_off, mask, mask_invert, _next, negative_slope=None):
+        """This (already folded) 1x1 conv's output as channels [chan_off, chan_off + out_channels) of the concatenated SPLIT / SPLIT_MX tensor `dst`
+        ([N, 2, C_total / 8, H, W, 8] halfs, tagged `_r3d_fmt`), times mask (or 1 - mask) per pixel and the in-multiplier of `_next`, the consumer of
+        `dst` (r3d_conv_forward_cat): `x_torso = torso_encoder(hid)` + its half of `cat([x * a, x_torso * (1 - a)])` (sr_with_ref.py:88,104)."""
+        lib = _lib.load()
+        x_fmt = getattr(x, "_r3d_fmt", "nchw")
+        assert x_fmt in ("nchw", "cb8") and self.kernel_size[0] == 1, "forward_cat: a 1x1 conv over an fp32 input"
+        x = _f32c(x)
+        N, C, H, W = self._shape(x, x_fmt)
+        assert C == self.in_channels and tuple(dst.shape[:2]) == (N, 2) and tuple(dst.shape[3:]) == (H, W, 8) and tuple(mask.shape) == (N, 1, H, W)
+        need = int(lib.r3d_conv_workspace_bytes(N, C, H, W))
+        work = self._buf("_workspace", need, x.device)
+        ns, stride = _next.in_scale()
+        _lib.check(lib.r3d_conv_forward_cat(_lib.ptr(self._prepacked), _lib.ptr(self._scales), _lib.ptr(self._bias32), N, C, self.out_channels, H, W, 1,
+                                            _lib.ptr(x), self._FMT[x_fmt], 0 if negative_slope is None else 1, float(negative_slope or 0.0), 1.0, -1.0,
+                                            _lib.ptr(dst), self._FMT[dst._r3d_fmt], dst.shape[2] * 8, chan_off, _lib.ptr(_f32c(mask)), int(bool(mask_invert)),
+                                            _lib.ptr(ns), stride, _lib.ptr(work), need, _lib.stream_ptr()), "conv_forward_cat")
+        return dst
+
     def _alloc_out(self, N, H, W, out_format, _next, dev):
         Cout = self.out_channels
         next_scale, next_stride = None, 0
@@ -578,8 +597,9 @@ def resize_bilinear(x, size, antialias=True):
 _BLEND_METERS = {}
 
 
-def blend_cat(a, b, mask, consumer, ws=None, _folded_head=None):
-    """cat([a * mask, b * (1 - mask)], dim=1) (sr_with_ref.py:104,114,126,136) written directly as the SPLIT input of
+def blend_cat(a, b, mask, consumer, ws=None, _folded_head=None, _b_channels=None, _dst=None):
+    """(b = None with _b_channels = Cb and _dst = the concatenated tensor: only the `a` part is written; Conv2d.forward_cat fills channels [Ca, Ca + Cb).)
+    cat([a * mask, b * (1 - mask)], dim=1) (sr_with_ref.py:104,114,126,136) written directly as the SPLIT input of
     `consumer` (a ConvStack / Conv2d / SynthesisBlock[NoUp]; for a block pass its `ws` [N,3,w_dim]): the consumer chain is folded
     here from max(bound(a), bound(b)) (mask in [0,1]), then r3d_blend_cat_to_split multiplies by its in-multiplier.
     a, b: NCHW fp32 or 'cb8'-tagged tensors; mask [N,1,H,W].  _folded_head: the consumer's first module when the caller has
@@ -594,7 +614,11 @@ def blend_cat(a, b, mask, consumer, ws=None, _folded_head=None):
             return t, 0, t.shape[1], t.shape[0], t.shape[2], t.shape[3]
         return t, 1, t.shape[1] * 8, t.shape[0], t.shape[2], t.shape[3]
     a, fa, Ca, N, H, W = desc(a)
-    b, fb, Cb, Nb, Hb, Wb = desc(b)
+    if b is None:
+        assert _folded_head is not None and _b_channels
+        fb, Cb, Nb, Hb, Wb = 0, int(_b_channels), N, H, W
+    else:
+        b, fb, Cb, Nb, Hb, Wb = desc(b)
     mask = _f32c(mask)
     assert (N, H, W) == (Nb, Hb, Wb) and tuple(mask.shape) == (N, 1, H, W), (a.shape, b.shape, mask.shape)
     if _folded_head is not None:
@@ -605,7 +629,8 @@ def blend_cat(a, b, mask, consumer, ws=None, _folded_head=None):
         (ba, da), (bb, db) = bound_of(a, meters[0], L), bound_of(b, meters[1], L)
         head = consumer.fold_for_input(N, a.device, [ba, bb], ws=ws, depth=max(da, db))
     ns, stride = head.in_scale()
-    y = torch.empty(N, 2, (Ca + Cb) // 8, H, W, 8, device=a.device, dtype=torch.float16)
+    y = _dst if _dst is not None else torch.empty(N, 2, (Ca + Cb) // 8, H, W, 8, device=a.device, dtype=torch.float16)
+    assert tuple(y.shape) == (N, 2, (Ca + Cb) // 8, H, W, 8) and y.is_contiguous()
     fmt = "split_mx" if head.wants_mx() else "split"       # an f16mx consumer: fp8 records in the lo plane
     _lib.check(lib.r3d_blend_cat_to_split(_lib.ptr(a), fa, Ca, _lib.ptr(b), fb, Cb, _lib.ptr(mask), N, H, W, _lib.ptr(y), SynthesisBlock._FMT[fmt],
                                           _lib.ptr(ns), stride, _lib.stream_ptr()), "blend_cat_to_split")

@@ -95,6 +95,40 @@ def test_blend_conv_inside_a_stack_feeds_the_next_layer(torch_cuda):
         assert e <= tol, prec
 
 
+@pytest.mark.parametrize("prec,N,Cin,Ca,Cb,H,W", [("f16x3", 1, 64, 256, 256, 64, 48), ("f16mx", 1, 64, 256, 256, 64, 48), ("f16mx", 2, 24, 32, 48, 37, 21), ("f16x3", 3, 16, 16, 128, 16, 20)])
+def test_conv_into_concatenation_bit_identical_to_two_steps(torch_cuda, prec, N, Cin, Ca, Cb, H, W):
+    """r3d_conv_forward_cat (the 1x1 torso_encoder writes `x_torso * (1 - alpha)` as the second part of the concatenated SPLIT / SPLIT_MX operand) +
+    r3d_blend_cat_to_split(b = NULL) (the first part) against conv -> fp32 -> r3d_blend_cat_to_split: every byte of both planes equal -- hi words, lo words or
+    e5m2 records -- on whole and ragged tiles, batches, Cout one / two cout blocks."""
+    torch = torch_cuda
+    from real3dportrait_amd import synth
+    from real3dportrait_amd.superresolution import Conv2d, blend_cat, chain_fold
+    hid = T(torch, synth.hash_unitvar(51, (N, Cin, H, W), stream=1) * np.float32(3.0))
+    a = T(torch, synth.hash_unitvar(51, (N, Ca, H, W), stream=2))
+    m = T(torch, np.abs(synth.hash_unitvar(51, (N, 1, H, W), stream=3)).clip(0, 1))
+    tconv, head = Conv2d(Cin, Cb, 1, 1, padding=0).cuda(), Conv2d(Ca + Cb, 32, 3, 1, padding=1).cuda()
+    tconv.precision = head.precision = prec
+    with torch.no_grad():
+        tconv.weight.copy_(T(torch, synth.hash_unitvar(51, (Cb, Cin, 1, 1), stream=4) / np.float32(np.sqrt(Cin))))
+        tconv.bias.copy_(T(torch, synth.hash_unitvar(51, (Cb,), stream=5)))
+    a8 = _cb8(torch, a)
+    tconv.prepare(N, hid.device); head.prepare(N, hid.device)
+    tconv._depth_in = head._depth_in = 0
+    bh = hid.abs().amax(dim=(1, 2, 3)).contiguous()
+    chain_fold([tconv.chain_op(-1), head.chain_op(-2, 0)], N, [bh, a8._r3d_bound])
+    xt = tconv(hid, out_format="cb8", _folded=True)
+    ref = blend_cat(a8, xt, m, head, _folded_head=head)
+    xs = torch.full((N, 2, (Ca + Cb) // 8, H, W, 8), float("nan"), device=hid.device, dtype=torch.float16)
+    xs._r3d_fmt, xs._r3d_for = ref._r3d_fmt, head
+    assert ref._r3d_fmt == ("split_mx" if prec == "f16mx" else "split")
+    tconv.forward_cat(hid, xs, Ca, m, True, head)
+    blend_cat(a8, None, m, head, _folded_head=head, _b_channels=Cb, _dst=xs)
+    torch.cuda.synchronize()
+    same = torch.equal(xs.view(torch.int16), ref.view(torch.int16))
+    print("conv into the concatenation (%s) N=%d %d -> %d + %d, %dx%d: %s" % (prec, N, Cin, Ca, Cb, H, W, "every byte equal" if same else "DIFFERENT"))
+    assert same
+
+
 def test_blend_conv_argument_errors(torch_cuda):
     """The C ABI refuses what the kernel does not cover (a channel sum that is not a multiple of 64, a missing pointer) with R3D_ERR_INVALID_ARG and a message."""
     torch = torch_cuda

@@ -39,6 +39,36 @@ def test_warp_sr_forward_v2_golden():
     assert not torch.equal(out2, outs[0])
 
 
+@pytest.mark.parametrize("prec", ["f16mx", "f16x3"])
+def test_warp_sr_forward_v2_round6_fusions_are_bit_identical(prec):
+    """Round 6 moved two blend + concatenation steps into the convs next to them: torso_encoder writes its half of :104's operand itself
+    (r3d_conv_forward_cat, R3D_FUSE_TORSO_CAT) and fuse_fg_bg_convs' 1x1 conv computes :113's operand while it stages it (r3d_conv_forward_blend,
+    R3D_FUSE_BLEND).  Same arithmetic in the same order: the fused forward's image equals the round-5 sequence bit for bit, at both precisions."""
+    import torch
+    import warp_mock
+    from real3dportrait_amd import sr_with_ref
+    g = load_golden("warp_sr_a")
+    i = {k: T(torch, v) for k, v in warp_mock.warp_inputs().items()}
+    outs = {}
+    saved = (sr_with_ref._FUSE_TORSO_CAT, sr_with_ref._FUSE_BLEND)
+    try:
+        for cat, bl in ((True, True), (False, False), (True, False), (False, True)):
+            sr_with_ref._FUSE_TORSO_CAT, sr_with_ref._FUSE_BLEND = cat, bl
+            sr = sr_with_ref.SuperresolutionHybrid8XDC_Warp(32, 512, 0, True, torso_model=warp_mock.MockTorso(),
+                                                            hparams={"htbsr_head_threshold": float(g["threshold"])}).cuda()
+            warp_mock.load_warp_params(sr, lambda blk, p: load_block(torch, blk, p), to=lambda a: T(torch, a))
+            sr.set_sr_precision(prec) if hasattr(sr, "set_sr_precision") else None
+            for m in sr.modules():
+                if hasattr(m, "precision"):
+                    m.precision = prec
+            out, _ = sr(i["x"][:, :3].contiguous(), i["x"], i["ws"], i["ref_torso_rgb"], i["ref_bg_rgb"], i["weights_img"], None, None, None, noise_mode="none")
+            outs[(cat, bl)] = out.clone()
+    finally:
+        sr_with_ref._FUSE_TORSO_CAT, sr_with_ref._FUSE_BLEND = saved
+    for k, v in outs.items():
+        assert torch.equal(v, outs[(False, False)]), (prec, k, float((v - outs[(False, False)]).abs().max()))
+
+
 def test_warp_sr_two_stage_entry_golden():
     """The reference's two-stage entry (sr_with_ref.py:164-218: infer_forward_stage1 -> infer_forward_stage2, unused by real3d_infer.py) on the
     mirror class against the reference's own outputs (tests/golden/warp_sr_two_stage_a.npz): block0's x, the dict's keys, the final image."""
