@@ -737,7 +737,7 @@ class ConvStack(nn.Sequential):
         dx = int(getattr(x, "_r3d_depth", 0))
         if _blend is not None:
             assert x is None
-            dx = max(int(getattr(_blend[0], "_r3d_depth", 0)), int(getattr(_blend[1], "_r3d_depth", 0)))
+            dx = 0            # as for blend_cat's untagged SPLIT output: the caller folded the stack from the sources' bounds
         elif x_fmt in ("split", "split_mx"):
             if getattr(x, "_r3d_for", None) is not plan[0][0]:
                 raise RuntimeError("SPLIT activation was scaled for a different consumer")
