@@ -391,11 +391,18 @@ __device__ __forceinline__ void split8_bounded(const float (&x)[8], h8& hi, h8& 
 // hi*hi + hi*lo + lo*hi accumulated in fp32; same scheme and probe as csrc/r3d_sr_f16x3.hip): K = 32 per MFMA, so
 // layer 1 (32 channels) is one k-step and layer 2 (64 hidden) two -> 24 MFMAs per 16-sample tile instead of 64
 // v_mfma_f32_16x16x4_f32 at half the issue cost each.
+#ifndef R3D_RAY_L2_F32
+#define R3D_RAY_L2_F32 0       // experiment (round 6): layer 2 on v_mfma_f32_16x16x4_f32 -- no hi/lo split of the 64 hidden values, 32 MFMAs of 32 cycles instead of 12 of 16
+#endif
 struct DecoderLds {
     uint4 w1f[4][2][64];       // [mt][hi|lo][lane]    A frag: W1'[16mt+(l&15)][8(l>>4)+j], j = 0..7
+#if R3D_RAY_L2_F32
+    float4 w2g[2][4][64];      // [ot][mt][lane]       A values of the four K = 4 steps r = 0..3 of hidden tile mt: W2'[1+16ot+(l&15)][16mt + 4(l>>4) + r]
+#else
     uint4 w2f[2][2][2][64];    // [ot][p][hi|lo][lane] A frag: W2'[1+16ot+(l&15)][u(p, l>>4, j)],
                                //   u(p,q,j) = 16(2p + (j>>2)) + 4q + (j&3): the hidden unit that accumulator register
                                //   (mt = 2p + (j>>2), reg = j&3) of k-slot q holds after layer 1
+#endif
     float w2s[kHid];           // W2'[0][:]  (density row, evaluated on the VALU)
     float b1[kHid];
     float b2[kOut];            // b2[0] density bias, b2[1..32] colour biases (times 2^-d, see DecFold)
@@ -424,6 +431,13 @@ __device__ __forceinline__ void stage_decoder(DecoderLds& L, const float* __rest
         h8 hi, lo; split8(v, hi, lo);
         L.w1f[mt][0][l] = *reinterpret_cast<uint4*>(&hi); L.w1f[mt][1][l] = *reinterpret_cast<uint4*>(&lo);
     }
+#if R3D_RAY_L2_F32
+    for (int i = threadIdx.x; i < 2 * 4 * 64; i += blockDim.x) {
+        const int l = i & 63, mt = (i >> 6) & 3, ot = i >> 8;
+        const float* r = w2 + (1 + 16 * ot + (l & 15)) * kHid + 16 * mt + 4 * (l >> 4);
+        L.w2g[ot][mt][l] = make_float4(r[0] * g2c, r[1] * g2c, r[2] * g2c, r[3] * g2c);
+    }
+#else
     for (int i = threadIdx.x; i < 2 * 2 * 64; i += blockDim.x) {
         const int l = i & 63, pp = (i >> 6) & 1, ot = i >> 7;
         float v[8];
@@ -433,6 +447,7 @@ __device__ __forceinline__ void stage_decoder(DecoderLds& L, const float* __rest
         h8 hi, lo; split8(v, hi, lo);
         L.w2f[ot][pp][0][l] = *reinterpret_cast<uint4*>(&hi); L.w2f[ot][pp][1][l] = *reinterpret_cast<uint4*>(&lo);
     }
+#endif
     for (int i = threadIdx.x; i < kHid; i += blockDim.x) { L.w2s[i] = w2[i] * (g2 * kLn2); L.b1[i] = b1[i] * kLog2e; }
     for (int i = threadIdx.x; i < kOut; i += blockDim.x) L.b2[i] = i == 0 ? b2[i] : b2[i] * kLog2e * F.b2s;
     if (threadIdx.x == 0) { L.xs3 = F.xs * (1.0f / 3.0f); L.hs = F.hs; L.ys = F.ys; }
@@ -641,6 +656,20 @@ __device__ __forceinline__ void decode_l2(const DecoderLds& L, int lane, const D
             col[ot][2] = L.b2[1 + 16 * ot + 4 * q + 2]; col[ot][3] = L.b2[1 + 16 * ot + 4 * q + 3];
         }
     }
+#if R3D_RAY_L2_F32
+    // K = 4 per MFMA: step (mt, r) multiplies hidden units 16 mt + 4 q + r (k-slot q = this lane's accumulator register r of tile mt) -- the fp32 values as they are;
+    // the two colour tiles alternate so that a dependent accumulate is two issue slots away
+#pragma unroll
+    for (int mt = 2 * PP; mt < 2 * PP + 2; ++mt) {
+        const float4 a0 = L.w2g[0][mt][lane], a1 = L.w2g[1][mt][lane];
+        const float A0[4] = {a0.x, a0.y, a0.z, a0.w}, A1[4] = {a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            col[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(A0[r], S.h[mt][r], col[0], 0, 0, 0);
+            col[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(A1[r], S.h[mt][r], col[1], 0, 0, 0);
+        }
+    }
+#else
     const float hv[8] = {S.h[2 * PP][0], S.h[2 * PP][1], S.h[2 * PP][2], S.h[2 * PP][3],
                          S.h[2 * PP + 1][0], S.h[2 * PP + 1][1], S.h[2 * PP + 1][2], S.h[2 * PP + 1][3]};
     h8 bh, bl;
@@ -653,6 +682,7 @@ __device__ __forceinline__ void decode_l2(const DecoderLds& L, int lane, const D
         col[ot] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bl, col[ot], 0, 0, 0);
         col[ot] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, bh, col[ot], 0, 0, 0);
     }
+#endif
     if (PP == 1) {
         const float ys = L.ys;
         if (ys != 1.0f) {
