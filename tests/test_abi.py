@@ -78,6 +78,23 @@ def test_argument_errors_are_reported_not_thrown():
     assert rc2 == -1 and b"bad argument" in lib.r3d_last_error()
     rc2 = lib.r3d_conv_forward(one, one, None, 1, 64, 32, 16, 16, 3, one, 0, 0, 0.0, 1.0, -1.0, one, 0, None, 0, None, one, 8, None)
     assert rc2 == -2 and b"workspace" in lib.r3d_last_error()
+    # the round-6 entry points: the fused blend conv and the conv that writes one part of a concatenation
+    rc2 = lib.r3d_conv_forward_blend(one, one, None, 1, 8, 40, 64, 4, 4, one, one, one, 0, 0.0, 1.0, -1.0, one, 0, None, 0, None, None)
+    assert rc2 == -1 and b"multiple of 64" in lib.r3d_last_error()
+    rc2 = lib.r3d_conv_forward_blend(one, one, None, 1, 32, 32, 64, 4, 4, one, None, one, 0, 0.0, 1.0, -1.0, one, 0, None, 0, None, None)
+    assert rc2 == -1 and b"bad argument" in lib.r3d_last_error()
+    rc2 = lib.r3d_conv_forward_blend(one, one, None, 1, 32, 32, 24, 4, 4, one, one, one, 0, 0.0, 1.0, -1.0, one, 3, None, 0, None, None)
+    assert rc2 == -1 and b"unsupported output" in lib.r3d_last_error()        # SPLIT_MX needs Cout % 16 == 0
+    rc2 = lib.r3d_conv_forward_cat(one, one, None, 1, 64, 256, 16, 16, 3, one, 0, 0, 0.0, 1.0, -1.0, one, 2, 512, 256, one, 1, None, 0, one, 1 << 40, None)
+    assert rc2 == -1 and b"1x1" in lib.r3d_last_error()
+    rc2 = lib.r3d_conv_forward_cat(one, one, None, 1, 64, 256, 16, 16, 1, one, 0, 0, 0.0, 1.0, -1.0, one, 2, 512, 264, one, 1, None, 0, one, 1 << 40, None)
+    assert rc2 == -1 and b"multiples of 16" in lib.r3d_last_error()
+    rc2 = lib.r3d_conv_forward_cat(one, one, None, 1, 64, 256, 16, 16, 1, one, 0, 0, 0.0, 1.0, -1.0, one, 0, 512, 256, one, 1, None, 0, one, 1 << 40, None)
+    assert rc2 == -1 and b"SPLIT" in lib.r3d_last_error()                     # the concatenated operand is SPLIT or SPLIT_MX
+    rc2 = lib.r3d_conv_forward_cat(one, one, None, 1, 64, 256, 16, 16, 1, one, 0, 0, 0.0, 1.0, -1.0, one, 2, 512, 256, one, 1, None, 0, one, 8, None)
+    assert rc2 == -2 and b"workspace" in lib.r3d_last_error()
+    rc2 = lib.r3d_blend_cat_to_split(one, 1, 8, None, 1, 8, one, 1, 4, 4, one, 2, None, 0, None)
+    assert rc2 == -1 and b"b = NULL" in lib.r3d_last_error()                  # writing only the `a` part needs whole 16-channel record groups
     # chain fold: a layer may only read the bound of an EARLIER op or of an external slot that exists
     op = _lib.ChainOp(kind=_lib.CHAIN_CONV, Cin=16, Cout=128, ksize=3, act=0, gain=1.0, clamp=-1.0, src_a=0, src_b=_lib.CHAIN_SRC_NONE,
                       scales=64, prepacked=64, bias=None)
