@@ -69,4 +69,37 @@ for c in range(ncase):
         err = max(err, np.abs(xo[n] - rx).max() / max(1.0, np.abs(rx).max()), np.abs(io[n] - ri).max() / max(1.0, np.abs(ri).max()))
     ok = err <= 2e-4; bad += not ok
     print("sr_block up=%d N=%d %d->%d %dx%d clamp=%s: rel err %.1e %s" % (up, Nb, Ci, Co, H, W, clamp, err, "ok" if ok else "FAIL"), flush=True)
-print("FUZZ: %d failures in %d cases" % (bad, 3 * ncase))
+    # ---- round 6: the fused blend + 1x1 conv (r3d_conv_forward_blend) vs fp64 and vs the two-step form, and a plain 3x3 conv on a Winograd-eligible shape -------------
+    from real3dportrait_amd.superresolution import _fold_single, blend_cat
+    Cs = 64 * int(rng.integers(1, 7)); Ca = 8 * int(rng.integers(1, Cs // 8)); Cb = Cs - Ca; Co = int(rng.choice([4, 12, 64, 128, 200])); H = int(rng.integers(1, 40)); W = int(rng.integers(1, 40))
+    Nb = int(rng.integers(1, 4)); slope = rng.choice([None, 0.01, 0.2]); kk = int(rng.integers(-12, 13))
+    a = synth.hash_unitvar(seed + 11, (Nb, Ca, H, W), stream=1) * np.float32(2.0 ** kk); b = synth.hash_unitvar(seed + 11, (Nb, Cb, H, W), stream=2) * np.float32(2.0 ** kk)
+    m = np.abs(synth.hash_unitvar(seed + 11, (Nb, 1, H, W), stream=3)).clip(0, 1).astype(np.float32)
+
+    def cb8(x):
+        t = T(x); n_, c_, h_, w_ = t.shape
+        y8 = t.view(n_, c_ // 8, 8, h_, w_).permute(0, 1, 3, 4, 2).contiguous(); y8._r3d_fmt = "cb8"
+        y8._r3d_bound, y8._r3d_depth = t.abs().amax(dim=(1, 2, 3)).contiguous(), 0
+        return y8
+    cv = Conv2d(Cs, Co, 1, 1, padding=0).cuda(); cv.precision = "f16x3"
+    with torch.no_grad():
+        cv.weight.copy_(T(synth.hash_unitvar(seed + 12, (Co, Cs, 1, 1), stream=2) / np.float32(np.sqrt(Cs)))); cv.bias.copy_(T(synth.hash_unitvar(seed + 12, (Co,), stream=3)))
+    a8, b8, mt = cb8(a), cb8(b), T(m)
+    _fold_single(cv, Nb, a8.device, [a8._r3d_bound, b8._r3d_bound], negative_slope=None if slope is None else float(slope))
+    y2 = cv(blend_cat(a8, b8, mt, cv, _folded_head=cv), negative_slope=None if slope is None else float(slope))
+    y1 = cv(None, negative_slope=None if slope is None else float(slope), _folded=True, _blend=(a8, b8, mt))
+    xd = torch.cat([torch.from_numpy(a).double() * torch.from_numpy(m).double(), torch.from_numpy(b).double() * (1 - torch.from_numpy(m).double())], dim=1)
+    r = torch.nn.functional.conv2d(xd, cv.weight.detach().double().cpu(), cv.bias.detach().double().cpu())
+    if slope is not None: r = torch.nn.functional.leaky_relu(r, float(slope))
+    err = (y1.cpu().double() - r).abs().max().item() / max(2.0 ** kk, r.abs().max().item()); same = torch.equal(y1, y2); ok = err <= 2e-6 and same; bad += not ok
+    print("blend_conv N=%d %d+%d->%d %dx%d slope=%s 2^%d: err %.1e bit-identical to two steps %s %s" % (Nb, Ca, Cb, Co, H, W, slope, kk, err, same, "ok" if ok else "FAIL"), flush=True)
+    Ci = 16 * int(rng.integers(1, 9)); Co = int(rng.choice([32, 128, 136, 256])); H = 16 * int(rng.integers(1, 5)); W = 16 * int(rng.integers(1, 5)); Nb = int(rng.integers(1, 3))
+    cv = Conv2d(Ci, Co, 3, 1, padding=1).cuda(); cv.precision = "f16x3"
+    x = T(synth.hash_unitvar(seed + 13, (Nb, Ci, H, W), stream=1) * np.float32(2.0 ** kk))
+    with torch.no_grad():
+        cv.weight.copy_(T(synth.hash_unitvar(seed + 14, (Co, Ci, 3, 3), stream=2) / np.float32(np.sqrt(Ci * 9)))); cv.bias.copy_(T(synth.hash_unitvar(seed + 14, (Co,), stream=3) * np.float32(2.0 ** kk)))
+    y = cv(x)
+    r = torch.nn.functional.conv2d(x.double().cpu(), cv.weight.detach().double().cpu(), cv.bias.detach().double().cpu(), padding=1)
+    err = (y.cpu().double() - r).abs().max().item() / r.abs().max().item(); ok = err <= 2e-6; bad += not ok
+    print("conv3x3 (Winograd-eligible) N=%d %d->%d %dx%d 2^%d: err %.1e %s" % (Nb, Ci, Co, H, W, kk, err, "ok" if ok else "FAIL"), flush=True)
+print("FUZZ: %d failures in %d cases" % (bad, 5 * ncase))
