@@ -270,7 +270,7 @@ def _forward_v2(self, S, rgb, x, ws, ref_torso_rgb, ref_bg_rgb, weights_img, seg
     chain_fold(ops + [b1.chain_op(last)], N, [m_x2, x_bg._r3d_bound], zero=[m_z])
     # f16mx: the last fusion conv leaves fp8 records for block1's up-sampling conv (R3D_FMT_SPLIT_MX), as block0 does in the head-only network
     zfmt = "split_mx" if b1.wants_mx() else "split"
-    if _FUSE_BLEND and fuse_fg.num_layers() > 1 and head.can_blend(x2, x_bg):
+    if _FUSE_BLEND and head.can_blend(x2, x_bg):
         # :113 inside the 1x1 conv of :114 (r3d_conv_forward_blend): the 512-channel concatenation is never written (bit-identical to the two-step form)
         z = fuse_fg(None, out_format=zfmt, _next=b1, _y_absmax=m_z, _blend=(x2, x_bg, pocc))
     else:

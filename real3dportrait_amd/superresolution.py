@@ -754,14 +754,15 @@ class ConvStack(nn.Sequential):
             # subnormal and the layer's cross products are noise (to_plane_cnn's last conv at full size: 3.4e-4 of max|ref| instead of 2.8e-5,
             # tests/test_gpu_mx.py) -- so a layer whose operand is more than MX_MAX_DEPTH layers from a measured bound runs f16x3.
             mx_next = nxt is not None and nxt.wants_mx() and m.out_channels % 16 == 0 and dx + k + 1 <= MX_MAX_DEPTH
+            bl = _blend if k == 0 else None
             if up:
-                x = upsample2x_bilinear(m(x, negative_slope=slope, out_format="cb8", _folded=True), "split_mx" if mx_next else "split", _next=nxt)
+                x = upsample2x_bilinear(m(x, negative_slope=slope, out_format="cb8", _folded=True, _blend=bl), "split_mx" if mx_next else "split", _next=nxt)
             elif nxt is not None and m.out_channels % 16 == 0:
-                x = m(x, negative_slope=slope, out_format="split_mx" if mx_next else "split", _next=nxt, _folded=True, _blend=_blend if k == 0 else None)
+                x = m(x, negative_slope=slope, out_format="split_mx" if mx_next else "split", _next=nxt, _folded=True, _blend=bl)
             elif nxt is not None:
                 raise NotImplementedError("ConvStack: inner layers need out_channels % 16 == 0")
             else:
-                x = m(x, negative_slope=slope, out_format=out_format, _next=_next, _folded=True, _y_absmax=_y_absmax)
+                x = m(x, negative_slope=slope, out_format=out_format, _next=_next, _folded=True, _y_absmax=_y_absmax, _blend=bl)
         return x
 
 
